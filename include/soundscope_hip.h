@@ -1,0 +1,217 @@
+/*
+ * soundscope_hip.h — C ABI of the MI355X-native soundscope analyzer hot path.
+ *
+ * This is the drop-in boundary for `pub struct Analyzer`
+ * (/root/reference/src/analyzer.rs:29-183).  Every Rust method of that type has
+ * exactly one entry point here with the same argument meaning and the same
+ * error behaviour; a Rust `analyzer.rs` that keeps the reference's signatures
+ * and forwards to these symbols is shown in INTEGRATION.md.  The arithmetic
+ * underneath runs in hand-written HIP kernels for gfx950 (soundscope_amd/csrc).
+ *
+ * Conventions
+ *   - plain C types only; host pointers unless a name says `_device`.
+ *   - every fallible call returns an `ss_status`; SS_OK == 0.  Nothing aborts.
+ *   - `(f64,f64)` vectors of the reference are written as interleaved doubles
+ *     `out_xy[2*i] = x, out_xy[2*i+1] = y` into caller-allocated storage.
+ *   - a handle is used by one thread at a time (the reference only ever calls
+ *     from the single TUI thread, src/main.rs:67-77); different handles are
+ *     independent (two coexist in the reference, src/tui.rs:459-460).
+ *   - there is NO CPU fallback: without a HIP device every compute entry point
+ *     returns SS_ERR_DEVICE.
+ */
+#ifndef SOUNDSCOPE_HIP_H
+#define SOUNDSCOPE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_ABI_VERSION 1
+
+typedef enum ss_status {
+    SS_OK = 0,
+    /* ebur128::Error (returned by add_samples / getters / create_loudness_meter) */
+    SS_ERR_NOMEM = 1,
+    SS_ERR_INVALID_MODE = 2,
+    SS_ERR_INVALID_CHANNEL = 3,
+    /* spectrum_analyzer::SpectrumAnalyzerError (returned by get_fft) */
+    SS_ERR_TOO_FEW_SAMPLES = 10,
+    SS_ERR_NAN = 11,
+    SS_ERR_INFINITY = 12,
+    SS_ERR_NOT_POW2 = 13,
+    SS_ERR_FREQ_LIMIT = 14,
+    SS_ERR_SCALING = 15,
+    /* this library */
+    SS_ERR_CAPACITY = 20,      /* caller buffer too small */
+    SS_ERR_UNSUPPORTED = 21,   /* e.g. FFT length > 32768 (the reference panics there) */
+    SS_ERR_INVALID_ARG = 22,
+    SS_ERR_DEVICE = 30         /* no HIP device / HIP runtime error */
+} ss_status;
+
+const char *ss_status_string(int status);
+int ss_abi_version(void);
+/* number of visible HIP devices (0 if none); ss_set_device binds the calling
+ * process's subsequent handle/batch creations to a device. */
+int ss_device_count(void);
+int ss_set_device(int device);
+/* last HIP runtime error text seen by this library on this thread ("" if none) */
+const char *ss_last_device_error(void);
+
+/* ------------------------------------------------------------------------ *
+ *  Analyzer mirror (one entry point per Rust method)
+ * ------------------------------------------------------------------------ */
+typedef struct ss_analyzer ss_analyzer;
+
+/* Analyzer::default() is ss_analyzer_create(2, 44100, &h)   analyzer.rs:34-45 */
+int ss_analyzer_create(uint32_t channels, uint32_t rate, ss_analyzer **out);
+/* Drop                                                                      */
+void ss_analyzer_destroy(ss_analyzer *h);
+/* create_loudness_meter(&mut self, channels, rate)           analyzer.rs:49-53
+ * sample_rate is updated BEFORE the fallible meter creation (rate sticks on error). */
+int ss_analyzer_configure(ss_analyzer *h, uint32_t channels, uint32_t rate);
+/* get_fft(&self, samples) -> Vec<(chart_x, dB)>              analyzer.rs:55-105
+ * n must be a power of two in [2, 32768]; cap_pairs >= n/2+1 is always enough. */
+int ss_get_fft(const ss_analyzer *h, const float *samples, size_t n,
+               double *out_xy, size_t cap_pairs, size_t *out_n);
+/* get_waveform(samples, waveform_window) — associated fn, no handle
+ *                                                            analyzer.rs:107-137
+ * out_xy receives (i,min),(i,max) pairs; cap_pairs >= 2*floor(window*1000). */
+int ss_get_waveform(const float *samples, size_t n, double waveform_window,
+                    double *out_xy, size_t cap_pairs, size_t *out_n);
+/* add_samples(&mut self, samples)                            analyzer.rs:139-141 */
+int ss_add_samples(ss_analyzer *h, const float *samples, size_t n);
+/* reset(&mut self)                                           analyzer.rs:143-145 */
+void ss_reset(ss_analyzer *h);
+/* get_shortterm_lufs / get_integrated_lufs / get_loudness_range
+ *                                                            analyzer.rs:147-157
+ * -inf is a valid SS_OK result (no blocks above the gate / silence). */
+int ss_get_shortterm_lufs(ss_analyzer *h, double *out);
+int ss_get_integrated_lufs(ss_analyzer *h, double *out);
+int ss_get_loudness_range(ss_analyzer *h, double *out);
+/* get_true_peak(&mut self) -> (left, right), linear amplitude analyzer.rs:159-164
+ * SS_ERR_INVALID_CHANNEL when the meter has fewer than 2 channels. */
+int ss_get_true_peak(ss_analyzer *h, double *left, double *right);
+/* sample_rate(&self)                                         analyzer.rs:166-168 */
+uint32_t ss_sample_rate(const ss_analyzer *h);
+/* calculate_integrated_lufs(&mut self, channels, samples) -> Option<f64>
+ *                                                            analyzer.rs:170-182
+ * SS_OK => Some(*out); any other status => None.  Uses the handle's
+ * sample_rate only; does not touch the handle's meter. */
+int ss_calculate_integrated_lufs(ss_analyzer *h, uint32_t channels,
+                                 const float *samples, size_t n, double *out);
+/* get_mid_and_side_samples(samples)                   audio_player.rs:400-419
+ * mid/side need n/2 floats each; *out_frames = n/2. */
+int ss_mid_side(const float *interleaved, size_t n, float *mid, float *side,
+                size_t *out_frames);
+
+/* extensions that the reference's ebur128 meter has under Mode::all() but the
+ * app does not surface */
+int ss_get_momentary_lufs(ss_analyzer *h, double *out);
+int ss_get_true_peak_channel(ss_analyzer *h, uint32_t channel, double *out);
+int ss_get_sample_peak_channel(ss_analyzer *h, uint32_t channel, double *out);
+/* true-peak oversampling: 0 = ebur128's rule (<96 kHz: 4x, <192 kHz: 2x, else
+ * off); 2 or 4 = forced (BASELINE config 5 asks for 4x at 96 kHz).  Takes
+ * effect at the next ss_analyzer_configure / ss_reset. */
+int ss_analyzer_set_true_peak_factor(ss_analyzer *h, int factor);
+
+/* ------------------------------------------------------------------------ *
+ *  Batch extension (NOT in the reference): many independent streams of equal
+ *  length analysed in one pass — the data-parallel form of
+ *  receive_audio_file + analyze_audio_file_samples (tui.rs:1207-1241,
+ *  :1482-1552) over a corpus.  Streams stay resident in HBM.
+ * ------------------------------------------------------------------------ */
+typedef struct ss_batch ss_batch;
+
+enum {
+    SS_BATCH_FFT = 1u,       /* per-window mid/side (2 ch) or per-channel spectrum */
+    SS_BATCH_LUFS = 2u,      /* K-weighting, gating blocks, histograms, I, LRA    */
+    SS_BATCH_TRUE_PEAK = 4u, /* sample peak + oversampled true peak               */
+    SS_BATCH_WAVEFORM = 8u,  /* min-max decimation of the interleaved buffer      */
+    SS_BATCH_ALL = 15u
+};
+
+typedef struct ss_batch_config {
+    uint32_t sample_rate;
+    uint32_t channels;          /* 2 => spectrum of mid/side (audio_player.rs:400-419);
+                                   otherwise per-channel spectrum */
+    uint32_t n_streams;
+    uint32_t fft_n;             /* window length (power of two, <= 32768) */
+    uint32_t hop_frames;        /* 1024 in the reference (audio_player.rs:65) */
+    uint32_t flags;             /* SS_BATCH_* */
+    int32_t true_peak_factor;   /* 0 = ebur128 rule, 2 / 4 = forced */
+    uint32_t reserved;
+    uint64_t frames_per_stream;
+    double waveform_window;     /* seconds; <= 0 => frames_per_stream / sample_rate */
+} ss_batch_config;
+
+typedef struct ss_stream_result {
+    double integrated_lufs;     /* loudness_global(), may be -inf            */
+    double loudness_range;      /* loudness_range()                          */
+    double true_peak[2];        /* channels 0,1: max(true, sample), linear   */
+    double sample_peak[2];
+    uint32_t n_gating_blocks;   /* 400 ms blocks evaluated                   */
+    uint32_t n_st_blocks;       /* 3 s blocks evaluated                      */
+} ss_stream_result;
+
+typedef struct ss_batch_layout {
+    uint32_t n_windows;         /* per stream */
+    uint32_t fft_channels;      /* 2 (mid, side) or channels */
+    uint32_t n_bins;            /* retained bins, 20 Hz..20 kHz */
+    uint32_t first_bin;         /* FFT bin index of retained bin 0 */
+    uint32_t n_wave_points;     /* per stream: 2 per decimation bin */
+    uint32_t n_subblocks;       /* complete 100 ms sub-blocks per stream */
+    uint64_t input_bytes;       /* device bytes of the input corpus */
+    uint64_t fft_bytes;         /* device bytes of the spectrum output */
+} ss_batch_layout;
+
+int ss_batch_create(const ss_batch_config *cfg, ss_batch **out);
+void ss_batch_destroy(ss_batch *b);
+int ss_batch_layout_get(const ss_batch *b, ss_batch_layout *out);
+/* copy host PCM into streams [first, first+count): interleaved f32,
+ * count*frames_per_stream*channels floats */
+int ss_batch_upload(ss_batch *b, uint32_t first, uint32_t count, const float *pcm);
+int ss_batch_download_input(ss_batch *b, uint32_t stream, float *pcm, size_t cap_floats);
+/* device pointer of the resident corpus ([stream][frame][channel] f32) for
+ * producers that already hold data on the GPU */
+void *ss_batch_input_device_ptr(ss_batch *b);
+/* fill the corpus with the documented synthetic signal: utility
+ * for benchmarks, not part of the measured path */
+int ss_batch_synthesize(ss_batch *b, uint64_t seed, uint32_t first_stream_id);
+/* enqueue one pass of the hot path over the whole batch; asynchronous */
+int ss_batch_run(ss_batch *b);
+int ss_batch_sync(ss_batch *b);
+/* results (after ss_batch_sync) */
+int ss_batch_results(ss_batch *b, ss_stream_result *out, uint32_t cap);
+/* spectrum of one stream: [n_windows][fft_channels][n_bins] f32 dB (pink-compensated) */
+int ss_batch_download_fft(ss_batch *b, uint32_t stream, float *out, size_t cap_floats);
+/* chart_x / frequency / pink compensation per retained bin (f64, n_bins each; any may be NULL) */
+int ss_batch_bin_tables(const ss_batch *b, double *chart_x, double *freq, double *pink_db);
+/* waveform of one stream: n_wave_points pairs (i, value) like get_waveform, as f32 values only:
+ * out[2*i] = min, out[2*i+1] = max of decimation bin i */
+int ss_batch_download_waveform(ss_batch *b, uint32_t stream, float *out, size_t cap_floats);
+/* K-weighted energy of the 100 ms sub-blocks of one stream: [n_subblocks][channels] f64 */
+int ss_batch_download_subblocks(ss_batch *b, uint32_t stream, double *out, size_t cap_doubles);
+/* corpus histograms summed over this batch's streams: 1000 block-energy bins
+ * followed by 1000 short-term bins (u64 each).  `_device` copies them into a
+ * caller-owned device buffer (e.g. the send buffer of an RCCL all-reduce). */
+int ss_batch_histograms(ss_batch *b, uint64_t *out2000);
+int ss_batch_histograms_device(ss_batch *b, void *dst_device_2000_u64);
+/* A7/A8 on a (summed / all-reduced) histogram: ebur128 loudness_global_multiple
+ * and loudness_range_multiple semantics.  Host-side, O(1000). */
+double ss_corpus_integrated_lufs(const uint64_t *block_hist1000);
+double ss_corpus_loudness_range(const uint64_t *st_hist1000);
+
+/* kernel timing with HIP events on the batch's own stream (for roofline
+ * reporting): enable, run N passes, then read accumulated per-kernel time. */
+enum { SS_KERNEL_FFT = 0, SS_KERNEL_TIME_DOMAIN = 1, SS_KERNEL_FINALIZE = 2, SS_KERNEL_WAVEFORM = 3, SS_KERNEL_COUNT = 4 };
+int ss_batch_timing_enable(ss_batch *b, int enable);
+int ss_batch_timing_read(ss_batch *b, int kernel, double *total_ms, uint64_t *launches);
+const char *ss_kernel_name(int kernel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOUNDSCOPE_HIP_H */

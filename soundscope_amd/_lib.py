@@ -1,0 +1,136 @@
+"""ctypes loader for the C-ABI library (include/soundscope_hip.h).
+
+The library is built in-tree by soundscope_amd/csrc/Makefile (hipcc, gfx950).
+There is no fallback of any kind: a missing library raises ImportError at load,
+and a missing GPU makes every compute entry point return SS_ERR_DEVICE, which
+the wrappers turn into DeviceError.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsoundscope_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+# every symbol include/soundscope_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "ss_status_string", "ss_abi_version", "ss_device_count", "ss_set_device", "ss_last_device_error",
+    "ss_analyzer_create", "ss_analyzer_destroy", "ss_analyzer_configure", "ss_get_fft", "ss_get_waveform",
+    "ss_add_samples", "ss_reset", "ss_get_shortterm_lufs", "ss_get_integrated_lufs", "ss_get_loudness_range",
+    "ss_get_true_peak", "ss_sample_rate", "ss_calculate_integrated_lufs", "ss_mid_side",
+    "ss_get_momentary_lufs", "ss_get_true_peak_channel", "ss_get_sample_peak_channel",
+    "ss_analyzer_set_true_peak_factor",
+    "ss_batch_create", "ss_batch_destroy", "ss_batch_layout_get", "ss_batch_upload", "ss_batch_download_input",
+    "ss_batch_input_device_ptr", "ss_batch_synthesize", "ss_batch_run", "ss_batch_sync", "ss_batch_results",
+    "ss_batch_download_fft", "ss_batch_bin_tables", "ss_batch_download_waveform", "ss_batch_download_subblocks",
+    "ss_batch_histograms", "ss_batch_histograms_device", "ss_corpus_integrated_lufs", "ss_corpus_loudness_range",
+    "ss_batch_timing_enable", "ss_batch_timing_read", "ss_kernel_name",
+]
+
+SS_OK = 0
+SS_ERR_NOMEM, SS_ERR_INVALID_MODE, SS_ERR_INVALID_CHANNEL = 1, 2, 3
+SS_ERR_TOO_FEW_SAMPLES, SS_ERR_NAN, SS_ERR_INFINITY, SS_ERR_NOT_POW2, SS_ERR_FREQ_LIMIT, SS_ERR_SCALING = 10, 11, 12, 13, 14, 15
+SS_ERR_CAPACITY, SS_ERR_UNSUPPORTED, SS_ERR_INVALID_ARG, SS_ERR_DEVICE = 20, 21, 22, 30
+
+SS_BATCH_FFT, SS_BATCH_LUFS, SS_BATCH_TRUE_PEAK, SS_BATCH_WAVEFORM, SS_BATCH_ALL = 1, 2, 4, 8, 15
+SS_KERNEL_FFT, SS_KERNEL_TIME_DOMAIN, SS_KERNEL_FINALIZE, SS_KERNEL_WAVEFORM, SS_KERNEL_COUNT = 0, 1, 2, 3, 4
+
+
+class BatchConfig(C.Structure):
+    _fields_ = [("sample_rate", C.c_uint32), ("channels", C.c_uint32), ("n_streams", C.c_uint32),
+                ("fft_n", C.c_uint32), ("hop_frames", C.c_uint32), ("flags", C.c_uint32),
+                ("true_peak_factor", C.c_int32), ("reserved", C.c_uint32),
+                ("frames_per_stream", C.c_uint64), ("waveform_window", C.c_double)]
+
+
+class StreamResult(C.Structure):
+    _fields_ = [("integrated_lufs", C.c_double), ("loudness_range", C.c_double),
+                ("true_peak", C.c_double * 2), ("sample_peak", C.c_double * 2),
+                ("n_gating_blocks", C.c_uint32), ("n_st_blocks", C.c_uint32)]
+
+
+class BatchLayout(C.Structure):
+    _fields_ = [("n_windows", C.c_uint32), ("fft_channels", C.c_uint32), ("n_bins", C.c_uint32),
+                ("first_bin", C.c_uint32), ("n_wave_points", C.c_uint32), ("n_subblocks", C.c_uint32),
+                ("input_bytes", C.c_uint64), ("fft_bytes", C.c_uint64)]
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.run(["make", "-C", CSRC], check=True, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def _bind(lib):
+    vp, f32p, f64p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double)
+    szp, u64p = C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)
+    sig = {
+        "ss_status_string": (C.c_char_p, [C.c_int]),
+        "ss_abi_version": (C.c_int, []),
+        "ss_device_count": (C.c_int, []),
+        "ss_set_device": (C.c_int, [C.c_int]),
+        "ss_last_device_error": (C.c_char_p, []),
+        "ss_analyzer_create": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(vp)]),
+        "ss_analyzer_destroy": (None, [vp]),
+        "ss_analyzer_configure": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
+        "ss_get_fft": (C.c_int, [vp, f32p, C.c_size_t, f64p, C.c_size_t, szp]),
+        "ss_get_waveform": (C.c_int, [f32p, C.c_size_t, C.c_double, f64p, C.c_size_t, szp]),
+        "ss_add_samples": (C.c_int, [vp, f32p, C.c_size_t]),
+        "ss_reset": (None, [vp]),
+        "ss_get_shortterm_lufs": (C.c_int, [vp, f64p]),
+        "ss_get_integrated_lufs": (C.c_int, [vp, f64p]),
+        "ss_get_loudness_range": (C.c_int, [vp, f64p]),
+        "ss_get_momentary_lufs": (C.c_int, [vp, f64p]),
+        "ss_get_true_peak": (C.c_int, [vp, f64p, f64p]),
+        "ss_get_true_peak_channel": (C.c_int, [vp, C.c_uint32, f64p]),
+        "ss_get_sample_peak_channel": (C.c_int, [vp, C.c_uint32, f64p]),
+        "ss_analyzer_set_true_peak_factor": (C.c_int, [vp, C.c_int]),
+        "ss_sample_rate": (C.c_uint32, [vp]),
+        "ss_calculate_integrated_lufs": (C.c_int, [vp, C.c_uint32, f32p, C.c_size_t, f64p]),
+        "ss_mid_side": (C.c_int, [f32p, C.c_size_t, f32p, f32p, szp]),
+        "ss_batch_create": (C.c_int, [C.POINTER(BatchConfig), C.POINTER(vp)]),
+        "ss_batch_destroy": (None, [vp]),
+        "ss_batch_layout_get": (C.c_int, [vp, C.POINTER(BatchLayout)]),
+        "ss_batch_upload": (C.c_int, [vp, C.c_uint32, C.c_uint32, f32p]),
+        "ss_batch_download_input": (C.c_int, [vp, C.c_uint32, f32p, C.c_size_t]),
+        "ss_batch_input_device_ptr": (vp, [vp]),
+        "ss_batch_synthesize": (C.c_int, [vp, C.c_uint64, C.c_uint32]),
+        "ss_batch_run": (C.c_int, [vp]),
+        "ss_batch_sync": (C.c_int, [vp]),
+        "ss_batch_results": (C.c_int, [vp, C.POINTER(StreamResult), C.c_uint32]),
+        "ss_batch_download_fft": (C.c_int, [vp, C.c_uint32, f32p, C.c_size_t]),
+        "ss_batch_bin_tables": (C.c_int, [vp, f64p, f64p, f64p]),
+        "ss_batch_download_waveform": (C.c_int, [vp, C.c_uint32, f32p, C.c_size_t]),
+        "ss_batch_download_subblocks": (C.c_int, [vp, C.c_uint32, f64p, C.c_size_t]),
+        "ss_batch_histograms": (C.c_int, [vp, u64p]),
+        "ss_batch_histograms_device": (C.c_int, [vp, vp]),
+        "ss_corpus_integrated_lufs": (C.c_double, [u64p]),
+        "ss_corpus_loudness_range": (C.c_double, [u64p]),
+        "ss_batch_timing_enable": (C.c_int, [vp, C.c_int]),
+        "ss_batch_timing_read": (C.c_int, [vp, C.c_int, f64p, u64p]),
+        "ss_kernel_name": (C.c_char_p, [C.c_int]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_LIB = None
+
+
+def lib():
+    """The loaded library.  Raises ImportError if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C soundscope_amd/csrc`). "
+                "soundscope_amd has no CPU fallback.")
+        _LIB = _bind(C.CDLL(LIB_PATH))
+    return _LIB

@@ -1,0 +1,124 @@
+"""Batch extension: many equal-length streams resident in HBM, analysed in one pass.
+
+Not part of the reference API (soundscope analyses one file at a time); it is the
+data-parallel form of receive_audio_file + analyze_audio_file_samples
+(reference src/tui.rs:1207-1241, :1482-1552) over a corpus.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .analyzer import _check
+
+
+class Batch:
+    def __init__(self, sample_rate=48000, channels=2, n_streams=1, frames_per_stream=480000,
+                 fft_n=4096, hop_frames=1024, flags=L.SS_BATCH_ALL, true_peak_factor=0,
+                 waveform_window=0.0):
+        cfg = L.BatchConfig(sample_rate, channels, n_streams, fft_n, hop_frames, flags, true_peak_factor, 0,
+                            frames_per_stream, waveform_window)
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        rc = L.lib().ss_batch_create(C.byref(cfg), C.byref(self._h))
+        if rc != L.SS_OK:
+            self._h = None
+            _check(rc)
+        lay = L.BatchLayout()
+        _check(L.lib().ss_batch_layout_get(self._h, C.byref(lay)))
+        self.layout = lay
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().ss_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def samples_per_stream(self):
+        return int(self.cfg.frames_per_stream) * int(self.cfg.channels)
+
+    def upload(self, first, pcm):
+        a = np.ascontiguousarray(pcm, dtype=np.float32)
+        count = a.size // self.samples_per_stream
+        assert count * self.samples_per_stream == a.size
+        _check(L.lib().ss_batch_upload(self._h, first, count, a.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def download_input(self, stream):
+        out = np.empty(self.samples_per_stream, np.float32)
+        _check(L.lib().ss_batch_download_input(self._h, stream, out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
+        return out
+
+    def input_device_ptr(self):
+        return L.lib().ss_batch_input_device_ptr(self._h)
+
+    def synthesize(self, seed=0x5EED0000, first_stream_id=0):
+        _check(L.lib().ss_batch_synthesize(self._h, seed, first_stream_id))
+
+    def run(self):
+        _check(L.lib().ss_batch_run(self._h))
+
+    def sync(self):
+        _check(L.lib().ss_batch_sync(self._h))
+
+    def results(self):
+        n = int(self.cfg.n_streams)
+        arr = (L.StreamResult * n)()
+        _check(L.lib().ss_batch_results(self._h, arr, n))
+        return arr
+
+    def fft(self, stream):
+        lay = self.layout
+        out = np.empty((lay.n_windows, lay.fft_channels, lay.n_bins), np.float32)
+        _check(L.lib().ss_batch_download_fft(self._h, stream, out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
+        return out
+
+    def bin_tables(self):
+        n = self.layout.n_bins
+        x, f, p = (np.empty(n, np.float64) for _ in range(3))
+        dp = C.POINTER(C.c_double)
+        _check(L.lib().ss_batch_bin_tables(self._h, x.ctypes.data_as(dp), f.ctypes.data_as(dp), p.ctypes.data_as(dp)))
+        return x, f, p
+
+    def waveform(self, stream):
+        pts = self.layout.n_wave_points
+        out = np.empty(pts, np.float32)
+        _check(L.lib().ss_batch_download_waveform(self._h, stream, out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
+        return out.reshape(-1, 2)          # [bin] -> (min, max)
+
+    def subblocks(self, stream):
+        n = self.layout.n_subblocks
+        out = np.empty((n, int(self.cfg.channels)), np.float64)
+        _check(L.lib().ss_batch_download_subblocks(self._h, stream, out.ctypes.data_as(C.POINTER(C.c_double)), out.size))
+        return out
+
+    def histograms(self):
+        out = np.empty(2000, np.uint64)
+        _check(L.lib().ss_batch_histograms(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out[:1000].copy(), out[1000:].copy()
+
+    def histograms_to_device(self, dev_ptr):
+        _check(L.lib().ss_batch_histograms_device(self._h, C.c_void_p(dev_ptr)))
+
+    def timing_enable(self, on=True):
+        _check(L.lib().ss_batch_timing_enable(self._h, 1 if on else 0))
+
+    def timing_read(self, kernel):
+        ms, n = C.c_double(), C.c_uint64()
+        _check(L.lib().ss_batch_timing_read(self._h, kernel, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def corpus_integrated_lufs(block_hist):
+    h = np.ascontiguousarray(block_hist, dtype=np.uint64)
+    return L.lib().ss_corpus_integrated_lufs(h.ctypes.data_as(C.POINTER(C.c_uint64)))
+
+
+def corpus_loudness_range(st_hist):
+    h = np.ascontiguousarray(st_hist, dtype=np.uint64)
+    return L.lib().ss_corpus_loudness_range(h.ctypes.data_as(C.POINTER(C.c_uint64)))

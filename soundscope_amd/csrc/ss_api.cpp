@@ -1,0 +1,1090 @@
+// ss_api.cpp — C ABI of include/soundscope_hip.h on top of the gfx950 kernels.
+// Host logic only: argument validation with the reference's error order,
+// device-resident state management, table caches, launches.  No CPU compute path.
+#include "../../include/soundscope_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "ss_kernels.h"
+#include "ss_tables.h"
+
+namespace {
+
+thread_local std::string g_last_err;
+
+bool hip_ok(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return true;
+    g_last_err = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+}
+#define HIPCHK(expr)                                   \
+    do {                                               \
+        if (!hip_ok((expr), #expr)) return SS_ERR_DEVICE; \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+    }
+    hipError_t alloc(size_t count)
+    {
+        release();
+        if (!count) return hipSuccess;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    hipError_t ensure(size_t count) { return count <= n ? hipSuccess : alloc(count); }
+    hipError_t upload(const std::vector<T> &h)
+    {
+        hipError_t e = alloc(h.size());
+        if (e != hipSuccess || h.empty()) return e;
+        return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+// ---- per-process caches of device-resident constant tables ------------------
+struct FftTables {
+    size_t n = 0;
+    std::vector<float> window_host;
+    DevBuf<float> window, half_window;
+    DevBuf<float2> tw_n, tw_256;
+};
+
+struct BinTables {
+    size_t first = 0, count = 0;
+    std::vector<double> freq, pink, chart_x;
+    DevBuf<float> pink_dev;
+};
+
+struct TdTables {
+    ssk::TdConst host;
+    DevBuf<ssk::TdConst> dev;
+};
+
+struct Ctx {
+    std::mutex mu;
+    bool probed = false;
+    int n_devices = 0;
+    std::map<size_t, std::unique_ptr<FftTables>> fft;
+    std::map<std::pair<uint32_t, size_t>, std::unique_ptr<BinTables>> bins;
+    std::map<std::pair<uint32_t, int>, std::unique_ptr<TdTables>> td;
+    DevBuf<double> hist_energies, hist_bounds;
+    // scratch for the handle-less entry points (ss_get_waveform, ss_mid_side)
+    DevBuf<float> scratch_in, scratch_out;
+    hipStream_t scratch_stream = nullptr;
+};
+
+Ctx &ctx()
+{
+    static Ctx c;
+    return c;
+}
+
+int probe_devices()
+{
+    Ctx &c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (!c.probed) {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess) { g_last_err = std::string("hipGetDeviceCount: ") + hipGetErrorString(e); n = 0; }
+        c.n_devices = n;
+        c.probed = true;
+    }
+    return c.n_devices;
+}
+
+int require_device()
+{
+    if (probe_devices() <= 0) {
+        if (g_last_err.empty()) g_last_err = "no HIP device visible";
+        return SS_ERR_DEVICE;
+    }
+    return SS_OK;
+}
+
+int get_fft_tables(size_t n, FftTables **out)
+{
+    Ctx &c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    auto it = c.fft.find(n);
+    if (it != c.fft.end()) { *out = it->second.get(); return SS_OK; }
+    auto t = std::make_unique<FftTables>();
+    t->n = n;
+    t->window_host = sst::hann_window(n);
+    std::vector<float> half(n);
+    for (size_t i = 0; i < n; i++) half[i] = 0.5f * t->window_host[i];
+    HIPCHK(t->window.upload(t->window_host));
+    HIPCHK(t->half_window.upload(half));
+    std::vector<float> tw;
+    // the 4096 kernel indexes W_N^(t*ka) up to 255*15; the generic kernel k < N/2
+    sst::twiddles(n, n == 4096 ? n : (n / 2 ? n / 2 : 1), tw);
+    std::vector<float2> tw2(tw.size() / 2);
+    for (size_t i = 0; i < tw2.size(); i++) tw2[i] = make_float2(tw[2 * i], tw[2 * i + 1]);
+    HIPCHK(t->tw_n.upload(tw2));
+    if (n == 4096) {
+        sst::twiddles(256, 256, tw);
+        std::vector<float2> t256(256);
+        for (size_t i = 0; i < 256; i++) t256[i] = make_float2(tw[2 * i], tw[2 * i + 1]);
+        HIPCHK(t->tw_256.upload(t256));
+    }
+    *out = t.get();
+    c.fft[n] = std::move(t);
+    return SS_OK;
+}
+
+int get_bin_tables(uint32_t rate, size_t n, BinTables **out)
+{
+    Ctx &c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    auto key = std::make_pair(rate, n);
+    auto it = c.bins.find(key);
+    if (it != c.bins.end()) { *out = it->second.get(); return SS_OK; }
+    auto t = std::make_unique<BinTables>();
+    t->count = sst::fft_bins(rate, n, &t->first);
+    sst::bin_tables(rate, n, t->freq, t->pink, t->chart_x);
+    std::vector<float> pf(t->count);
+    for (size_t i = 0; i < t->count; i++) pf[i] = (float)t->pink[i];
+    HIPCHK(t->pink_dev.upload(pf));
+    *out = t.get();
+    c.bins[key] = std::move(t);
+    return SS_OK;
+}
+
+int get_td_tables(uint32_t rate, int factor, TdTables **out)
+{
+    Ctx &c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    auto key = std::make_pair(rate, factor);
+    auto it = c.td.find(key);
+    if (it != c.td.end()) { *out = it->second.get(); return SS_OK; }
+    auto t = std::make_unique<TdTables>();
+    ssk::TdConst &k = t->host;
+    std::memset(&k, 0, sizeof k);
+    sst::kweight_design((double)rate, k.b, k.a);
+    for (int s = 0; s < 8; s++) sst::kweight_transition_pow(k.a, (uint64_t)ssk::kTdChunk << s, k.m_pow[s]);
+    k.tp_factor = factor;
+    k.tp_len = 0;
+    if (factor) {
+        std::vector<std::vector<sst::PolyTap>> ph; int delay;
+        sst::true_peak_design(factor, ph, &delay);
+        // branch 0 is the identity tap (x[n - 6] * 1.0 / x[n - 12] * 1.0): it can only
+        // reproduce the sample peak, which true_peak() maxes in anyway.
+        k.tp_len = factor == 4 ? 12 : 24;
+        for (int f = 1; f < factor; f++)
+            for (const auto &tap : ph[f]) k.tp[f - 1][tap.delay] = tap.coeff;
+    }
+    k.s100 = (rate + 5) / 10;
+    std::vector<ssk::TdConst> v(1, k);
+    HIPCHK(t->dev.upload(v));
+    *out = t.get();
+    c.td[key] = std::move(t);
+    return SS_OK;
+}
+
+int get_hist_tables(const double **energies, const double **bounds)
+{
+    Ctx &c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (!c.hist_energies.p) {
+        std::vector<double> e(sst::kHistBins), b(sst::kHistBins + 1);
+        sst::histogram_tables(e.data(), b.data());
+        HIPCHK(c.hist_energies.upload(e));
+        HIPCHK(c.hist_bounds.upload(b));
+    }
+    *energies = c.hist_energies.p;
+    *bounds = c.hist_bounds.p;
+    return SS_OK;
+}
+
+bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+
+int meter_args_ok(uint32_t channels, uint32_t rate)
+{
+    // EbuR128::new: channels == 0 || > 64, rate < 16 || > 2_822_400 -> Error::NoMem
+    if (channels == 0 || channels > 64) return SS_ERR_NOMEM;
+    if (rate < 16 || rate > 2822400) return SS_ERR_NOMEM;
+    // sub-blocks shorter than one chunk are not supported by the chunked recurrence
+    if ((rate + 5) / 10 < (uint32_t)ssk::kTdChunk) return SS_ERR_UNSUPPORTED;
+    return SS_OK;
+}
+
+}  // namespace
+
+// ============================================================================
+//  handle
+// ============================================================================
+struct ss_analyzer {
+    uint32_t channels = 0, rate = 0;
+    int tp_cfg = 0;            // 0 = crate rule
+    int tp_factor = 0;         // effective
+    bool meter_ok = false;
+    hipStream_t stream = nullptr;
+    TdTables *td = nullptr;
+    DevBuf<ssk::TdState> state;
+    DevBuf<uint64_t> hist;          // 2 x 1000
+    DevBuf<double> sub;             // kSubCap x C
+    DevBuf<double> ring;            // ring_frames x C
+    DevBuf<double> weights;
+    DevBuf<uint32_t> counts;
+    DevBuf<double> out2;
+    DevBuf<float> in, fft_out;
+    uint64_t ring_frames = 0;
+    uint64_t frames_fed = 0;
+    static constexpr uint32_t kSubCap = 96;
+};
+
+namespace {
+
+int handle_make_meter(ss_analyzer *h, uint32_t channels, uint32_t rate)
+{
+    h->meter_ok = false;
+    int rc = meter_args_ok(channels, rate);
+    if (rc) return rc;
+    h->channels = channels;
+    h->tp_factor = h->tp_cfg ? h->tp_cfg : sst::true_peak_factor_for_rate(rate);
+    rc = get_td_tables(rate, h->tp_factor, &h->td);
+    if (rc) return rc;
+    const uint64_t s100 = (rate + 5) / 10;
+    uint64_t ring_frames = (uint64_t)rate * 3000 / 1000;
+    if (ring_frames % s100) ring_frames += s100 - ring_frames % s100;
+    h->ring_frames = ring_frames;
+    HIPCHK(h->state.alloc(1));
+    HIPCHK(h->hist.alloc(2 * sst::kHistBins));
+    HIPCHK(h->sub.alloc((size_t)ss_analyzer::kSubCap * channels));
+    HIPCHK(h->ring.alloc(ring_frames * channels));
+    HIPCHK(h->counts.alloc(2));
+    HIPCHK(h->out2.alloc(2));
+    std::vector<double> w(channels);
+    sst::channel_weights(channels, w.data());
+    HIPCHK(h->weights.upload(w));
+    h->meter_ok = true;
+    return SS_OK;
+}
+
+int handle_reset(ss_analyzer *h)
+{
+    if (!h->meter_ok) return SS_OK;
+    HIPCHK(hipMemsetAsync(h->state.p, 0, sizeof(ssk::TdState), h->stream));
+    HIPCHK(hipMemsetAsync(h->hist.p, 0, h->hist.n * sizeof(uint64_t), h->stream));
+    HIPCHK(hipMemsetAsync(h->sub.p, 0, h->sub.n * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(h->ring.p, 0, h->ring.n * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(h->counts.p, 0, 2 * sizeof(uint32_t), h->stream));
+    h->frames_fed = 0;
+    return SS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *ss_status_string(int s)
+{
+    switch (s) {
+        case SS_OK: return "ok";
+        case SS_ERR_NOMEM: return "ebur128: NoMem";
+        case SS_ERR_INVALID_MODE: return "ebur128: InvalidMode";
+        case SS_ERR_INVALID_CHANNEL: return "ebur128: InvalidChannelIndex";
+        case SS_ERR_TOO_FEW_SAMPLES: return "spectrum-analyzer: TooFewSamples";
+        case SS_ERR_NAN: return "spectrum-analyzer: NaNValuesNotSupported";
+        case SS_ERR_INFINITY: return "spectrum-analyzer: InfinityValuesNotSupported";
+        case SS_ERR_NOT_POW2: return "spectrum-analyzer: SamplesLengthNotAPowerOfTwo";
+        case SS_ERR_FREQ_LIMIT: return "spectrum-analyzer: InvalidFrequencyLimit";
+        case SS_ERR_SCALING: return "spectrum-analyzer: ScalingError";
+        case SS_ERR_CAPACITY: return "output buffer too small";
+        case SS_ERR_UNSUPPORTED: return "unsupported configuration";
+        case SS_ERR_INVALID_ARG: return "invalid argument";
+        case SS_ERR_DEVICE: return "HIP device error";
+        default: return "unknown status";
+    }
+}
+
+int ss_abi_version(void) { return SS_ABI_VERSION; }
+int ss_device_count(void) { return probe_devices(); }
+int ss_set_device(int device)
+{
+    if (require_device()) return SS_ERR_DEVICE;
+    HIPCHK(hipSetDevice(device));
+    return SS_OK;
+}
+const char *ss_last_device_error(void) { return g_last_err.c_str(); }
+
+int ss_analyzer_create(uint32_t channels, uint32_t rate, ss_analyzer **out)
+{
+    if (!out) return SS_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (require_device()) return SS_ERR_DEVICE;
+    auto h = std::make_unique<ss_analyzer>();
+    h->rate = rate;
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(h->in.alloc(32768));
+    HIPCHK(h->fft_out.alloc(16385));
+    int rc = handle_make_meter(h.get(), channels, rate);
+    if (rc) { (void)hipStreamDestroy(h->stream); return rc; }
+    rc = handle_reset(h.get());
+    if (rc) { (void)hipStreamDestroy(h->stream); return rc; }
+    *out = h.release();
+    return SS_OK;
+}
+
+void ss_analyzer_destroy(ss_analyzer *h)
+{
+    if (!h) return;
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    delete h;
+}
+
+int ss_analyzer_configure(ss_analyzer *h, uint32_t channels, uint32_t rate)
+{
+    if (!h) return SS_ERR_INVALID_ARG;
+    h->rate = rate;                         // analyzer.rs:50: before the fallible call
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int rc = handle_make_meter(h, channels, rate);
+    if (rc) return rc;
+    return handle_reset(h);
+}
+
+int ss_analyzer_set_true_peak_factor(ss_analyzer *h, int factor)
+{
+    if (!h || (factor != 0 && factor != 2 && factor != 4)) return SS_ERR_INVALID_ARG;
+    h->tp_cfg = factor;
+    return SS_OK;
+}
+
+int ss_get_fft(const ss_analyzer *hc, const float *samples, size_t n,
+               double *out_xy, size_t cap_pairs, size_t *out_n)
+{
+    ss_analyzer *h = const_cast<ss_analyzer *>(hc);
+    if (out_n) *out_n = 0;
+    if (!h || (!samples && n) || !out_xy) return SS_ERR_INVALID_ARG;
+    // samples_fft_to_spectrum checks, in the crate's order, applied to the
+    // windowed samples (hann_window runs first, analyzer.rs:57)
+    if (n < 2) return SS_ERR_TOO_FEW_SAMPLES;
+    const bool pow2 = is_pow2(n);
+    if (n > 32768 && pow2) return SS_ERR_UNSUPPORTED;
+    {
+        // w[i] == 0 turns an infinite sample into NaN (0 * inf); only the first few
+        // window entries can be exactly zero
+        bool any_nan = false, any_inf = false;
+        const std::vector<float> *win = nullptr;
+        std::vector<float> win_local;
+        for (size_t i = 0; i < n; i++) {
+            const float x = samples[i];
+            if (std::isnan(x)) { any_nan = true; continue; }
+            if (!std::isinf(x)) continue;
+            if (!win) {
+                if (pow2) {
+                    FftTables *wt = nullptr;
+                    int rc = get_fft_tables(n, &wt);
+                    if (rc) return rc;
+                    win = &wt->window_host;
+                } else {
+                    win_local = sst::hann_window(n);
+                    win = &win_local;
+                }
+            }
+            if ((*win)[i] == 0.0f) any_nan = true; else any_inf = true;
+        }
+        if (any_nan) return SS_ERR_NAN;
+        if (any_inf) return SS_ERR_INFINITY;
+    }
+    if (!pow2) return SS_ERR_NOT_POW2;
+    if (20000.0f > (float)h->rate / 2.0f) return SS_ERR_FREQ_LIMIT;
+
+    FftTables *ft; BinTables *bt;
+    int rc = get_fft_tables(n, &ft);
+    if (rc) return rc;
+    rc = get_bin_tables(h->rate, n, &bt);
+    if (rc) return rc;
+    if (bt->count > cap_pairs) return SS_ERR_CAPACITY;
+    if (bt->count == 0) return SS_OK;
+
+    HIPCHK(hipMemcpyAsync(h->in.p, samples, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    ssk::FftBatchParams p{};
+    p.pcm = h->in.p; p.out = h->fft_out.p;
+    p.window = ft->window.p; p.half_window = ft->half_window.p;
+    p.tw_n = ft->tw_n.p; p.tw_256 = ft->tw_256.p; p.pink = nullptr;
+    p.frames_per_stream = n; p.first_start = 0; p.n_streams = 1; p.channels = 1;
+    p.n_windows = 1; p.hop = 0; p.n = (uint32_t)n;
+    p.first_bin = (uint32_t)bt->first; p.n_bins = (uint32_t)bt->count; p.windows_per_block = 1;
+    p.db_offset = (float)(20.0 * std::log10(4.0 / (double)n));
+    HIPCHK(ssk::launch_fft_generic(p, 0, h->stream));
+    std::vector<float> db(bt->count);
+    HIPCHK(hipMemcpyAsync(db.data(), h->fft_out.p, bt->count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < bt->count; i++)
+        if (std::isnan(db[i]) || std::isinf(db[i])) return SS_ERR_SCALING;
+    // analyzer.rs:75-102 in f64: + pink compensation, log-x chart position
+    for (size_t i = 0; i < bt->count; i++) {
+        out_xy[2 * i] = bt->chart_x[i];
+        out_xy[2 * i + 1] = (double)db[i] + bt->pink[i];
+    }
+    if (out_n) *out_n = bt->count;
+    return SS_OK;
+}
+
+int ss_get_waveform(const float *samples, size_t n, double waveform_window,
+                    double *out_xy, size_t cap_pairs, size_t *out_n)
+{
+    if (out_n) *out_n = 0;
+    if ((!samples && n) || (!out_xy && cap_pairs)) return SS_ERR_INVALID_ARG;
+    if (require_device()) return SS_ERR_DEVICE;
+    const double wd = waveform_window * 1000.0;
+    // Rust `as usize`: saturating, NaN -> 0
+    size_t window = (wd != wd || wd <= 0.0) ? 0 : (wd >= 1.8446744073709552e19 ? SIZE_MAX : (size_t)wd);
+    if (window == 0 || n == 0) return SS_OK;        // loop body never pushes a point
+    // bins with start < n produce points; start = floor(i * spp) is monotone
+    const double spp = (double)n / (double)window;
+    size_t bins = window;
+    if (window > n) {
+        // first i with floor(i*spp) >= n
+        size_t lo = 0, hi = window;
+        while (lo < hi) {
+            size_t mid = lo + (hi - lo) / 2;
+            if ((size_t)((double)mid * spp) >= n) hi = mid; else lo = mid + 1;
+        }
+        bins = lo;
+    }
+    if (bins > 0xFFFFFFFFull) return SS_ERR_UNSUPPORTED;
+    if (2 * bins > cap_pairs) return SS_ERR_CAPACITY;
+    Ctx &c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (!c.scratch_stream) HIPCHK(hipStreamCreateWithFlags(&c.scratch_stream, hipStreamNonBlocking));
+    HIPCHK(c.scratch_in.ensure(n));
+    HIPCHK(c.scratch_out.ensure(2 * bins));
+    HIPCHK(hipMemcpyAsync(c.scratch_in.p, samples, n * sizeof(float), hipMemcpyHostToDevice, c.scratch_stream));
+    ssk::WaveParams p{};
+    p.pcm = c.scratch_in.p; p.stream_stride = n; p.n_samples = n; p.n_streams = 1;
+    p.window = (uint32_t)window; p.out = c.scratch_out.p; p.out_stride = 2 * bins;
+    if (window > 0xFFFFFFFFull) return SS_ERR_UNSUPPORTED;
+    HIPCHK(ssk::launch_waveform(p, c.scratch_stream));
+    std::vector<float> mm(2 * bins);
+    HIPCHK(hipMemcpyAsync(mm.data(), c.scratch_out.p, 2 * bins * sizeof(float), hipMemcpyDeviceToHost, c.scratch_stream));
+    HIPCHK(hipStreamSynchronize(c.scratch_stream));
+    for (size_t i = 0; i < bins; i++) {
+        out_xy[4 * i + 0] = (double)i; out_xy[4 * i + 1] = (double)mm[2 * i];
+        out_xy[4 * i + 2] = (double)i; out_xy[4 * i + 3] = (double)mm[2 * i + 1];
+    }
+    if (out_n) *out_n = 2 * bins;
+    return SS_OK;
+}
+
+int ss_mid_side(const float *interleaved, size_t n, float *mid, float *side, size_t *out_frames)
+{
+    if (out_frames) *out_frames = 0;
+    const size_t frames = n / 2;
+    if (!frames) return SS_OK;
+    if (!interleaved || !mid || !side) return SS_ERR_INVALID_ARG;
+    if (require_device()) return SS_ERR_DEVICE;
+    Ctx &c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (!c.scratch_stream) HIPCHK(hipStreamCreateWithFlags(&c.scratch_stream, hipStreamNonBlocking));
+    HIPCHK(c.scratch_in.ensure(2 * frames));
+    HIPCHK(c.scratch_out.ensure(2 * frames));
+    HIPCHK(hipMemcpyAsync(c.scratch_in.p, interleaved, 2 * frames * sizeof(float), hipMemcpyHostToDevice, c.scratch_stream));
+    HIPCHK(ssk::launch_mid_side(c.scratch_in.p, frames, c.scratch_out.p, c.scratch_out.p + frames, c.scratch_stream));
+    HIPCHK(hipMemcpyAsync(mid, c.scratch_out.p, frames * sizeof(float), hipMemcpyDeviceToHost, c.scratch_stream));
+    HIPCHK(hipMemcpyAsync(side, c.scratch_out.p + frames, frames * sizeof(float), hipMemcpyDeviceToHost, c.scratch_stream));
+    HIPCHK(hipStreamSynchronize(c.scratch_stream));
+    if (out_frames) *out_frames = frames;
+    return SS_OK;
+}
+
+int ss_add_samples(ss_analyzer *h, const float *samples, size_t n)
+{
+    if (!h) return SS_ERR_INVALID_ARG;
+    if (!h->meter_ok) return SS_ERR_INVALID_MODE;
+    if (n == 0) return SS_OK;
+    if (!samples) return SS_ERR_INVALID_ARG;
+    const uint32_t C = h->channels;
+    if (n % C) return SS_ERR_NOMEM;             // add_frames_f32: partial frame
+    const uint64_t S = h->td->host.s100;
+    const double *he, *hb;
+    int rc = get_hist_tables(&he, &hb);
+    if (rc) return rc;
+    // pieces of at most 32 sub-blocks so the sub-block ring (96) always holds the
+    // 30-block history a short-term block needs
+    const uint64_t piece_frames = 32 * S;
+    uint64_t frames = n / C, done = 0;
+    while (done < frames) {
+        const uint64_t take = frames - done < piece_frames ? frames - done : piece_frames;
+        HIPCHK(h->in.ensure(take * C));
+        HIPCHK(hipMemcpyAsync(h->in.p, samples + done * C, take * C * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        ssk::TdParams p{};
+        p.pcm = h->in.p; p.stream_stride = 0; p.n_frames = take; p.n_streams = 1; p.channels = C;
+        p.k = h->td->dev.p; p.state = h->state.p;
+        p.subblocks = h->sub.p; p.sub_stride = 0; p.sub_cap = ss_analyzer::kSubCap;
+        p.ring = h->ring.p; p.ring_frames = h->ring_frames; p.tp_factor = h->tp_factor;
+        HIPCHK(ssk::launch_time_domain(p, h->stream));
+        const uint64_t sb0 = h->frames_fed / S, sb1 = (h->frames_fed + take) / S;
+        if (sb1 > sb0) {
+            ssk::FinalizeParams f{};
+            f.k = h->td->dev.p; f.subblocks = h->sub.p; f.sub_stride = 0; f.sub_cap = ss_analyzer::kSubCap;
+            f.hist_energies = he; f.hist_bounds = hb; f.weights = h->weights.p;
+            f.hist = h->hist.p; f.corpus_hist = nullptr; f.n_streams = 1; f.channels = C;
+            f.sub_begin = sb0; f.sub_end = sb1;
+            f.out_integrated = nullptr; f.out_lra = nullptr; f.out_counts = h->counts.p;
+            HIPCHK(ssk::launch_finalize(f, h->stream));
+        }
+        // the staging buffer is reused by the next piece
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->frames_fed += take;
+        done += take;
+    }
+    return SS_OK;
+}
+
+void ss_reset(ss_analyzer *h)
+{
+    if (h) (void)handle_reset(h);
+}
+
+static int ring_loudness(ss_analyzer *h, uint64_t frames, double *out)
+{
+    if (!h || !out) return SS_ERR_INVALID_ARG;
+    if (!h->meter_ok) return SS_ERR_INVALID_MODE;
+    if (frames > h->ring_frames) return SS_ERR_INVALID_MODE;
+    HIPCHK(ssk::launch_ring_energy(h->ring.p, h->ring_frames, h->channels, h->frames_fed, frames,
+                                   h->weights.p, h->out2.p, h->stream));
+    double r[2];
+    HIPCHK(hipMemcpyAsync(r, h->out2.p, sizeof r, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *out = r[1];
+    return SS_OK;
+}
+
+int ss_get_shortterm_lufs(ss_analyzer *h, double *out)
+{
+    if (!h || !h->meter_ok) return h ? SS_ERR_INVALID_MODE : SS_ERR_INVALID_ARG;
+    return ring_loudness(h, (uint64_t)h->td->host.s100 * 30, out);
+}
+
+int ss_get_momentary_lufs(ss_analyzer *h, double *out)
+{
+    if (!h || !h->meter_ok) return h ? SS_ERR_INVALID_MODE : SS_ERR_INVALID_ARG;
+    return ring_loudness(h, (uint64_t)h->td->host.s100 * 4, out);
+}
+
+static int hist_eval(ss_analyzer *h, double r[2])
+{
+    if (!h) return SS_ERR_INVALID_ARG;
+    if (!h->meter_ok) return SS_ERR_INVALID_MODE;
+    const double *he, *hb;
+    int rc = get_hist_tables(&he, &hb);
+    if (rc) return rc;
+    HIPCHK(ssk::launch_hist_eval(h->hist.p, he, hb, h->out2.p, h->stream));
+    HIPCHK(hipMemcpyAsync(r, h->out2.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SS_OK;
+}
+
+int ss_get_integrated_lufs(ss_analyzer *h, double *out)
+{
+    if (!out) return SS_ERR_INVALID_ARG;
+    double r[2];
+    int rc = hist_eval(h, r);
+    if (rc) return rc;
+    *out = r[0];
+    return SS_OK;
+}
+
+int ss_get_loudness_range(ss_analyzer *h, double *out)
+{
+    if (!out) return SS_ERR_INVALID_ARG;
+    double r[2];
+    int rc = hist_eval(h, r);
+    if (rc) return rc;
+    *out = r[1];
+    return SS_OK;
+}
+
+static int read_peaks(ss_analyzer *h, uint32_t ch, double *sample_pk, double *true_pk)
+{
+    if (!h) return SS_ERR_INVALID_ARG;
+    if (!h->meter_ok) return SS_ERR_INVALID_MODE;
+    if (ch >= h->channels) return SS_ERR_INVALID_CHANNEL;
+    float sp, tp;
+    HIPCHK(hipMemcpyAsync(&sp, &h->state.p->sample_peak[ch], sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&tp, &h->state.p->true_peak[ch], sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (sample_pk) *sample_pk = (double)sp;
+    if (true_pk) *true_pk = (double)(tp > sp ? tp : sp);    // true_peak(): max(true, sample)
+    return SS_OK;
+}
+
+int ss_get_true_peak(ss_analyzer *h, double *left, double *right)
+{
+    if (!left || !right) return SS_ERR_INVALID_ARG;
+    double l, r;
+    int rc = read_peaks(h, 0, nullptr, &l);     // analyzer.rs:160
+    if (rc) return rc;
+    rc = read_peaks(h, 1, nullptr, &r);         // analyzer.rs:161
+    if (rc) return rc;
+    *left = l; *right = r;
+    return SS_OK;
+}
+
+int ss_get_true_peak_channel(ss_analyzer *h, uint32_t channel, double *out)
+{
+    if (!out) return SS_ERR_INVALID_ARG;
+    return read_peaks(h, channel, nullptr, out);
+}
+
+int ss_get_sample_peak_channel(ss_analyzer *h, uint32_t channel, double *out)
+{
+    if (!out) return SS_ERR_INVALID_ARG;
+    return read_peaks(h, channel, out, nullptr);
+}
+
+uint32_t ss_sample_rate(const ss_analyzer *h) { return h ? h->rate : 0; }
+
+}  // extern "C"
+
+// ============================================================================
+//  batch
+// ============================================================================
+struct ss_batch {
+    ss_batch_config cfg{};
+    ss_batch_layout lay{};
+    hipStream_t stream = nullptr;
+    int tp_factor = 0;
+    int fft_mode = 1;           // generic-kernel mode (1 mid/side, 2 per channel)
+    bool fft_fast = false;      // N=4096 stereo kernel
+    uint64_t first_start = 0;
+    uint32_t wave_window = 0;
+    uint32_t windows_per_block = 16;
+    FftTables *ft = nullptr;
+    BinTables *bt = nullptr;
+    TdTables *td = nullptr;
+    DevBuf<float> pcm, fft, wave;
+    DevBuf<ssk::TdState> state;
+    DevBuf<double> sub, weights, integrated, lra, out2;
+    DevBuf<uint64_t> hist, corpus;
+    DevBuf<uint32_t> counts;
+    bool timing = false;
+    hipEvent_t ev[2 * SS_KERNEL_COUNT];
+    bool ev_ready = false;
+    double t_ms[SS_KERNEL_COUNT] = {0, 0, 0, 0};
+    uint64_t t_n[SS_KERNEL_COUNT] = {0, 0, 0, 0};
+    bool pending_events = false;
+};
+
+namespace {
+
+int batch_collect_timing(ss_batch *b)
+{
+    if (!b->pending_events) return SS_OK;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (int k = 0; k < SS_KERNEL_COUNT; k++) {
+        float ms = 0.f;
+        hipError_t e = hipEventElapsedTime(&ms, b->ev[2 * k], b->ev[2 * k + 1]);
+        if (e == hipSuccess) { b->t_ms[k] += ms; b->t_n[k]++; }
+    }
+    b->pending_events = false;
+    return SS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
+{
+    if (!cfg || !out) return SS_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (require_device()) return SS_ERR_DEVICE;
+    if (cfg->n_streams == 0 || cfg->frames_per_stream == 0) return SS_ERR_INVALID_ARG;
+    if ((cfg->flags & SS_BATCH_ALL) == 0) return SS_ERR_INVALID_ARG;
+    auto b = std::make_unique<ss_batch>();
+    b->cfg = *cfg;
+    const uint32_t C = cfg->channels;
+    const uint64_t F = cfg->frames_per_stream;
+    if (C == 0 || C > 64) return SS_ERR_NOMEM;
+    if (cfg->flags & (SS_BATCH_LUFS | SS_BATCH_TRUE_PEAK)) {
+        int rc = meter_args_ok(C, cfg->sample_rate);
+        if (rc) return rc;
+    }
+    if (cfg->true_peak_factor != 0 && cfg->true_peak_factor != 2 && cfg->true_peak_factor != 4) return SS_ERR_INVALID_ARG;
+    HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    ss_batch_layout &L = b->lay;
+    L.input_bytes = (uint64_t)cfg->n_streams * F * C * sizeof(float);
+    HIPCHK(b->pcm.alloc((size_t)cfg->n_streams * F * C));
+
+    if (cfg->flags & SS_BATCH_FFT) {
+        const size_t n = cfg->fft_n;
+        if (n < 2) return SS_ERR_TOO_FEW_SAMPLES;
+        if (!is_pow2(n)) return SS_ERR_NOT_POW2;
+        if (n > 32768) return SS_ERR_UNSUPPORTED;
+        if (20000.0f > (float)cfg->sample_rate / 2.0f) return SS_ERR_FREQ_LIMIT;
+        if (cfg->hop_frames == 0) return SS_ERR_INVALID_ARG;
+        int rc = get_fft_tables(n, &b->ft);
+        if (rc) return rc;
+        rc = get_bin_tables(cfg->sample_rate, n, &b->bt);
+        if (rc) return rc;
+        // cadence of analyze_audio_file_samples (tui.rs:1482-1526): window [p-N, p) at
+        // p = k*hop, skipped when p - N == 0 (saturating_sub) => k from N/hop + 1
+        const uint64_t hop = cfg->hop_frames;
+        const uint64_t k_min = n / hop + 1, k_max = F / hop;
+        L.n_windows = k_max >= k_min ? (uint32_t)(k_max - k_min + 1) : 0;
+        b->first_start = k_min * hop - n;
+        L.fft_channels = (C == 2) ? 2 : C;
+        b->fft_mode = (C == 2) ? 1 : (C == 1 ? 0 : 2);
+        L.n_bins = (uint32_t)b->bt->count;
+        L.first_bin = (uint32_t)b->bt->first;
+        b->fft_fast = (C == 2 && n == 4096 && hop % 256 == 0);
+        L.fft_bytes = (uint64_t)cfg->n_streams * L.n_windows * L.fft_channels * L.n_bins * sizeof(float);
+        HIPCHK(b->fft.alloc((size_t)(L.fft_bytes / sizeof(float))));
+    }
+    if (cfg->flags & (SS_BATCH_LUFS | SS_BATCH_TRUE_PEAK)) {
+        b->tp_factor = (cfg->flags & SS_BATCH_TRUE_PEAK)
+                           ? (cfg->true_peak_factor ? cfg->true_peak_factor : sst::true_peak_factor_for_rate(cfg->sample_rate))
+                           : 0;
+        int rc = get_td_tables(cfg->sample_rate, b->tp_factor, &b->td);
+        if (rc) return rc;
+        const uint64_t S = b->td->host.s100;
+        L.n_subblocks = (uint32_t)(F / S);
+        HIPCHK(b->state.alloc(cfg->n_streams));
+        HIPCHK(b->sub.alloc((size_t)cfg->n_streams * (L.n_subblocks ? L.n_subblocks : 1) * C));
+        HIPCHK(b->hist.alloc((size_t)cfg->n_streams * 2 * sst::kHistBins));
+        HIPCHK(b->corpus.alloc(2 * sst::kHistBins));
+        HIPCHK(b->integrated.alloc(cfg->n_streams));
+        HIPCHK(b->lra.alloc(cfg->n_streams));
+        HIPCHK(b->counts.alloc((size_t)cfg->n_streams * 2));
+        HIPCHK(b->out2.alloc(2));
+        std::vector<double> w(C);
+        sst::channel_weights(C, w.data());
+        HIPCHK(b->weights.upload(w));
+    }
+    if (cfg->flags & SS_BATCH_WAVEFORM) {
+        const double win = cfg->waveform_window > 0.0 ? cfg->waveform_window : (double)F / (double)cfg->sample_rate;
+        const double wd = win * 1000.0;
+        const uint64_t W = (wd != wd || wd <= 0.0) ? 0 : (uint64_t)wd;
+        if (W > 0xFFFFFFFFull) return SS_ERR_UNSUPPORTED;
+        b->wave_window = (uint32_t)W;
+        // points: bins whose start floor(i*spp) < len
+        const uint64_t len = F * C;
+        const double spp = (double)len / (double)W;
+        uint64_t bins = W;
+        if (W > len) {
+            uint64_t lo = 0, hi = W;
+            while (lo < hi) { uint64_t mid = lo + (hi - lo) / 2; if ((uint64_t)((double)mid * spp) >= len) hi = mid; else lo = mid + 1; }
+            bins = lo;
+        }
+        L.n_wave_points = (uint32_t)(2 * bins);
+        HIPCHK(b->wave.alloc((size_t)cfg->n_streams * (W ? 2 * W : 2)));
+    }
+    for (auto &e : b->ev) HIPCHK(hipEventCreate(&e));
+    b->ev_ready = true;
+    *out = b.release();
+    return SS_OK;
+}
+
+void ss_batch_destroy(ss_batch *b)
+{
+    if (!b) return;
+    if (b->stream) { (void)hipStreamSynchronize(b->stream); }
+    if (b->ev_ready) for (auto &e : b->ev) (void)hipEventDestroy(e);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+int ss_batch_layout_get(const ss_batch *b, ss_batch_layout *out)
+{
+    if (!b || !out) return SS_ERR_INVALID_ARG;
+    *out = b->lay;
+    return SS_OK;
+}
+
+int ss_batch_upload(ss_batch *b, uint32_t first, uint32_t count, const float *pcm)
+{
+    if (!b || !pcm) return SS_ERR_INVALID_ARG;
+    if ((uint64_t)first + count > b->cfg.n_streams) return SS_ERR_INVALID_ARG;
+    const size_t per = (size_t)b->cfg.frames_per_stream * b->cfg.channels;
+    HIPCHK(hipMemcpyAsync(b->pcm.p + (size_t)first * per, pcm, (size_t)count * per * sizeof(float),
+                          hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return SS_OK;
+}
+
+int ss_batch_download_input(ss_batch *b, uint32_t stream, float *pcm, size_t cap)
+{
+    if (!b || !pcm || stream >= b->cfg.n_streams) return SS_ERR_INVALID_ARG;
+    const size_t per = (size_t)b->cfg.frames_per_stream * b->cfg.channels;
+    if (cap < per) return SS_ERR_CAPACITY;
+    HIPCHK(hipMemcpyAsync(pcm, b->pcm.p + (size_t)stream * per, per * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return SS_OK;
+}
+
+void *ss_batch_input_device_ptr(ss_batch *b) { return b ? b->pcm.p : nullptr; }
+
+int ss_batch_synthesize(ss_batch *b, uint64_t seed, uint32_t first_stream_id)
+{
+    if (!b) return SS_ERR_INVALID_ARG;
+    HIPCHK(ssk::launch_synth(b->pcm.p, b->cfg.n_streams, b->cfg.frames_per_stream, b->cfg.channels,
+                             b->cfg.sample_rate, seed, first_stream_id, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return SS_OK;
+}
+
+int ss_batch_run(ss_batch *b)
+{
+    if (!b) return SS_ERR_INVALID_ARG;
+    int rc = batch_collect_timing(b);
+    if (rc) return rc;
+    const ss_batch_config &c = b->cfg;
+    const ss_batch_layout &L = b->lay;
+    const uint32_t C = c.channels;
+    const bool tm = b->timing;
+    auto rec = [&](int idx) -> hipError_t { return tm ? hipEventRecord(b->ev[idx], b->stream) : hipSuccess; };
+
+    HIPCHK(rec(2 * SS_KERNEL_FFT));
+    if ((c.flags & SS_BATCH_FFT) && L.n_windows) {
+        ssk::FftBatchParams p{};
+        p.pcm = b->pcm.p; p.out = b->fft.p;
+        p.window = b->ft->window.p; p.half_window = b->ft->half_window.p;
+        p.tw_n = b->ft->tw_n.p; p.tw_256 = b->ft->tw_256.p; p.pink = b->bt->pink_dev.p;
+        p.frames_per_stream = c.frames_per_stream; p.first_start = b->first_start;
+        p.n_streams = c.n_streams; p.channels = C; p.n_windows = L.n_windows; p.hop = c.hop_frames;
+        p.n = c.fft_n; p.first_bin = L.first_bin; p.n_bins = L.n_bins;
+        p.windows_per_block = b->windows_per_block;
+        if (b->fft_fast) {
+            p.db_offset = (float)(10.0 * std::log10(4.0 / ((double)c.fft_n * (double)c.fft_n)));
+            HIPCHK(ssk::launch_fft4096_ms(p, b->stream));
+        } else {
+            p.db_offset = (float)(20.0 * std::log10(4.0 / (double)c.fft_n));
+            HIPCHK(ssk::launch_fft_generic(p, b->fft_mode, b->stream));
+        }
+    }
+    HIPCHK(rec(2 * SS_KERNEL_FFT + 1));
+
+    const bool td = (c.flags & (SS_BATCH_LUFS | SS_BATCH_TRUE_PEAK)) != 0;
+    HIPCHK(rec(2 * SS_KERNEL_TIME_DOMAIN));
+    if (td) {
+        HIPCHK(hipMemsetAsync(b->state.p, 0, b->state.n * sizeof(ssk::TdState), b->stream));
+        HIPCHK(hipMemsetAsync(b->hist.p, 0, b->hist.n * sizeof(uint64_t), b->stream));
+        HIPCHK(hipMemsetAsync(b->corpus.p, 0, b->corpus.n * sizeof(uint64_t), b->stream));
+        HIPCHK(hipMemsetAsync(b->counts.p, 0, b->counts.n * sizeof(uint32_t), b->stream));
+        HIPCHK(rec(2 * SS_KERNEL_TIME_DOMAIN));   // time the kernel, not the memsets
+        ssk::TdParams p{};
+        p.pcm = b->pcm.p; p.stream_stride = c.frames_per_stream * C; p.n_frames = c.frames_per_stream;
+        p.n_streams = c.n_streams; p.channels = C; p.k = b->td->dev.p; p.state = b->state.p;
+        p.subblocks = b->sub.p; p.sub_cap = L.n_subblocks ? L.n_subblocks : 1;
+        p.sub_stride = (uint64_t)p.sub_cap * C; p.ring = nullptr; p.ring_frames = 0; p.tp_factor = b->tp_factor;
+        HIPCHK(ssk::launch_time_domain(p, b->stream));
+    }
+    HIPCHK(rec(2 * SS_KERNEL_TIME_DOMAIN + 1));
+
+    HIPCHK(rec(2 * SS_KERNEL_FINALIZE));
+    if (td) {
+        const double *he, *hb;
+        rc = get_hist_tables(&he, &hb);
+        if (rc) return rc;
+        ssk::FinalizeParams f{};
+        f.k = b->td->dev.p; f.subblocks = b->sub.p; f.sub_cap = L.n_subblocks ? L.n_subblocks : 1;
+        f.sub_stride = (uint64_t)f.sub_cap * C;
+        f.hist_energies = he; f.hist_bounds = hb; f.weights = b->weights.p; f.hist = b->hist.p;
+        f.corpus_hist = b->corpus.p; f.n_streams = c.n_streams; f.channels = C;
+        f.sub_begin = 0; f.sub_end = L.n_subblocks;
+        f.out_integrated = b->integrated.p; f.out_lra = b->lra.p; f.out_counts = b->counts.p;
+        HIPCHK(ssk::launch_finalize(f, b->stream));
+    }
+    HIPCHK(rec(2 * SS_KERNEL_FINALIZE + 1));
+
+    HIPCHK(rec(2 * SS_KERNEL_WAVEFORM));
+    if ((c.flags & SS_BATCH_WAVEFORM) && b->wave_window) {
+        ssk::WaveParams p{};
+        p.pcm = b->pcm.p; p.stream_stride = c.frames_per_stream * C; p.n_samples = c.frames_per_stream * C;
+        p.n_streams = c.n_streams; p.window = b->wave_window; p.out = b->wave.p; p.out_stride = (uint64_t)2 * b->wave_window;
+        HIPCHK(ssk::launch_waveform(p, b->stream));
+    }
+    HIPCHK(rec(2 * SS_KERNEL_WAVEFORM + 1));
+    b->pending_events = tm;
+    return SS_OK;
+}
+
+int ss_batch_sync(ss_batch *b)
+{
+    if (!b) return SS_ERR_INVALID_ARG;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return batch_collect_timing(b);
+}
+
+int ss_batch_results(ss_batch *b, ss_stream_result *out, uint32_t cap)
+{
+    if (!b || !out) return SS_ERR_INVALID_ARG;
+    const uint32_t n = b->cfg.n_streams;
+    if (cap < n) return SS_ERR_CAPACITY;
+    std::memset(out, 0, sizeof(ss_stream_result) * n);
+    if (!b->state.p) return SS_OK;
+    std::vector<double> integ(n), lra(n);
+    std::vector<uint32_t> cnt(2 * (size_t)n);
+    std::vector<ssk::TdState> st(n);
+    HIPCHK(hipMemcpyAsync(integ.data(), b->integrated.p, n * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(lra.data(), b->lra.p, n * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(cnt.data(), b->counts.p, 2 * (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(st.data(), b->state.p, n * sizeof(ssk::TdState), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (uint32_t i = 0; i < n; i++) {
+        out[i].integrated_lufs = integ[i];
+        out[i].loudness_range = lra[i];
+        for (uint32_t c = 0; c < 2 && c < b->cfg.channels; c++) {
+            const float sp = st[i].sample_peak[c], tp = st[i].true_peak[c];
+            out[i].sample_peak[c] = sp;
+            out[i].true_peak[c] = tp > sp ? tp : sp;
+        }
+        out[i].n_gating_blocks = cnt[2 * i];
+        out[i].n_st_blocks = cnt[2 * i + 1];
+    }
+    return SS_OK;
+}
+
+int ss_batch_download_fft(ss_batch *b, uint32_t stream, float *out, size_t cap)
+{
+    if (!b || !out || stream >= b->cfg.n_streams) return SS_ERR_INVALID_ARG;
+    const size_t per = (size_t)b->lay.n_windows * b->lay.fft_channels * b->lay.n_bins;
+    if (cap < per) return SS_ERR_CAPACITY;
+    if (!per) return SS_OK;
+    HIPCHK(hipMemcpyAsync(out, b->fft.p + (size_t)stream * per, per * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return SS_OK;
+}
+
+int ss_batch_bin_tables(const ss_batch *b, double *chart_x, double *freq, double *pink_db)
+{
+    if (!b || !b->bt) return SS_ERR_INVALID_ARG;
+    const size_t n = b->bt->count;
+    if (chart_x) std::memcpy(chart_x, b->bt->chart_x.data(), n * sizeof(double));
+    if (freq) std::memcpy(freq, b->bt->freq.data(), n * sizeof(double));
+    if (pink_db) std::memcpy(pink_db, b->bt->pink.data(), n * sizeof(double));
+    return SS_OK;
+}
+
+int ss_batch_download_waveform(ss_batch *b, uint32_t stream, float *out, size_t cap)
+{
+    if (!b || !out || stream >= b->cfg.n_streams) return SS_ERR_INVALID_ARG;
+    const size_t pts = b->lay.n_wave_points;
+    if (cap < pts) return SS_ERR_CAPACITY;
+    if (!pts) return SS_OK;
+    HIPCHK(hipMemcpyAsync(out, b->wave.p + (size_t)stream * 2 * b->wave_window, pts * sizeof(float),
+                          hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return SS_OK;
+}
+
+int ss_batch_download_subblocks(ss_batch *b, uint32_t stream, double *out, size_t cap)
+{
+    if (!b || !out || stream >= b->cfg.n_streams || !b->sub.p) return SS_ERR_INVALID_ARG;
+    const size_t per = (size_t)b->lay.n_subblocks * b->cfg.channels;
+    if (cap < per) return SS_ERR_CAPACITY;
+    if (!per) return SS_OK;
+    HIPCHK(hipMemcpyAsync(out, b->sub.p + (size_t)stream * per, per * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return SS_OK;
+}
+
+int ss_batch_histograms(ss_batch *b, uint64_t *out2000)
+{
+    if (!b || !out2000 || !b->corpus.p) return SS_ERR_INVALID_ARG;
+    HIPCHK(hipMemcpyAsync(out2000, b->corpus.p, 2 * sst::kHistBins * sizeof(uint64_t), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return SS_OK;
+}
+
+int ss_batch_histograms_device(ss_batch *b, void *dst)
+{
+    if (!b || !dst || !b->corpus.p) return SS_ERR_INVALID_ARG;
+    HIPCHK(hipMemcpyAsync(dst, b->corpus.p, 2 * sst::kHistBins * sizeof(uint64_t), hipMemcpyDeviceToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return SS_OK;
+}
+
+double ss_corpus_integrated_lufs(const uint64_t *h) { return h ? sst::gated_loudness(h) : NAN; }
+double ss_corpus_loudness_range(const uint64_t *h) { return h ? sst::loudness_range(h) : NAN; }
+
+int ss_batch_timing_enable(ss_batch *b, int enable)
+{
+    if (!b) return SS_ERR_INVALID_ARG;
+    int rc = batch_collect_timing(b);
+    if (rc) return rc;
+    b->timing = enable != 0;
+    for (int k = 0; k < SS_KERNEL_COUNT; k++) { b->t_ms[k] = 0; b->t_n[k] = 0; }
+    return SS_OK;
+}
+
+int ss_batch_timing_read(ss_batch *b, int kernel, double *total_ms, uint64_t *launches)
+{
+    if (!b || kernel < 0 || kernel >= SS_KERNEL_COUNT) return SS_ERR_INVALID_ARG;
+    int rc = batch_collect_timing(b);
+    if (rc) return rc;
+    if (total_ms) *total_ms = b->t_ms[kernel];
+    if (launches) *launches = b->t_n[kernel];
+    return SS_OK;
+}
+
+const char *ss_kernel_name(int kernel)
+{
+    switch (kernel) {
+        case SS_KERNEL_FFT: return "k_fft4096_ms";
+        case SS_KERNEL_TIME_DOMAIN: return "k_time_domain";
+        case SS_KERNEL_FINALIZE: return "k_finalize";
+        case SS_KERNEL_WAVEFORM: return "k_waveform";
+        default: return "?";
+    }
+}
+
+// Analyzer::calculate_integrated_lufs (analyzer.rs:170-182): fresh meter at the
+// handle's sample rate, whole buffer fed in 2*sr-sample chunks, loudness_global.
+int ss_calculate_integrated_lufs(ss_analyzer *h, uint32_t channels, const float *samples, size_t n, double *out)
+{
+    if (!h || !out) return SS_ERR_INVALID_ARG;
+    const uint32_t rate = h->rate;
+    int rc = meter_args_ok(channels, rate);           // EbuR128::new(...) else return None
+    if (rc) return rc;
+    // every chunk of samples.chunks(2*sr) must hold whole frames, else add_frames fails -> None
+    const size_t chunk = (size_t)rate * 2;
+    if (n > 0) {
+        if (chunk % channels) { if (n >= chunk || n % channels) return SS_ERR_NOMEM; }
+        else if (n % channels) return SS_ERR_NOMEM;
+    }
+    if (n == 0) { *out = -INFINITY; return SS_OK; }    // no blocks: loudness_global() = -inf
+    if (!samples) return SS_ERR_INVALID_ARG;
+    ss_batch_config cfg{};
+    cfg.sample_rate = rate; cfg.channels = channels; cfg.n_streams = 1; cfg.flags = SS_BATCH_LUFS;
+    cfg.frames_per_stream = n / channels; cfg.fft_n = 0; cfg.hop_frames = 0;
+    ss_batch *b = nullptr;
+    rc = ss_batch_create(&cfg, &b);
+    if (rc) return rc;
+    rc = ss_batch_upload(b, 0, 1, samples);
+    if (!rc) rc = ss_batch_run(b);
+    if (!rc) rc = ss_batch_sync(b);
+    ss_stream_result r{};
+    if (!rc) rc = ss_batch_results(b, &r, 1);
+    ss_batch_destroy(b);
+    if (rc) return rc;
+    *out = r.integrated_lufs;
+    return SS_OK;
+}
+
+}  // extern "C"

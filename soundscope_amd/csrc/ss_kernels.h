@@ -1,0 +1,117 @@
+// ss_kernels.h — parameter blocks and launchers of the gfx950 kernels.
+// Host code (ss_api.cpp) sees only this header; device code lives in ss_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace ssk {
+
+constexpr int kHistBins = 1000;
+constexpr int kMaxChannels = 64;
+constexpr int kTdChunk = 48;      // frames per sequential chunk in the time-domain kernel
+constexpr int kTdThreads = 256;
+constexpr int kTpHistMax = 24;    // longest polyphase branch (factor 2)
+
+// ---- spectrum ---------------------------------------------------------------
+struct FftBatchParams {
+    const float *pcm;            // [stream][frame][channels] f32
+    float *out;                  // [stream][window][fft_channels][n_bins] f32 dB (+pink)
+    const float *window;         // N (generic kernel) — full Hann
+    const float *half_window;    // N (4096 kernel)   — 0.5 * Hann
+    const float2 *tw_n;          // W_N^k, k < N  (4096 kernel uses k < 3841; generic k < N/2)
+    const float2 *tw_256;        // W_256^k, k < 256 (4096 kernel)
+    const float *pink;           // n_bins f32, or nullptr for raw dBFS
+    uint64_t frames_per_stream;
+    uint64_t first_start;        // frame index where window 0 starts
+    uint32_t n_streams;
+    uint32_t channels;
+    uint32_t n_windows;
+    uint32_t hop;
+    uint32_t n;                  // FFT length
+    uint32_t first_bin, n_bins;
+    uint32_t windows_per_block;  // 4096 kernel
+    float db_offset;             // 10*log10(4/N^2) (4096) or 20*log10(4/N) (generic)
+};
+
+// mid/side packed N=4096 kernel (stereo only).  hop must be a multiple of 256.
+hipError_t launch_fft4096_ms(const FftBatchParams &p, hipStream_t s);
+// any power-of-two N in [2, 32768]; mode 0: mono buffers (channels == 1),
+// 1: stereo -> mid/side, 2: per channel
+hipError_t launch_fft_generic(const FftBatchParams &p, int mode, hipStream_t s);
+
+// ---- time domain ------------------------------------------------------------
+struct TdConst {                 // one per (rate, true-peak factor), device resident
+    double b[5], a[5];
+    double m_pow[8][16];         // (A^L)^(2^k), A = zero-input transition, L = kTdChunk
+    float tp[3][kTpHistMax];     // polyphase branches 1..factor-1, coefficient of x[n - t]
+    int32_t tp_factor;           // 0, 2, 4
+    int32_t tp_len;              // taps per branch (12 or 24)
+    uint32_t s100;               // frames per 100 ms sub-block = (rate + 5) / 10
+    uint32_t pad;
+};
+
+struct TdState {                 // per stream / per handle, device resident
+    double v[kMaxChannels][4];           // DF-II state v1..v4
+    double acc[kMaxChannels];            // energy of the current incomplete sub-block
+    float tp_hist[kMaxChannels][kTpHistMax]; // last samples (newest first is index 0)
+    float sample_peak[kMaxChannels];
+    float true_peak[kMaxChannels];
+    uint64_t frames_fed;                 // since reset
+};
+
+struct TdParams {
+    const float *pcm;            // [stream][frame][channels]
+    uint64_t stream_stride;      // floats between consecutive streams
+    uint64_t n_frames;           // frames to consume from each stream this call
+    uint32_t n_streams;
+    uint32_t channels;
+    const TdConst *k;
+    TdState *state;              // [stream]
+    double *subblocks;           // [stream][slot][channels] f64, slot = sub-block index % sub_cap
+    uint64_t sub_stride;         // doubles between streams
+    uint32_t sub_cap;            // ring capacity in sub-blocks
+    double *ring;                // optional filtered-sample ring [ring_frames][channels] (handle API)
+    uint64_t ring_frames;
+    int32_t tp_factor;           // must equal k->tp_factor (selects the kernel instantiation)
+};
+hipError_t launch_time_domain(const TdParams &p, hipStream_t s);
+
+struct FinalizeParams {
+    const TdConst *k;
+    const double *subblocks; uint64_t sub_stride; uint32_t sub_cap;
+    const double *hist_energies;     // 1000
+    const double *hist_bounds;       // 1001
+    const double *weights;           // [channels]
+    uint64_t *hist;                  // [stream][2][1000] (block, short-term)
+    uint64_t *corpus_hist;           // [2][1000] or nullptr
+    uint32_t n_streams, channels;
+    uint64_t sub_begin, sub_end;     // absolute sub-block index range completed by this call
+    double *out_integrated;          // [stream] (nullable)
+    double *out_lra;                 // [stream] (nullable)
+    uint32_t *out_counts;            // [stream][2] gating / short-term blocks evaluated (nullable)
+};
+hipError_t launch_finalize(const FinalizeParams &p, hipStream_t s);
+// gate + LRA on explicit histograms (corpus gate after the all-reduce; handle getters)
+hipError_t launch_hist_eval(const uint64_t *hist2000, const double *energies, const double *bounds,
+                            double *out2, hipStream_t s);
+// mean-square of the filtered ring over the last `frames` frames (handle getters)
+hipError_t launch_ring_energy(const double *ring, uint64_t ring_frames, uint32_t channels,
+                              uint64_t end_frame, uint64_t frames, const double *weights,
+                              double *out2 /* energy, loudness */, hipStream_t s);
+
+// ---- waveform ---------------------------------------------------------------
+struct WaveParams {
+    const float *pcm; uint64_t stream_stride; uint64_t n_samples; // interleaved samples per stream
+    uint32_t n_streams; uint32_t window;   // number of decimation bins W
+    float *out; uint64_t out_stride;       // [stream][W][2] f32 (min, max)
+};
+hipError_t launch_waveform(const WaveParams &p, hipStream_t s);
+
+// ---- utilities --------------------------------------------------------------
+hipError_t launch_mid_side(const float *interleaved, size_t frames, float *mid, float *side, hipStream_t s);
+hipError_t launch_synth(float *pcm, uint32_t n_streams, uint64_t frames, uint32_t channels,
+                        uint32_t rate, uint64_t seed, uint32_t first_id, hipStream_t s);
+
+}  // namespace ssk

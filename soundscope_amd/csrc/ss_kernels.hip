@@ -1,0 +1,901 @@
+// ss_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the soundscope
+// analyzer hot path.  Reference semantics: /root/reference/src/analyzer.rs
+// (get_fft :55-105, get_waveform :107-137, add_samples/getters :139-164,
+// calculate_integrated_lufs :170-182) and src/audio_player.rs:400-419, plus the
+// arithmetic of ebur128 0.1.10 / spectrum-analyzer 1.7.0 / microfft 0.6.0 as
+// restated in DESIGN.md.  Nothing here is translated from the reference: the
+// reference has no GPU code.
+#include "ss_kernels.h"
+
+#ifndef SS_FFT_WAVES
+#define SS_FFT_WAVES 2   // min waves per SIMD the N=4096 kernel is register-allocated for
+#endif
+
+namespace ssk {
+
+// ============================================================================
+//  small complex helpers (f32)
+// ============================================================================
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
+// a * (c - i s)
+__device__ __forceinline__ float2 cmul_cs(float2 a, float c, float s) { return make_float2(a.x * c + a.y * s, a.y * c - a.x * s); }
+// a * (-i)
+__device__ __forceinline__ float2 cmul_mi(float2 a) { return make_float2(a.y, -a.x); }
+
+// forward radix-4 butterfly on (a0,a1,a2,a3) in place: A_k = sum_j a_j (-i)^(jk)
+__device__ __forceinline__ void radix4(float2 &a0, float2 &a1, float2 &a2, float2 &a3)
+{
+    float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = csub(a1, a3);
+    a0 = cadd(t0, t2);
+    a2 = csub(t0, t2);
+    a1 = make_float2(t1.x + t3.y, t1.y - t3.x);   // t1 - i t3
+    a3 = make_float2(t1.x - t3.y, t1.y + t3.x);   // t1 + i t3
+}
+
+// Forward 16-point DFT in registers.  Input a[j] natural order; output
+// X[k] is left in a[R16(k)] with R16(k) = ((k & 3) << 2) | (k >> 2).
+#define R16(k) ((((k) & 3) << 2) | ((k) >> 2))
+__device__ __forceinline__ void fft16(float2 (&a)[16])
+{
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R = 0.70710678118654752f;
+    // stage 1: 4-point DFTs over q of a[r + 4q]; result p lands in a[r + 4p]
+    radix4(a[0], a[4], a[8], a[12]);
+    radix4(a[1], a[5], a[9], a[13]);
+    radix4(a[2], a[6], a[10], a[14]);
+    radix4(a[3], a[7], a[11], a[15]);
+    // twiddle a[r + 4p] *= W16^(r p)
+    a[5] = cmul_cs(a[5], C1, S1);                                      // r=1,p=1: W^1
+    a[9] = make_float2((a[9].x + a[9].y) * R, (a[9].y - a[9].x) * R);  // r=1,p=2: W^2
+    a[13] = cmul_cs(a[13], S1, C1);                                    // r=1,p=3: W^3
+    a[6] = make_float2((a[6].x + a[6].y) * R, (a[6].y - a[6].x) * R);  // r=2,p=1: W^2
+    a[10] = cmul_mi(a[10]);                                            // r=2,p=2: W^4
+    a[14] = make_float2((a[14].y - a[14].x) * R, -(a[14].x + a[14].y) * R); // r=2,p=3: W^6 = (-R,-R)
+    a[7] = cmul_cs(a[7], S1, C1);                                      // r=3,p=1: W^3
+    a[11] = make_float2((a[11].y - a[11].x) * R, -(a[11].x + a[11].y) * R); // r=3,p=2: W^6
+    a[15] = cmul_cs(a[15], -C1, -S1);                                  // r=3,p=3: W^9 = (-C1, +S1)
+    // stage 2: 4-point DFTs over r of a[r + 4p]; result s lands in a[s + 4p] = X[p + 4s]
+    radix4(a[0], a[1], a[2], a[3]);
+    radix4(a[4], a[5], a[6], a[7]);
+    radix4(a[8], a[9], a[10], a[11]);
+    radix4(a[12], a[13], a[14], a[15]);
+}
+
+// dB of a squared magnitude q with dB = 10*log10(2)*log2(q) + off; q == 0 -> -150
+// (scale_to_dbfs, analyzer.rs:11-27: val == 0.0 => -150.0)
+__device__ __forceinline__ float db_from_sq(float q, float off)
+{
+    float r = fmaf(__log2f(q), 3.01029995663981195f, off);
+    return q == 0.0f ? -150.0f : r;
+}
+
+// ============================================================================
+//  Spectrum, N = 4096, stereo -> mid/side packed as one complex FFT.
+//
+//  z[n] = (mid[n] + i side[n]) * hann[n];  Z = FFT_4096(z);
+//  M[k] = (Z[k] + conj Z[N-k]) / 2,  S[k] = (Z[k] - conj Z[N-k]) / (2i).
+//  4096 = 16 x 16 x 16: three register-resident radix-16 passes, two full LDS
+//  exchanges plus a half-size mirror exchange.  256 threads = one window at a
+//  time; a workgroup walks `windows_per_block` consecutive windows of one
+//  stream and keeps the raw samples in registers, so with hop = 256*HS each
+//  sample is fetched from HBM once per workgroup (HS new slots per window).
+//
+//  Index algebra (n = t + 256 j, t = tb + 16 ta, k = ka + 16 kb + 256 kc):
+//   P1: A[ka]  = sum_j  z[t+256j] W16^(j ka)            ; *= W4096^(t ka)
+//   P2: B[kb]  = sum_ta A'[ka; tb+16ta] W16^(ta kb)     ; *= W256^(tb kb)
+//   P3: Z[ka+16kb+256kc] = sum_tb B'[ka,kb; tb] W16^(tb kc)
+//  Thread roles: P1 thread = t; P2 thread = tb + 16 ka; P3 thread = ka + 16 kb,
+//  which then owns bins v + 256 kc — stride-256, so output stores coalesce and
+//  the mirror bin N-k lives at thread 256-v, slot 15-kc.
+// ============================================================================
+constexpr int kX1Stride = 272;   // 256 + 16: de-phases the 4 ka-groups of a wave across banks
+constexpr int kX2Stride = 17;    // row of 16 padded to 17: conflict-free b64 row reads
+
+template <int HS>
+__global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams p)
+{
+    __shared__ __attribute__((aligned(16))) float2 xbuf[16 * kX1Stride];   // 34816 B
+    __shared__ __attribute__((aligned(16))) float2 tw2s[256];              //  2048 B
+
+    const int t = threadIdx.x;
+    const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
+    const uint32_t stream = blockIdx.x / groups;
+    const uint32_t grp = blockIdx.x - stream * groups;
+    const uint32_t w_begin = grp * p.windows_per_block;
+    uint32_t w_end = w_begin + p.windows_per_block;
+    if (w_end > p.n_windows) w_end = p.n_windows;
+
+    const float2 *src = reinterpret_cast<const float2 *>(p.pcm) + (size_t)stream * p.frames_per_stream +
+                        p.first_start + (size_t)w_begin * p.hop;
+
+    // per-thread constants, resident across the window loop
+    float hw[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) hw[j] = p.half_window[t + 256 * j];
+    float2 tw1[16];
+#pragma unroll
+    for (int ka = 1; ka < 16; ka++) tw1[ka] = p.tw_n[t * ka];
+    tw2s[t] = p.tw_256[t];
+
+    const int tb = t & 15, hi = t >> 4;
+    const uint32_t last_bin = p.first_bin + p.n_bins - 1;
+    const size_t out_win_stride = (size_t)2 * p.n_bins;
+    float *outp = p.out + ((size_t)stream * p.n_windows + w_begin) * out_win_stride;
+
+    // raw sums/differences: sd[j] = (l + r, l - r) of frame t + 256 j
+    float sm[16], df[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        float2 v = src[t + 256 * j];
+        sm[j] = v.x + v.y;
+        df[j] = v.x - v.y;
+    }
+
+    for (uint32_t w = w_begin; w < w_end; ++w) {
+        // prefetch the HS new slots of the next window (consumed after the epilogue)
+        float2 nx[HS > 0 ? HS : 1];
+        const bool more = (w + 1 < w_end);
+        if (HS > 0 && more) {
+#pragma unroll
+            for (int q = 0; q < HS; q++) nx[q] = src[(size_t)(w + 1 - w_begin) * p.hop + t + 256 * (16 - HS + q)];
+        }
+
+        float2 z[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) z[j] = make_float2(sm[j] * hw[j], df[j] * hw[j]);
+
+        // ---- pass 1
+        fft16(z);
+        __syncthreads();                       // previous window's mirror reads are done
+        xbuf[t] = z[R16(0)];
+#pragma unroll
+        for (int ka = 1; ka < 16; ka++) xbuf[ka * kX1Stride + t] = cmul(z[R16(ka)], tw1[ka]);
+        __syncthreads();
+        // ---- pass 2 (thread = tb + 16 ka)
+#pragma unroll
+        for (int ta = 0; ta < 16; ta++) z[ta] = xbuf[hi * kX1Stride + tb + 16 * ta];
+        fft16(z);
+        __syncthreads();
+        xbuf[hi * kX2Stride + tb] = z[R16(0)];
+#pragma unroll
+        for (int kb = 1; kb < 16; kb++)
+            xbuf[kb * kX1Stride + hi * kX2Stride + tb] = cmul(z[R16(kb)], tw2s[tb * kb]);
+        __syncthreads();
+        // ---- pass 3 (thread = ka + 16 kb): ka = tb, kb = hi
+#pragma unroll
+        for (int q = 0; q < 16; q++) z[q] = xbuf[hi * kX1Stride + tb * kX2Stride + q];
+        fft16(z);
+        __syncthreads();
+        // ---- mirror exchange: publish slots kc = 8..15
+#pragma unroll
+        for (int kc = 8; kc < 16; kc++) xbuf[(kc - 8) * 256 + t] = z[R16(kc)];
+        __syncthreads();
+        // ---- epilogue: bins k = t + 256 kc, kc = 0..7
+        float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
+        float *o_side = o_mid + p.n_bins;
+#pragma unroll
+        for (int kc = 0; kc < 8; kc++) {
+            const uint32_t k = (uint32_t)t + 256u * kc;
+            if (k >= p.first_bin && k <= last_bin) {
+                const float2 zk = z[R16(kc)];
+                const float2 zm = xbuf[(8 - kc) * 256 - t];      // Z[N - k]
+                const float ar = zk.x + zm.x, ai = zk.y - zm.y;  // 2 * M
+                const float br = zk.y + zm.y, bi = zk.x - zm.x;  // 2 * S (up to sign/swap)
+                const float qm = fmaf(ar, ar, ai * ai);
+                const float qs = fmaf(br, br, bi * bi);
+                const uint32_t idx = k - p.first_bin;
+                const float pk = p.pink ? p.pink[idx] : 0.0f;
+                o_mid[idx] = db_from_sq(qm, p.db_offset) + pk;
+                o_side[idx] = db_from_sq(qs, p.db_offset) + pk;
+            }
+        }
+        // ---- slide the sample registers
+        if (more) {
+            if (HS > 0) {
+#pragma unroll
+                for (int j = 0; j < 16 - HS; j++) { sm[j] = sm[j + HS]; df[j] = df[j + HS]; }
+#pragma unroll
+                for (int q = 0; q < HS; q++) { sm[16 - HS + q] = nx[q].x + nx[q].y; df[16 - HS + q] = nx[q].x - nx[q].y; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    float2 v = src[(size_t)(w + 1 - w_begin) * p.hop + t + 256 * j];
+                    sm[j] = v.x + v.y;
+                    df[j] = v.x - v.y;
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_fft4096_ms(const FftBatchParams &p, hipStream_t s)
+{
+    if (p.n_windows == 0 || p.n_streams == 0) return hipSuccess;
+    const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
+    dim3 grid(groups * p.n_streams), block(256);
+    if (p.hop == 1024) hipLaunchKernelGGL(k_fft4096_ms<4>, grid, block, 0, s, p);
+    else if (p.hop == 512) hipLaunchKernelGGL(k_fft4096_ms<2>, grid, block, 0, s, p);
+    else if (p.hop == 2048) hipLaunchKernelGGL(k_fft4096_ms<8>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(k_fft4096_ms<0>, grid, block, 0, s, p);
+    return hipGetLastError();
+}
+
+// ============================================================================
+//  Spectrum, generic power-of-two N (2..32768), one real channel per workgroup:
+//  real FFT through an N/2-point complex FFT held in LDS (in-place radix-2
+//  decimation in frequency, bit-reversed read-out), then the same epilogue.
+//  Used by the single-window API (analyzer.rs:55-105 takes any power of two)
+//  and by batch shapes the specialised kernel does not cover.
+// ============================================================================
+__device__ __forceinline__ uint32_t bitrev(uint32_t v, int bits) { return bits ? (__brev(v) >> (32 - bits)) : 0u; }
+
+__global__ __launch_bounds__(256) void k_fft_generic(FftBatchParams p, int mode, int log2m)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 zs[];
+    const uint32_t n = p.n, m = n >> 1;
+    const uint32_t fft_ch = (mode == 0) ? 1u : (mode == 1 ? 2u : p.channels);
+    // block -> (stream, window, channel)
+    uint32_t bid = blockIdx.x;
+    const uint32_t ch = bid % fft_ch; bid /= fft_ch;
+    const uint32_t w = bid % p.n_windows;
+    const uint32_t stream = bid / p.n_windows;
+    const size_t start = p.first_start + (size_t)w * p.hop;
+    const float *base = p.pcm + ((size_t)stream * p.frames_per_stream + start) * p.channels;
+
+    auto sample = [&](uint32_t i) -> float {
+        if (mode == 1) {
+            float2 v = reinterpret_cast<const float2 *>(base)[i];
+            // get_mid_and_side_samples: (l + r) / 2., (l - r) / 2.
+            return ch == 0 ? (v.x + v.y) * 0.5f : (v.x - v.y) * 0.5f;
+        }
+        return base[(size_t)i * p.channels + (mode == 0 ? 0 : ch)];
+    };
+    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+        float x0 = sample(2 * i) * p.window[2 * i];
+        float x1 = sample(2 * i + 1) * p.window[2 * i + 1];
+        zs[i] = make_float2(x0, x1);
+    }
+    // DIF radix-2 stages: span s = m/2 .. 1
+    for (uint32_t s = m >> 1; s >= 1; s >>= 1) {
+        __syncthreads();
+        const uint32_t tw_step = n / (2 * s) ;   // W_{2s}^r = W_n^(r * n/(2s))
+        for (uint32_t b = threadIdx.x; b < (m >> 1); b += blockDim.x) {
+            const uint32_t r = b & (s - 1);
+            const uint32_t i = ((b & ~(s - 1)) << 1) | r;
+            const uint32_t j = i + s;
+            const float2 a = zs[i], c = zs[j];
+            zs[i] = cadd(a, c);
+            zs[j] = cmul(csub(a, c), p.tw_n[r * tw_step]);
+        }
+    }
+    __syncthreads();
+    float *o = p.out + (((size_t)stream * p.n_windows + w) * fft_ch + ch) * p.n_bins;
+    for (uint32_t idx = threadIdx.x; idx < p.n_bins; idx += blockDim.x) {
+        const uint32_t k = p.first_bin + idx;
+        float xr, xi;
+        const float2 z0 = zs[0];
+        if (k == m) { xr = z0.x - z0.y; xi = 0.0f; }                 // Nyquist
+        else if (k == 0) { xr = z0.x + z0.y; xi = 0.0f; }
+        else {
+            const float2 zk = zs[bitrev(k, log2m)];
+            const float2 zc = zs[bitrev(m - k, log2m)];
+            const float sr = (zk.x + zc.x) * 0.5f, si = (zk.y - zc.y) * 0.5f;
+            const float dr = (zk.x - zc.x) * 0.5f, di = (zk.y + zc.y) * 0.5f;
+            const float2 wv = p.tw_n[k];
+            const float tr = wv.x * dr - wv.y * di;
+            const float ti = wv.x * di + wv.y * dr;
+            xr = sr + ti;
+            xi = si - tr;
+        }
+        const float q = fmaf(xr, xr, xi * xi);
+        float r = fmaf(log2f(q), 3.01029995663981195f, p.db_offset);
+        r = (q == 0.0f) ? -150.0f : r;
+        o[idx] = r + (p.pink ? p.pink[idx] : 0.0f);
+    }
+}
+
+hipError_t launch_fft_generic(const FftBatchParams &p, int mode, hipStream_t s)
+{
+    if (p.n_windows == 0 || p.n_streams == 0 || p.n_bins == 0) return hipSuccess;
+    const uint32_t fft_ch = (mode == 0) ? 1u : (mode == 1 ? 2u : p.channels);
+    const uint32_t m = p.n >> 1;
+    int log2m = 0;
+    while ((1u << log2m) < m) log2m++;
+    const size_t lds = (size_t)(m ? m : 1) * sizeof(float2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_generic),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid(p.n_streams * p.n_windows * fft_ch), block(256);
+    hipLaunchKernelGGL(k_fft_generic, grid, block, lds, s, p, mode, log2m);
+    return hipGetLastError();
+}
+
+// ============================================================================
+//  Time domain: K-weighting IIR (f64), 100 ms sub-block energies, sample peak
+//  and polyphase true peak (f32) — EbuR128::add_frames_f32 of ebur128 0.1.10
+//  (called at analyzer.rs:140 and :176), re-cut for a GPU:
+//
+//  One workgroup owns one stream and walks it tile by tile; a tile is (a piece
+//  of) one 100 ms sub-block.  Inside a tile each thread owns one
+//  (chunk of L frames, channel).  The recurrence is broken by the linear-system
+//  identity  state_out = A^L state_in + zero_state_response:
+//    pass 1: per chunk, run the state recurrence from zero            (4 FMA)
+//    scan  : Hillis-Steele over chunks with the constant matrices (A^L)^(2^k)
+//    pass 2: rerun each chunk from its true initial state, accumulate y^2,
+//            and evaluate the polyphase FIR / peaks on the same samples.
+//  All f64 work keeps the reference's recurrence; only the association of the
+//  carried state (1e-16 relative) differs.
+// ============================================================================
+template <int FACTOR>
+struct TpCfg { static constexpr int HIST = (FACTOR == 2) ? 24 : 12; static constexpr int BR = (FACTOR == 4) ? 3 : (FACTOR == 2 ? 1 : 0); };
+
+__device__ __forceinline__ void mat4_apply_add(const double *__restrict__ M, const double (&x)[4], double (&z)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        z[r] = fma(M[r * 4 + 0], x[0], fma(M[r * 4 + 1], x[1], fma(M[r * 4 + 2], x[2], fma(M[r * 4 + 3], x[3], z[r]))));
+}
+
+template <int FACTOR, bool RING>
+__global__ __launch_bounds__(kTdThreads) void k_time_domain(TdParams p, uint32_t pst /*padded chunk stride, dwords*/)
+{
+    constexpr int L = kTdChunk;
+    constexpr int HIST = TpCfg<FACTOR>::HIST;
+    constexpr int BR = TpCfg<FACTOR>::BR;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // carve: scan buffers (2 x 256 x 4 f64), carry (64 x 4 f64), acc (64 f64), tile, halo, peaks
+    double *zsA = reinterpret_cast<double *>(smem);                 // 8192 B
+    double *zsB = zsA + kTdThreads * 4;                              // 8192 B
+    double *carry = zsB + kTdThreads * 4;                            // 2048 B
+    double *accs = carry + kMaxChannels * 4;                         //  512 B
+    unsigned *pk = reinterpret_cast<unsigned *>(accs + kMaxChannels); // 2 x 64 x 4 = 512 B
+    float *halo = reinterpret_cast<float *>(pk + 2 * kMaxChannels);  // (kTpHistMax-1) x C, sized for 64 ch: 5888 B
+    float *tile = halo + (kTpHistMax - 1) * kMaxChannels;
+
+    const TdConst &K = *p.k;
+    const uint32_t C = p.channels;
+    const uint32_t S = K.s100;
+    const uint32_t nch = kTdThreads / C;
+    const uint32_t tile_cap = nch * L;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t chunk = tid / C, ch = tid - chunk * C;
+    const bool lane_ok = chunk < nch;
+    const uint32_t stream = blockIdx.x;
+    TdState &st = p.state[stream];
+    const float *src = p.pcm + (size_t)stream * p.stream_stride;
+
+    // ---- load per-stream state
+    if (tid < C) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) carry[tid * 4 + q] = st.v[tid][q];
+        accs[tid] = st.acc[tid];
+        pk[tid] = __float_as_uint(st.sample_peak[tid]);
+        pk[kMaxChannels + tid] = __float_as_uint(st.true_peak[tid]);
+        for (int q = 1; q < kTpHistMax; q++) halo[(q - 1) * C + tid] = st.tp_hist[tid][q - 1];   // halo[q-1] = x[-q]
+    }
+    uint64_t abs_frame = st.frames_fed;
+    __syncthreads();
+
+    const double a1 = K.a[1], a2 = K.a[2], a3 = K.a[3], a4 = K.a[4];
+    const double b0 = K.b[0], b1 = K.b[1], b2 = K.b[2], b3 = K.b[3], b4 = K.b[4];
+
+    uint64_t pos = 0;
+    while (pos < p.n_frames) {
+        const uint32_t off = (uint32_t)(abs_frame % S);
+        uint64_t seg64 = S - off;
+        if (seg64 > tile_cap) seg64 = tile_cap;
+        if (seg64 > p.n_frames - pos) seg64 = p.n_frames - pos;
+        const uint32_t seg = (uint32_t)seg64;
+        const uint32_t nchunks = (seg + L - 1) / L;
+
+        // ---- stage the tile: coalesced global reads, padded chunk-major LDS image
+        {
+            const float *g = src + pos * C;
+            const uint32_t total = seg * C, lc = L * C;
+            uint32_t cidx = tid / lc, r = tid - cidx * lc;
+            const uint32_t dstep = kTdThreads / lc, rstep = kTdThreads - dstep * lc;
+            for (uint32_t i = tid; i < total; i += kTdThreads) {
+                tile[cidx * pst + r] = g[i];
+                cidx += dstep; r += rstep;
+                if (r >= lc) { r -= lc; cidx++; }
+            }
+        }
+        __syncthreads();
+
+        const bool active = lane_ok && chunk < nchunks;
+        const uint32_t len = active ? ((seg - chunk * L) < (uint32_t)L ? (seg - chunk * L) : (uint32_t)L) : 0u;
+        const float *xs = tile + chunk * pst + ch;
+
+        // ---- pass 1: zero-state response of the state recurrence
+        double z[4] = {0.0, 0.0, 0.0, 0.0};
+        if (active) {
+            double v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0;
+            for (uint32_t i = 0; i < len; i++) {
+                const double x = (double)xs[i * C];
+                const double v0 = x - a1 * v1 - a2 * v2 - a3 * v3 - a4 * v4;
+                v4 = v3; v3 = v2; v2 = v1; v1 = v0;
+            }
+            z[0] = v1; z[1] = v2; z[2] = v3; z[3] = v4;
+            if (chunk == 0) {
+                const double cin[4] = {carry[ch * 4 + 0], carry[ch * 4 + 1], carry[ch * 4 + 2], carry[ch * 4 + 3]};
+                mat4_apply_add(K.m_pow[0], cin, z);
+            }
+        }
+        // ---- scan over chunks (ping-pong, one barrier per step)
+        double *cur = zsA, *nxt = zsB;
+#pragma unroll
+        for (int q = 0; q < 4; q++) cur[tid * 4 + q] = z[q];
+        __syncthreads();
+        for (int kstep = 0; (1u << kstep) < nchunks; kstep++) {
+            const uint32_t d = 1u << kstep;
+            if (active && chunk >= d) {
+                const uint32_t ptid = tid - d * C;
+                const double xin[4] = {cur[ptid * 4 + 0], cur[ptid * 4 + 1], cur[ptid * 4 + 2], cur[ptid * 4 + 3]};
+                mat4_apply_add(K.m_pow[kstep], xin, z);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) nxt[tid * 4 + q] = z[q];
+            __syncthreads();
+            double *tmp = cur; cur = nxt; nxt = tmp;
+        }
+        // cur[i] = state after chunk i (valid for full chunks)
+
+        // ---- pass 2: true-state rerun + energy + peaks
+        double e = 0.0;
+        double v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0;
+        if (active) {
+            if (chunk == 0) { v1 = carry[ch * 4 + 0]; v2 = carry[ch * 4 + 1]; v3 = carry[ch * 4 + 2]; v4 = carry[ch * 4 + 3]; }
+            else { const uint32_t ptid = tid - C; v1 = cur[ptid * 4 + 0]; v2 = cur[ptid * 4 + 1]; v3 = cur[ptid * 4 + 2]; v4 = cur[ptid * 4 + 3]; }
+            float sp = 0.0f, tp = 0.0f;
+            float h[HIST];
+            if (FACTOR != 0) {
+                // h[(i - t) mod HIST] = x[i - t]; before the chunk: slot HIST - t holds x[-t]
+#pragma unroll
+                for (int tt = 1; tt < HIST; tt++) {
+                    float hv;
+                    if (chunk == 0) hv = halo[(tt - 1) * C + ch];
+                    else hv = (tile + (chunk - 1) * pst + ch)[(L - tt) * C];
+                    h[HIST - tt] = hv;
+                }
+                h[0] = 0.0f;
+            }
+            const uint64_t ring_base = abs_frame + (uint64_t)chunk * L;
+            for (uint32_t i0 = 0; i0 < (uint32_t)L; i0 += HIST) {
+#pragma unroll
+                for (int u = 0; u < HIST; u++) {
+                    const uint32_t i = i0 + u;
+                    if (i < len) {
+                        const float xf = xs[i * C];
+                        sp = fmaxf(sp, fabsf(xf));
+                        if (FACTOR != 0) {
+                            h[u] = xf;
+#pragma unroll
+                            for (int f = 0; f < BR; f++) {
+                                float acc = 0.0f;
+#pragma unroll
+                                for (int tt = 0; tt < HIST; tt++) acc = fmaf(h[(u - tt + HIST) % HIST], K.tp[f][tt], acc);
+                                tp = fmaxf(tp, fabsf(acc));
+                            }
+                        }
+                        const double x = (double)xf;
+                        const double v0 = x - a1 * v1 - a2 * v2 - a3 * v3 - a4 * v4;
+                        const double y = b0 * v0 + b1 * v1 + b2 * v2 + b3 * v3 + b4 * v4;
+                        v4 = v3; v3 = v2; v2 = v1; v1 = v0;
+                        e = fma(y, y, e);
+                        if (RING) p.ring[((ring_base + i) % p.ring_frames) * C + ch] = y;
+                    }
+                }
+            }
+            atomicMax(&pk[ch], __float_as_uint(sp));
+            if (FACTOR != 0) atomicMax(&pk[kMaxChannels + ch], __float_as_uint(tp));
+        }
+        __syncthreads();   // all reads of cur / carry / halo / tile-history done
+        // carry-out: exact state after the last valid sample
+        if (active && chunk == nchunks - 1) { carry[ch * 4 + 0] = v1; carry[ch * 4 + 1] = v2; carry[ch * 4 + 2] = v3; carry[ch * 4 + 3] = v4; }
+        // new halo: x[end - q], q = 1..kTpHistMax-1
+        if (tid < C) {
+            float nh[kTpHistMax - 1];
+#pragma unroll
+            for (int q = 1; q < kTpHistMax; q++) {
+                float hv;
+                if ((uint32_t)q <= seg) { const uint32_t f = seg - q; hv = tile[(f / L) * pst + (f % L) * C + tid]; }
+                else hv = halo[(q - seg - 1) * C + tid];
+                nh[q - 1] = hv;
+            }
+#pragma unroll
+            for (int q = 0; q < kTpHistMax - 1; q++) halo[q * C + tid] = nh[q];
+        }
+        // ---- deterministic tree reduction of the chunk energies per channel
+        double *es = zsA;     // both scan buffers are free now
+        es[tid] = e;
+        __syncthreads();
+        for (uint32_t sft = 128; sft >= 1; sft >>= 1) {
+            if (lane_ok && chunk < sft && chunk + sft < nchunks) es[tid] += es[tid + sft * C];
+            __syncthreads();
+        }
+        if (tid < C) {
+            double a = accs[tid] + es[tid];
+            if (off + seg == S) {
+                const uint64_t sb = abs_frame / S;
+                p.subblocks[(size_t)stream * p.sub_stride + (size_t)(sb % p.sub_cap) * C + tid] = a;
+                a = 0.0;
+            }
+            accs[tid] = a;
+        }
+        __syncthreads();
+        abs_frame += seg;
+        pos += seg;
+    }
+
+    // ---- store state
+    if (tid < C) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) st.v[tid][q] = carry[tid * 4 + q];
+        st.acc[tid] = accs[tid];
+        st.sample_peak[tid] = __uint_as_float(pk[tid]);
+        st.true_peak[tid] = __uint_as_float(pk[kMaxChannels + tid]);
+        for (int q = 1; q < kTpHistMax; q++) st.tp_hist[tid][q - 1] = halo[(q - 1) * C + tid];
+        if (tid == 0) st.frames_fed = abs_frame;
+    }
+}
+
+static uint32_t td_padded_stride(uint32_t C)
+{
+    const uint32_t lc = kTdChunk * C;
+    const uint32_t pad = (C + 32 - (lc % 32)) % 32;   // chunk stride == C (mod 32): lane-linear banks
+    return lc + pad;
+}
+
+template <int FACTOR, bool RING>
+static hipError_t td_launch(const TdParams &p, hipStream_t s)
+{
+    const uint32_t C = p.channels;
+    const uint32_t pst = td_padded_stride(C);
+    const uint32_t nch = kTdThreads / C;
+    const size_t fixed = (size_t)kTdThreads * 4 * 8 * 2 + kMaxChannels * 4 * 8 + kMaxChannels * 8 +
+                         2 * kMaxChannels * 4 + (size_t)(kTpHistMax - 1) * kMaxChannels * 4;
+    const size_t lds = fixed + (size_t)nch * pst * 4;
+    auto fn = k_time_domain<FACTOR, RING>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fn, dim3(p.n_streams), dim3(kTdThreads), lds, s, p, pst);
+    return hipGetLastError();
+}
+
+hipError_t launch_time_domain(const TdParams &p, hipStream_t s)
+{
+    if (p.n_streams == 0 || p.n_frames == 0) return hipSuccess;
+    const int factor = p.tp_factor;
+    const bool ring = p.ring != nullptr;
+    switch (factor) {
+        case 4: return ring ? td_launch<4, true>(p, s) : td_launch<4, false>(p, s);
+        case 2: return ring ? td_launch<2, true>(p, s) : td_launch<2, false>(p, s);
+        default: return ring ? td_launch<0, true>(p, s) : td_launch<0, false>(p, s);
+    }
+}
+
+// ============================================================================
+//  Gating blocks, histograms, integrated loudness and LRA
+//  (ebur128 calc_gating_block / loudness_global / loudness_range, histogram mode)
+// ============================================================================
+__device__ __forceinline__ uint32_t hist_index(const double *__restrict__ bounds, double energy)
+{
+    uint32_t lo = 0, hi = kHistBins;
+    do {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (energy >= bounds[mid]) lo = mid; else hi = mid;
+    } while (hi - lo != 1);
+    return lo;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// one wave evaluates gate and LRA on an LDS histogram pair (block, short-term)
+__device__ void eval_hist(const unsigned long long *hb, const unsigned long long *hs,
+                          const double *__restrict__ en, const double *__restrict__ bd,
+                          double *out_i, double *out_lra)
+{
+    const int lane = threadIdx.x & 63;
+    // ---- integrated: relative gate at -10 LU of the mean of all blocks
+    double sum = 0.0; unsigned long long cnt = 0;
+    for (int i = lane; i < kHistBins; i += 64) { sum += (double)hb[i] * en[i]; cnt += hb[i]; }
+    sum = wave_sum(sum); cnt = wave_sum_u64(cnt);
+    double integrated;
+    if (cnt == 0) integrated = -INFINITY;
+    else {
+        const double rel = (sum / (double)cnt) * 0.1;
+        uint32_t start;
+        if (rel < bd[0]) start = 0;
+        else { start = hist_index(bd, rel); if (rel > en[start]) start++; }
+        double g = 0.0; unsigned long long c2 = 0;
+        for (int i = lane; i < kHistBins; i += 64) if ((uint32_t)i >= start) { g += (double)hb[i] * en[i]; c2 += hb[i]; }
+        g = wave_sum(g); c2 = wave_sum_u64(c2);
+        integrated = c2 ? 10.0 * log10(g / (double)c2) - 0.691 : -INFINITY;
+    }
+    // ---- LRA (EBU Tech 3342) on the short-term histogram
+    double power = 0.0; unsigned long long size = 0;
+    for (int i = lane; i < kHistBins; i += 64) { power += (double)hs[i] * en[i]; size += hs[i]; }
+    power = wave_sum(power); size = wave_sum_u64(size);
+    double lra = 0.0;
+    if (size != 0) {
+        const double integ = 0.01 * (power / (double)size);
+        uint32_t index;
+        if (integ < bd[0]) index = 0;
+        else { index = hist_index(bd, integ); if (integ > en[index]) index++; }
+        unsigned long long above = 0;
+        for (int i = lane; i < kHistBins; i += 64) if ((uint32_t)i >= index) above += hs[i];
+        above = wave_sum_u64(above);
+        if (above != 0 && lane == 0) {
+            const unsigned long long plow = (unsigned long long)((double)(above - 1) * 0.1 + 0.5);
+            const unsigned long long phigh = (unsigned long long)((double)(above - 1) * 0.95 + 0.5);
+            unsigned long long acc = 0; uint32_t j = index;
+            while (acc <= plow) acc += hs[j++];
+            const double l_en = en[j - 1];
+            while (acc <= phigh) acc += hs[j++];
+            const double h_en = en[j - 1];
+            lra = (10.0 * log10(h_en) - 0.691) - (10.0 * log10(l_en) - 0.691);
+        }
+        lra = __shfl(lra, 0, 64);
+    }
+    if (lane == 0) { if (out_i) *out_i = integrated; if (out_lra) *out_lra = lra; }
+}
+
+__global__ __launch_bounds__(64) void k_finalize(FinalizeParams p)
+{
+    __shared__ unsigned long long hb[kHistBins];
+    __shared__ unsigned long long hs[kHistBins];
+    __shared__ unsigned int counts[2];
+    const uint32_t stream = blockIdx.x;
+    const int lane = threadIdx.x;
+    unsigned long long *gh = reinterpret_cast<unsigned long long *>(p.hist) + (size_t)stream * 2 * kHistBins;
+    unsigned long long *corpus = reinterpret_cast<unsigned long long *>(p.corpus_hist);
+    for (int i = lane; i < kHistBins; i += 64) { hb[i] = gh[i]; hs[i] = gh[kHistBins + i]; }
+    if (lane < 2) counts[lane] = 0;
+    __syncthreads();
+
+    const uint32_t C = p.channels;
+    const double S = (double)p.k->s100;
+    const double *P = p.subblocks + (size_t)stream * p.sub_stride;
+    // gating block ending with sub-block j: j-3..j ; short-term block: j-29..j when (j-29) % 10 == 0
+    for (uint64_t j = p.sub_begin + lane; j < p.sub_end; j += 64) {
+        if (j >= 3) {
+            double sum = 0.0;
+            for (uint32_t c = 0; c < C; c++) {
+                const double w = p.weights[c];
+                if (w == 0.0) continue;
+                double cs = 0.0;
+                for (int q = 3; q >= 0; q--) cs += P[(size_t)((j - q) % p.sub_cap) * C + c];
+                sum += w * cs;
+            }
+            sum /= 4.0 * S;
+            atomicAdd(&counts[0], 1u);
+            if (sum >= p.hist_bounds[0]) atomicAdd(&hb[hist_index(p.hist_bounds, sum)], 1ull);
+        }
+        if (j >= 29 && (j - 29) % 10 == 0) {
+            double sum = 0.0;
+            for (uint32_t c = 0; c < C; c++) {
+                const double w = p.weights[c];
+                if (w == 0.0) continue;
+                double cs = 0.0;
+                for (int q = 29; q >= 0; q--) cs += P[(size_t)((j - q) % p.sub_cap) * C + c];
+                sum += w * cs;
+            }
+            sum /= 30.0 * S;
+            atomicAdd(&counts[1], 1u);
+            if (sum >= p.hist_bounds[0]) atomicAdd(&hs[hist_index(p.hist_bounds, sum)], 1ull);
+        }
+    }
+    __syncthreads();
+    // corpus contribution = what this call added
+    for (int i = lane; i < kHistBins; i += 64) {
+        const unsigned long long db = hb[i] - gh[i], ds = hs[i] - gh[kHistBins + i];
+        if (corpus) {
+            if (db) atomicAdd(&corpus[i], db);
+            if (ds) atomicAdd(&corpus[kHistBins + i], ds);
+        }
+        gh[i] = hb[i];
+        gh[kHistBins + i] = hs[i];
+    }
+    if (p.out_counts && lane < 2) p.out_counts[stream * 2 + lane] += counts[lane];
+    eval_hist(hb, hs, p.hist_energies, p.hist_bounds,
+              p.out_integrated ? &p.out_integrated[stream] : nullptr,
+              p.out_lra ? &p.out_lra[stream] : nullptr);
+}
+
+hipError_t launch_finalize(const FinalizeParams &p, hipStream_t s)
+{
+    if (p.n_streams == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_finalize, dim3(p.n_streams), dim3(64), 0, s, p);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(64) void k_hist_eval(const unsigned long long *hist2000, const double *en,
+                                                  const double *bd, double *out2)
+{
+    __shared__ unsigned long long hb[kHistBins];
+    __shared__ unsigned long long hs[kHistBins];
+    for (int i = threadIdx.x; i < kHistBins; i += 64) { hb[i] = hist2000[i]; hs[i] = hist2000[kHistBins + i]; }
+    __syncthreads();
+    eval_hist(hb, hs, en, bd, &out2[0], &out2[1]);
+}
+
+hipError_t launch_hist_eval(const uint64_t *hist2000, const double *energies, const double *bounds,
+                            double *out2, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_hist_eval, dim3(1), dim3(64), 0, s,
+                       reinterpret_cast<const unsigned long long *>(hist2000), energies, bounds, out2);
+    return hipGetLastError();
+}
+
+// mean square over the last `frames` frames of the filtered ring, channel-weighted
+// (calc_gating_block on the ring "as is": loudness_shortterm / loudness_momentary)
+__global__ __launch_bounds__(256) void k_ring_energy(const double *ring, uint64_t ring_frames, uint32_t C,
+                                                     uint64_t end_frame, uint64_t frames,
+                                                     const double *weights, double *out)
+{
+    __shared__ double red[256];
+    double acc = 0.0;
+    const uint64_t total = frames * C;
+    // ring position of absolute frame f is f % ring_frames; frames before 0 are the zeroed ring
+    const uint64_t begin = end_frame + ring_frames * 4 - frames;    // keep the subtraction non-negative
+    for (uint64_t i = threadIdx.x; i < total; i += 256) {
+        const uint64_t f = i / C; const uint32_t c = (uint32_t)(i - f * C);
+        const double w = weights[c];
+        const double y = ring[((begin + f) % ring_frames) * C + c];
+        acc = fma(w * y, y, acc);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double e = red[0] / (double)frames;
+        out[0] = e;
+        out[1] = e <= 0.0 ? -INFINITY : 10.0 * log10(e) - 0.691;   // energy_to_loudness
+    }
+}
+
+hipError_t launch_ring_energy(const double *ring, uint64_t ring_frames, uint32_t channels,
+                              uint64_t end_frame, uint64_t frames, const double *weights,
+                              double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_ring_energy, dim3(1), dim3(256), 0, s, ring, ring_frames, channels,
+                       end_frame % ring_frames, frames, weights, out);
+    return hipGetLastError();
+}
+
+// ============================================================================
+//  Waveform: min-max decimation, Analyzer::get_waveform (analyzer.rs:107-137).
+//  Bin i covers [floor(i*spp), min(ceil((i+1)*spp), len)), spp = len / W in
+//  f64 — the same f64 expressions as the reference, evaluated per bin.
+//  16 lanes per bin; min/max are IEEE minNum/maxNum (NaN-ignoring, like
+//  f32::min/max), seeded with NaN so an all-NaN bin stays NaN.
+// ============================================================================
+__global__ __launch_bounds__(256) void k_waveform(WaveParams p)
+{
+    const uint32_t lane16 = threadIdx.x & 15;
+    const uint64_t gbin = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const uint64_t total_bins = (uint64_t)p.n_streams * p.window;
+    if (gbin >= total_bins) return;
+    const uint32_t stream = (uint32_t)(gbin / p.window);
+    const uint32_t i = (uint32_t)(gbin - (uint64_t)stream * p.window);
+    const double spp = (double)p.n_samples / (double)p.window;
+    const double sd = (double)i * spp;
+    const double ed = ceil((double)(i + 1) * spp);
+    uint64_t start = (uint64_t)sd;
+    uint64_t end = (ed >= 1.8446744073709552e19) ? ~0ull : (uint64_t)ed;
+    if (end > p.n_samples) end = p.n_samples;
+    float *o = p.out + (size_t)stream * p.out_stride + (size_t)i * 2;
+    if (start >= p.n_samples) return;            // `break`: this and all later bins produce no point
+    const float *x = p.pcm + (size_t)stream * p.stream_stride;
+    float mn = __builtin_nanf(""), mx = __builtin_nanf("");
+    for (uint64_t j = start + lane16; j < end; j += 16) {
+        const float v = x[j];
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+#pragma unroll
+    for (int ofs = 8; ofs >= 1; ofs >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, ofs, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, ofs, 16));
+    }
+    if (lane16 == 0) { o[0] = mn; o[1] = mx; }
+}
+
+hipError_t launch_waveform(const WaveParams &p, hipStream_t s)
+{
+    const uint64_t total_bins = (uint64_t)p.n_streams * p.window;
+    if (total_bins == 0) return hipSuccess;
+    const uint64_t blocks = (total_bins * 16 + 255) / 256;
+    hipLaunchKernelGGL(k_waveform, dim3((uint32_t)blocks), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ============================================================================
+//  Utilities
+// ============================================================================
+// get_mid_and_side_samples, audio_player.rs:400-419
+__global__ void k_mid_side(const float2 *in, size_t frames, float *mid, float *side)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < frames) {
+        const float2 v = in[i];
+        mid[i] = (v.x + v.y) / 2.0f;
+        side[i] = (v.x - v.y) / 2.0f;
+    }
+}
+
+hipError_t launch_mid_side(const float *interleaved, size_t frames, float *mid, float *side, hipStream_t s)
+{
+    if (!frames) return hipSuccess;
+    hipLaunchKernelGGL(k_mid_side, dim3((uint32_t)((frames + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float2 *>(interleaved), frames, mid, side);
+    return hipGetLastError();
+}
+
+// Synthetic corpus: per stream two sines + uniform noise, level
+// spread over ~20 dB, 5 % of streams carry a 3 s near-silent segment.
+__device__ __forceinline__ uint32_t mix32(uint64_t x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return (uint32_t)x;
+}
+__device__ __forceinline__ float u01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
+
+__global__ __launch_bounds__(256) void k_synth(float *pcm, uint32_t n_streams, uint64_t frames, uint32_t C,
+                                               uint32_t rate, uint64_t seed, uint32_t first_id)
+{
+    const uint64_t per_stream = frames * C;
+    const uint64_t total = per_stream * n_streams;
+    for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (uint64_t)gridDim.x * 256) {
+        const uint32_t s = (uint32_t)(g / per_stream);
+        const uint64_t r = g - (uint64_t)s * per_stream;
+        const uint64_t f = r / C; const uint32_t c = (uint32_t)(r - f * C);
+        const uint64_t sid = seed * 0x9E3779B97F4A7C15ull + (uint64_t)(first_id + s) * 0xD1B54A32D192ED03ull;
+        const float uf = u01(mix32(sid + 11 + c * 7919ull));
+        const float freq = 50.0f * __expf(uf * 5.480639f);                 // log-uniform 50..12000 Hz
+        const float phase = u01(mix32(sid + 23 + c));
+        const float level = __expf(-2.3025851f * u01(mix32(sid + 5)));     // amplitude 1 .. 0.1
+        const bool has_gap = (mix32(sid + 99) % 20u) == 0u;
+        const uint64_t gap0 = (uint64_t)(u01(mix32(sid + 101)) * 0.6f * (float)frames);
+        float gain = level;
+        if (has_gap && f >= gap0 && f < gap0 + 3ull * rate) gain *= 1e-4f;
+        const double cyc = (double)freq * (double)f / (double)rate + (double)phase;
+        const float ph = (float)(cyc - floor(cyc));
+        const float noise = 2.0f * u01(mix32(sid ^ (r * 0x2545F4914F6CDD1Dull + 77))) - 1.0f;
+        pcm[g] = gain * (0.25f * __sinf(6.2831853f * ph) + 0.05f * noise);
+    }
+}
+
+hipError_t launch_synth(float *pcm, uint32_t n_streams, uint64_t frames, uint32_t channels,
+                        uint32_t rate, uint64_t seed, uint32_t first_id, hipStream_t s)
+{
+    if (!n_streams || !frames) return hipSuccess;
+    hipLaunchKernelGGL(k_synth, dim3(4096), dim3(256), 0, s, pcm, n_streams, frames, channels, rate, seed, first_id);
+    return hipGetLastError();
+}
+
+}  // namespace ssk

@@ -1,0 +1,72 @@
+"""The C-ABI library loads and exports every symbol include/soundscope_hip.h declares (no GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import soundscope_amd as ssa
+from soundscope_amd import _lib as L
+
+HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "soundscope_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ss_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_all_exported():
+    lib = ctypes.CDLL(L.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in soundscope_hip.h but not exported"
+
+
+def test_python_binding_covers_header():
+    assert sorted(L.SYMBOLS) == declared_symbols()
+
+
+def test_abi_version_and_status_strings():
+    lib = L.lib()
+    assert lib.ss_abi_version() == 1
+    assert lib.ss_status_string(0) == b"ok"
+    assert b"NotAPowerOfTwo" in lib.ss_status_string(L.SS_ERR_NOT_POW2)
+
+
+def test_no_cpu_fallback_without_device():
+    """On a box without a GPU every compute entry point must fail loudly (SS_ERR_DEVICE)."""
+    if L.lib().ss_device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(ssa.DeviceError):
+        ssa.Analyzer()
+    with pytest.raises(ssa.DeviceError):
+        ssa.Analyzer.get_waveform(np.zeros(100, np.float32), 0.05)
+    with pytest.raises(ssa.DeviceError):
+        ssa.Batch(n_streams=1, frames_per_stream=48000)
+
+
+def test_struct_sizes_match_header():
+    # ss_batch_config: 8 x u32 + u64 + f64; ss_stream_result: 6 f64 + 2 u32; ss_batch_layout: 6 u32 + 2 u64
+    assert ctypes.sizeof(L.BatchConfig) == 48
+    assert ctypes.sizeof(L.StreamResult) == 56
+    assert ctypes.sizeof(L.BatchLayout) == 40
+
+
+def test_corpus_gate_host_helpers_match_oracle(oracle):
+    """ss_corpus_* is host logic (A7/A8 on an all-reduced histogram); check it against the oracle."""
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        h = np.zeros(1000, np.uint64)
+        idx = rng.integers(300, 700, 40)
+        h[idx] += rng.integers(1, 50, 40).astype(np.uint64)
+        if rng.random() < 0.5:
+            h[rng.integers(0, 200, 10)] += 5
+        assert ssa.corpus_integrated_lufs(h) == oracle.gated_loudness_hist(h)
+        assert ssa.corpus_loudness_range(h) == oracle.loudness_range_hist(h)
+    z = np.zeros(1000, np.uint64)
+    assert ssa.corpus_integrated_lufs(z) == -np.inf
+    assert ssa.corpus_loudness_range(z) == 0.0

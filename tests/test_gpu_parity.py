@@ -1,0 +1,348 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on identical buffers.
+
+Bars (BASELINE.json north_star): min-max decimation bit-exact; FFT magnitudes, LUFS and
+true peak within +-0.01 dB / 1e-4 relative.  The spectrum metric is `conftest.db_close`.
+"""
+import numpy as np
+import pytest
+
+import soundscope_amd as ssa
+from soundscope_amd import _lib as L
+from conftest import db_close, make_multich, make_stereo
+
+pytestmark = pytest.mark.gpu
+
+TOL_DB = 0.01
+
+
+def lufs_close(a, b, tol=TOL_DB):
+    if np.isinf(a) or np.isinf(b):
+        return a == b
+    return abs(a - b) <= tol
+
+
+def rel_close(a, b, rel=1e-4):
+    return abs(a - b) <= rel * max(abs(b), 1e-30)
+
+
+# ---------------------------------------------------------------- get_fft
+@pytest.mark.parametrize("rate,n", [(44100, 16384), (48000, 4096), (48000, 16384), (96000, 16384),
+                                     (44100, 2048), (48000, 32768), (44100, 64), (40000, 2), (48000, 8)])
+def test_get_fft_matches_oracle(oracle, rate, n):
+    an = ssa.Analyzer()
+    an.create_loudness_meter(2, rate)
+    rng = np.random.default_rng(n + rate)
+    t = np.arange(n) / rate
+    x = (0.7 * np.sin(2 * np.pi * 997.0 * t) + 0.1 * np.sin(2 * np.pi * 5000.0 * t + 1.0)
+         + 0.01 * rng.standard_normal(n)).astype(np.float32)
+    got = an.get_fft(x)
+    ref = oracle.get_fft(rate, x)
+    assert got.shape == ref.shape
+    if ref.shape[0]:
+        assert np.array_equal(got[:, 0], ref[:, 0])           # chart_x is table-exact
+        assert db_close(got[:, 1], ref[:, 1], TOL_DB)
+
+
+def test_get_fft_reference_unit_tests(oracle):
+    """analyzer.rs:225-322 restated: 0 dBFS bin-centred sine -> ~0 dB; 125 Hz vs 1 kHz -> ~-9 dB."""
+    an = ssa.Analyzer()
+    sr = 44100
+    res = np.float32(sr) / np.float32(16384.0)
+
+    def tone(target):
+        b = np.round(np.float32(target) / res)
+        f = np.float32(b) * res
+        t = np.arange(16384, dtype=np.float32) / np.float32(sr)
+        return np.sin(np.float32(2.0) * np.float32(np.pi) * f * t).astype(np.float32)
+
+    m1k = an.get_fft(tone(1000.0))[:, 1].max()
+    m125 = an.get_fft(tone(125.0))[:, 1].max()
+    assert -1.0 <= m1k <= 1.0
+    assert -10.5 <= m125 - m1k <= -8.0
+    assert abs(m1k - oracle.get_fft(sr, tone(1000.0))[:, 1].max()) < 1e-3
+
+
+def test_get_fft_error_order():
+    an = ssa.Analyzer()
+    def code(x):
+        with pytest.raises(ssa.AnalyzerError) as e:
+            an.get_fft(x)
+        return e.value.code
+    assert code(np.zeros(0, np.float32)) == L.SS_ERR_TOO_FEW_SAMPLES
+    assert code(np.zeros(1, np.float32)) == L.SS_ERR_TOO_FEW_SAMPLES
+    assert code(np.zeros(1000, np.float32)) == L.SS_ERR_NOT_POW2
+    x = np.zeros(1024, np.float32); x[5] = np.nan
+    assert code(x) == L.SS_ERR_NAN
+    x = np.zeros(1000, np.float32); x[5] = np.nan           # NaN is reported before not-pow2
+    assert code(x) == L.SS_ERR_NAN
+    x = np.zeros(1024, np.float32); x[500] = np.inf
+    assert code(x) == L.SS_ERR_INFINITY
+    x = np.zeros(1024, np.float32); x[0] = np.inf           # hann[0] == 0: 0*inf = NaN
+    assert code(x) == L.SS_ERR_NAN
+    an.create_loudness_meter(2, 32000)                       # 20 kHz > Nyquist
+    assert code(np.zeros(1024, np.float32)) == L.SS_ERR_FREQ_LIMIT
+
+
+def test_get_fft_silence_is_minus_150(oracle):
+    an = ssa.Analyzer()
+    got = an.get_fft(np.zeros(4096, np.float32))
+    ref = oracle.get_fft(44100, np.zeros(4096, np.float32))
+    assert np.array_equal(got, ref)                          # -150 + pink, exactly
+
+
+# ---------------------------------------------------------------- get_waveform (bit-exact)
+@pytest.mark.parametrize("n,window", [(44100, 15.0), (960000, 10.0), (1000, 0.3), (100, 15.0), (7, 0.001),
+                                       (0, 1.0), (12345, 0.0), (48000 * 2 * 3 + 1, 3.0000001), (661500, 15.0)])
+def test_get_waveform_bit_exact(oracle, n, window):
+    rng = np.random.default_rng(n)
+    x = rng.uniform(-1, 1, n).astype(np.float32) if n else np.zeros(0, np.float32)
+    got = ssa.Analyzer.get_waveform(x, window)
+    ref = oracle.get_waveform(x, window)
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref)
+
+
+def test_get_waveform_reference_unit_test(oracle):
+    x = np.sin(np.arange(44100, dtype=np.float32) / np.float32(44100.0)).astype(np.float32)
+    w = ssa.Analyzer.get_waveform(x, 15.0)
+    assert w.shape == (30000, 2)
+    assert np.array_equal(w[0::2, 0], np.arange(15000))
+    assert np.all(w[0::2, 1] <= w[1::2, 1])
+    assert np.array_equal(w, oracle.get_waveform(x, 15.0))
+
+
+def test_get_waveform_nan_semantics(oracle):
+    x = np.linspace(-1, 1, 4000).astype(np.float32)
+    x[100:140] = np.nan          # a fully-NaN bin and partially-NaN bins
+    x[1000] = np.nan
+    got = ssa.Analyzer.get_waveform(x, 0.1)
+    ref = oracle.get_waveform(x, 0.1)
+    assert np.array_equal(got, ref, equal_nan=True)
+
+
+def test_mid_side_bit_exact(oracle):
+    x = make_stereo(5, 10001)
+    x = np.concatenate([x, np.float32([0.3])])              # odd trailing sample is dropped
+    m, s = ssa.get_mid_and_side_samples(x)
+    rm, rs = oracle.mid_side(x)
+    assert np.array_equal(m, rm) and np.array_equal(s, rs)
+
+
+# ---------------------------------------------------------------- streaming meter
+@pytest.mark.parametrize("rate,slice_samples", [(48000, 16384), (44100, 16384), (48000, 9600), (48000, 7),
+                                                 (96000, 100000), (44100, 88200)])
+def test_add_samples_streaming_matches_oracle(oracle, rate, slice_samples):
+    frames = rate * 8
+    x = make_stereo(rate + slice_samples, frames, rate, level=0.8, gap=True)
+    if slice_samples == 7:
+        x = x[:2 * rate * 2]                                  # tiny slices: keep the call count sane
+        slice_samples = 14
+    an = ssa.Analyzer()
+    an.create_loudness_meter(2, rate)
+    m = oracle.Meter(2, rate)
+    step = 0
+    for off in range(0, x.size, slice_samples):
+        sl = x[off:off + slice_samples]
+        an.add_samples(sl)
+        m.add_frames(sl)
+        step += 1
+        if step % 7 == 0 or off + slice_samples >= x.size:
+            assert lufs_close(an.get_shortterm_lufs(), m.shortterm()), off
+            assert lufs_close(an.get_momentary_lufs(), m.momentary()), off
+    assert lufs_close(an.get_integrated_lufs(), m.integrated())
+    assert abs(an.get_loudness_range() - m.loudness_range()) <= TOL_DB
+    l, r = an.get_true_peak()
+    assert rel_close(l, m.true_peak(0)) and rel_close(r, m.true_peak(1))
+    assert an.get_sample_peak_channel(0) == m.sample_peak(0)
+    assert an.sample_rate() == rate
+    # reset clears everything
+    an.reset(); m.reset()
+    assert an.get_integrated_lufs() == -np.inf == m.integrated()
+    assert an.get_shortterm_lufs() == -np.inf
+    an.add_samples(x[:rate]); m.add_frames(x[:rate])
+    assert lufs_close(an.get_shortterm_lufs(), m.shortterm())
+
+
+def test_tick_driver_quirk_overlapping_refeed(oracle):
+    """tui.rs:1528-1543: every tick re-feeds the last 16384 interleaved samples (8x overlap)."""
+    rate = 48000
+    x = make_stereo(77, rate * 4, rate)
+    an = ssa.Analyzer(); an.create_loudness_meter(2, rate)
+    m = oracle.Meter(2, rate)
+    for pos in range(2048, x.size + 1, 2048):
+        lb = max(pos - 16384, 0)
+        if lb == 0:
+            continue
+        an.add_samples(x[lb:pos]); m.add_frames(x[lb:pos])
+        if (pos // 2048) % 16 == 0:
+            assert lufs_close(an.get_shortterm_lufs(), m.shortterm())
+    assert lufs_close(an.get_integrated_lufs(), m.integrated())
+
+
+def test_meter_errors_and_reinit(oracle):
+    an = ssa.Analyzer()
+    an.create_loudness_meter(1, 48000)                       # analyzer.rs:389-398
+    with pytest.raises(ssa.AnalyzerError) as e:
+        an.get_true_peak()                                   # channel 1 does not exist
+    assert e.value.code == L.SS_ERR_INVALID_CHANNEL
+    an.create_loudness_meter(6, 96000)
+    with pytest.raises(ssa.AnalyzerError) as e:
+        an.add_samples(np.zeros(7, np.float32))              # partial frame
+    assert e.value.code == L.SS_ERR_NOMEM
+    for ch, rate in [(0, 48000), (65, 48000), (2, 15), (2, 2822401)]:
+        with pytest.raises(ssa.AnalyzerError) as e:
+            an.create_loudness_meter(ch, rate)
+        assert e.value.code == L.SS_ERR_NOMEM
+        assert an.sample_rate() == rate                      # rate sticks even on error (analyzer.rs:50)
+
+
+@pytest.mark.parametrize("channels,rate", [(1, 48000), (6, 48000), (8, 96000), (5, 44100), (3, 22050)])
+def test_multichannel_meter(oracle, channels, rate):
+    x = make_multich(channels * 31 + rate, rate * 5, channels, rate)
+    an = ssa.Analyzer(); an.create_loudness_meter(channels, rate)
+    m = oracle.Meter(channels, rate)
+    an.add_samples(x); m.add_frames(x)
+    assert lufs_close(an.get_integrated_lufs(), m.integrated())
+    assert lufs_close(an.get_shortterm_lufs(), m.shortterm())
+    for c in range(channels):
+        assert rel_close(an.get_true_peak_channel(c), m.true_peak(c))
+
+
+def test_forced_true_peak_factor(oracle):
+    rate = 96000
+    x = make_stereo(9, rate * 2, rate, level=1.5)
+    for factor in (0, 2, 4):
+        an = ssa.Analyzer(); an.set_true_peak_factor(factor); an.create_loudness_meter(2, rate)
+        m = oracle.Meter(2, rate, force_tp_factor=factor)
+        an.add_samples(x); m.add_frames(x)
+        l, r = an.get_true_peak()
+        assert rel_close(l, m.true_peak(0)) and rel_close(r, m.true_peak(1))
+
+
+def test_true_peak_ebu3341_intersample(oracle):
+    """EBU 3341 case 16-like: fs/4 sine, 45 deg phase, 0.5 FS: sample peaks 0.354, true peak ~0.5."""
+    rate = 48000
+    n = np.arange(rate)
+    s = (0.5 * np.sin(2 * np.pi * (rate / 4) * n / rate + np.pi / 4)).astype(np.float32)
+    x = np.empty(2 * rate, np.float32); x[0::2] = s; x[1::2] = s
+    an = ssa.Analyzer(); an.create_loudness_meter(2, rate); an.add_samples(x)
+    l, _ = an.get_true_peak()
+    assert 20 * np.log10(l) == pytest.approx(-6.0, abs=0.4)
+    assert an.get_sample_peak_channel(0) < 0.36
+
+
+# ---------------------------------------------------------------- calculate_integrated_lufs
+def test_calculate_integrated_lufs(oracle):
+    rate = 48000
+    x = make_stereo(11, rate * 10, rate, gap=True)
+    an = ssa.Analyzer(); an.create_loudness_meter(2, rate)
+    got = an.calculate_integrated_lufs(2, x)
+    ref = oracle.calculate_integrated_lufs(rate, 2, x)
+    assert lufs_close(got, ref)
+    assert an.calculate_integrated_lufs(2, x[:-1]) is None            # partial frame -> None
+    assert an.calculate_integrated_lufs(0, x) is None                 # meter creation fails -> None
+    assert an.calculate_integrated_lufs(2, np.zeros(0, np.float32)) == -np.inf
+    assert an.calculate_integrated_lufs(2, x[:rate // 2]) == oracle.calculate_integrated_lufs(rate, 2, x[:rate // 2])
+    # EBU 3341 case 1: stereo 1 kHz -23 dBFS, 20 s -> -23.0 +-0.1 LUFS
+    t = np.arange(rate * 20) / rate
+    s = (10 ** (-23 / 20) * np.sin(2 * np.pi * 1000 * t)).astype(np.float32)
+    st = np.repeat(s, 2)
+    assert an.calculate_integrated_lufs(2, st) == pytest.approx(-23.0, abs=0.1)
+
+
+# ---------------------------------------------------------------- batch
+def _check_batch_against_oracle(oracle, b, xs, rate, fft_n, hop, tp_factor=0):
+    lay = b.layout
+    res = b.results()
+    for i, x in enumerate(xs):
+        ref = oracle.analyze_stream(rate, x, fft_n, hop, force_tp_factor=tp_factor)
+        assert lay.n_windows == ref["n_windows"] and lay.n_bins == ref["n_bins"]
+        fft = b.fft(i)
+        for w in range(lay.n_windows):
+            for c in range(2):
+                assert db_close(fft[w, c], ref["fft"][w, c], TOL_DB), (i, w, c)
+        assert lufs_close(res[i].integrated_lufs, ref["integrated"])
+        assert abs(res[i].loudness_range - ref["lra"]) <= TOL_DB
+        for c in range(2):
+            assert rel_close(res[i].true_peak[c], ref["true_peak"][c])
+            assert res[i].sample_peak[c] == ref["sample_peak"][c]
+        wave = b.waveform(i)
+        assert np.array_equal(wave.reshape(-1), ref["wave"][:, 1].astype(np.float32))
+
+
+@pytest.mark.parametrize("frames", [48000 * 10, 48000 * 3 + 123, 4096 + 1024, 4096 + 1023, 5000])
+def test_batch_fast_path_matches_oracle(oracle, frames):
+    """config 2 shape: 48 kHz stereo, N=4096, hop 1024 — the LDS radix-16 kernel + full meter."""
+    rate, ns = 48000, 3
+    xs = [make_stereo(100 + i + frames, frames, rate, level=0.3 + 0.3 * i, gap=(i == 1 and frames > 5 * rate)) for i in range(ns)]
+    b = ssa.Batch(rate, 2, ns, frames, 4096, 1024)
+    b.upload(0, np.concatenate(xs))
+    b.run(); b.sync()
+    _check_batch_against_oracle(oracle, b, xs, rate, 4096, 1024)
+    # corpus gate = gate on the sum of the streams' histograms
+    hb, hs = b.histograms()
+    ms = []
+    for x in xs:
+        m = oracle.Meter(2, rate); m.add_frames(x); ms.append(m)
+    assert np.array_equal(hb, sum(m.block_hist() for m in ms))
+    assert np.array_equal(hs, sum(m.st_hist() for m in ms))
+    assert ssa.corpus_integrated_lufs(hb) == oracle.gated_loudness_hist(hb)
+
+
+@pytest.mark.parametrize("rate,fft_n,hop", [(44100, 16384, 1024), (48000, 2048, 512), (48000, 4096, 1000), (48000, 4096, 512)])
+def test_batch_other_shapes_match_oracle(oracle, rate, fft_n, hop):
+    frames = rate * 2 + 77
+    xs = [make_stereo(7 + i, frames, rate) for i in range(2)]
+    b = ssa.Batch(rate, 2, 2, frames, fft_n, hop)
+    b.upload(0, np.concatenate(xs))
+    b.run(); b.sync()
+    _check_batch_against_oracle(oracle, b, xs, rate, fft_n, hop)
+
+
+def test_batch_synth_roundtrip_and_rerun_is_deterministic(oracle):
+    b = ssa.Batch(48000, 2, 4, 48000 * 4, 4096, 1024)
+    b.synthesize(1234, 0)
+    b.run(); b.sync()
+    f0 = b.fft(2).copy(); r0 = [(r.integrated_lufs, r.true_peak[0]) for r in b.results()]
+    b.run(); b.sync()
+    assert np.array_equal(f0, b.fft(2))
+    assert r0 == [(r.integrated_lufs, r.true_peak[0]) for r in b.results()]
+    x = b.download_input(2)
+    assert np.abs(x).max() < 1.0 and np.abs(x).max() > 0.01
+    _check_batch_against_oracle(oracle, b, [b.download_input(i) for i in range(4)], 48000, 4096, 1024)
+
+
+def test_batch_eight_channel_96k(oracle):
+    """config 5 shape (shortened): 96 kHz, 8 ch, N=16384 per channel, forced 4x true peak."""
+    rate, ch, frames = 96000, 8, 96000 * 2
+    x = make_multich(5, frames, ch, rate)
+    b = ssa.Batch(rate, ch, 1, frames, 16384, 1024, true_peak_factor=4)
+    b.upload(0, x)
+    b.run(); b.sync()
+    lay = b.layout
+    assert lay.fft_channels == 8 and lay.n_bins == 3410
+    fft = b.fft(0)
+    xm = x.reshape(frames, ch)
+    for w in (0, lay.n_windows // 2, lay.n_windows - 1):
+        start = (w + 1) * 1024
+        for c in (0, 3, 7):
+            ref = oracle.get_fft(rate, xm[start:start + 16384, c])
+            assert db_close(fft[w, c], ref[:, 1], TOL_DB)
+    m = oracle.Meter(ch, rate, force_tp_factor=4); m.add_frames(x)
+    r = b.results()[0]
+    assert lufs_close(r.integrated_lufs, m.integrated())
+    assert rel_close(r.true_peak[0], m.true_peak(0)) and rel_close(r.true_peak[1], m.true_peak(1))
+
+
+def test_spectrum_linearity_property():
+    """Size-independent property at the full config-2 size: scaling the input by 2 adds 6.0206 dB."""
+    frames = 48000 * 10
+    x = make_stereo(42, frames, level=0.2)
+    b = ssa.Batch(48000, 2, 2, frames, 4096, 1024, flags=L.SS_BATCH_FFT | L.SS_BATCH_LUFS)
+    b.upload(0, np.concatenate([x, 2 * x]))
+    b.run(); b.sync()
+    a, c = b.fft(0), b.fft(1)
+    assert a.shape == (464, 2, 1705)
+    assert np.abs((c - a) - 20 * np.log10(2)).max() < 1e-3
+    r = b.results()
+    assert r[1].integrated_lufs - r[0].integrated_lufs == pytest.approx(20 * np.log10(2), abs=0.11)  # 0.1 LU bins
