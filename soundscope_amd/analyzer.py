@@ -92,7 +92,7 @@ class Analyzer:
         a, ap = _f32(samples)
         wd = waveform_window * 1000.0
         w = int(wd) if wd == wd and wd > 0 else 0
-        cap = 2 * min(w, max(a.size, 1)) + 2
+        cap = 2 * w + 2
         out = np.empty((cap, 2), np.float64)
         n = C.c_size_t(0)
         _check(L.lib().ss_get_waveform(ap, a.size, float(waveform_window),
