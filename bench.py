@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the soundscope analyzer hot path on MI355X.
+
+One step = one pass of the whole hot path (mid/side 4096-pt Hann FFT spectrum at hop 1024,
+K-weighted gated loudness + LRA, 4x true peak, min-max decimation) over a batch of synthetic
+48 kHz stereo f32 streams already resident in HBM, followed by the corpus gate (one all-reduce
+of the 2x1000-bin histograms when N > 1).  Weak scaling: every rank holds `--streams` streams
+(1024 x 10 s = BASELINE config 3 per GPU; 8 ranks = config 4's 8192 streams).
+
+Launch:  python bench.py --gpus 1 --steps K --warmup W
+         python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(batch, rate, fft_n, hop, budget_s=15.0):
+    """Time the CPU restatement (oracle, kind 'port') on a bounded sample of the same streams."""
+    from oracle import pyoracle as po
+    native = True
+    try:
+        po.build(native=True)
+        po.lib(native=True)
+    except Exception:
+        native = False
+    if native:      # keep whichever build is faster on this host (AVX-512 codegen can lose)
+        x0 = batch.download_input(0)
+        tt = []
+        for nat in (False, True):
+            t0 = time.perf_counter()
+            po.analyze_stream(rate, x0, fft_n, hop, native=nat)
+            tt.append(time.perf_counter() - t0)
+        native = tt[1] < tt[0]
+    n_streams = int(batch.cfg.n_streams)
+    done, samples, t_used = 0, 0, 0.0
+    while done < n_streams and t_used < budget_s:
+        x = batch.download_input(done)
+        t0 = time.perf_counter()
+        po.analyze_stream(rate, x, fft_n, hop, want_fft=True, want_wave=True, native=native)
+        t_used += time.perf_counter() - t0
+        samples += x.size
+        done += 1
+    return {"value": samples / t_used, "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": f"{done} of the batch's streams ({samples} samples), single thread, "
+                      f"gcc -O3{' -march=native' if native else ''}, full analyze_stream pass "
+                      "(waveform + mid/side + 2 FFTs/window incl. the crate's stats sorts + meter with true peak)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=1024, help="streams per GPU")
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--rate", type=int, default=48000)
+    ap.add_argument("--fft-n", type=int, default=4096)
+    ap.add_argument("--hop", type=int, default=1024)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+
+    import soundscope_amd as ssa
+    from soundscope_amd import _lib as L
+    from soundscope_amd.distributed import allreduce_histograms, corpus_gate, shard_streams
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (soundscope_amd has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    rc = L.lib().ss_set_device(local_rank)
+    if rc:
+        raise SystemExit("ss_set_device failed: " + L.lib().ss_last_device_error().decode())
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    frames = int(round(args.seconds * args.rate))
+    total_streams = args.streams * world
+    first, count = shard_streams(total_streams, rank, world)
+    b = ssa.Batch(args.rate, 2, count, frames, args.fft_n, args.hop, flags=L.SS_BATCH_ALL)
+    b.synthesize(0x5EED0000, first)
+    lay = b.layout
+    hist = torch.zeros(2000, dtype=torch.int64, device="cuda")
+
+    def step():
+        b.run()
+        b.histograms_to_device(hist.data_ptr())      # syncs the batch's stream
+        allreduce_histograms(hist)                     # RCCL over xGMI when world > 1
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    b.timing_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    b.sync()
+
+    samples_per_step = total_streams * frames * 2
+    value = samples_per_step * args.steps / dt
+    corpus_i, corpus_lra = corpus_gate(hist.cpu().numpy())
+
+    if rank == 0:
+        # dominant kernel: the spectrum kernel.  Algorithmic bytes per launch:
+        # every input f32 once + every retained bin once = 4 B/sample + 4*W*2*nbins per stream.
+        fft_ms, fft_n_launch = b.timing_read(L.SS_KERNEL_FFT)
+        alg_bytes = count * (frames * 2 * 4 + lay.n_windows * lay.fft_channels * lay.n_bins * 4)
+        achieved = alg_bytes / (fft_ms / max(fft_n_launch, 1) * 1e-3) / 1e9 if fft_ms > 0 else None
+        kernels = {}
+        for k in range(L.SS_KERNEL_COUNT):
+            ms, n = b.timing_read(k)
+            kernels[L.lib().ss_kernel_name(k).decode()] = round(ms / max(n, 1), 4)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "fft_hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "audio samples/s analyzed (48 kHz stereo)", "value": value, "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.streams} streams/GPU x {args.seconds:g} s, {args.rate} Hz stereo f32 "
+                                   f"(BASELINE config 3 per GPU; config 4 at 8 GPUs): mid/side {args.fft_n}-pt Hann FFT "
+                                   f"hop {args.hop} + K-weighted gated LUFS/LRA + 4x true peak + min-max decimation "
+                                   "+ corpus gate (1 all-reduce of 2x1000 u64)",
+                       "streams_total": total_streams, "windows_per_stream": lay.n_windows, "bins": lay.n_bins,
+                       "sharding": f"streams, {world} rank(s)", "corpus_integrated_lufs": corpus_i,
+                       "corpus_lra": corpus_lra, "kernel_ms": kernels},
+            "roofline": {"bound": "hbm", "kernel": L.lib().ss_kernel_name(L.SS_KERNEL_FFT).decode(),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu:
+            cb = cpu_baseline(b, args.rate, args.fft_n, args.hop)
+            out["cpu_baseline"] = cb
+            out["config"]["gpu_over_cpu_1core"] = value / cb["value"]
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
