@@ -1,0 +1,31 @@
+"""N > 1 path on CPU: world_size-2 (and 3) gloo runs of the sharded corpus gate."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from soundscope_amd.distributed import shard_streams
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_shard_streams_partitions():
+    for n in (1, 7, 8, 1024, 8192):
+        for world in (1, 2, 3, 4, 8):
+            parts = [shard_streams(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and sum(c for _, c in parts) == n
+            assert all(parts[r][0] + parts[r][1] == parts[r + 1][0] for r in range(world - 1))
+            assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+    assert shard_streams(8192, 3, 8) == (3072, 1024)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_corpus_gate_allreduce_gloo(world):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    port = 29400 + world + (os.getpid() % 200)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(HERE, "_gloo_worker.py")]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert f"GLOO_OK world={world}" in p.stdout
