@@ -88,7 +88,7 @@ struct Ctx {
     int n_devices = 0;
     std::map<size_t, std::unique_ptr<FftTables>> fft;
     std::map<std::pair<uint32_t, size_t>, std::unique_ptr<BinTables>> bins;
-    std::map<std::pair<uint32_t, int>, std::unique_ptr<TdTables>> td;
+    std::map<std::pair<uint32_t, uint32_t>, std::unique_ptr<TdTables>> td;   // (rate, factor | channels << 8)
     DevBuf<double> hist_energies, hist_bounds;
     // scratch for the handle-less entry points (ss_get_waveform, ss_mid_side)
     DevBuf<float> scratch_in, scratch_out;
@@ -172,18 +172,18 @@ int get_bin_tables(uint32_t rate, size_t n, BinTables **out)
     return SS_OK;
 }
 
-int get_td_tables(uint32_t rate, int factor, TdTables **out)
+int get_td_tables(uint32_t rate, int factor, uint32_t channels, TdTables **out)
 {
     Ctx &c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);
-    auto key = std::make_pair(rate, factor);
+    auto key = std::make_pair(rate, (uint32_t)factor | (channels << 8));
     auto it = c.td.find(key);
     if (it != c.td.end()) { *out = it->second.get(); return SS_OK; }
     auto t = std::make_unique<TdTables>();
     ssk::TdConst &k = t->host;
     std::memset(&k, 0, sizeof k);
     sst::kweight_design((double)rate, k.b, k.a);
-    for (int s = 0; s < 8; s++) sst::kweight_transition_pow(k.a, (uint64_t)ssk::kTdChunk << s, k.m_pow[s]);
+    for (int s = 0; s < 8; s++) sst::kweight_transition_pow(k.a, (uint64_t)ssk::td_chunk_frames(channels, (rate + 5) / 10) << s, k.m_pow[s]);
     k.tp_factor = factor;
     k.tp_len = 0;
     if (factor) {
@@ -220,13 +220,14 @@ int get_hist_tables(const double **energies, const double **bounds)
 
 bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 
+// run-in of time segments > 0 in the time-domain kernel: 0.3 s, e^-72 of the initial state survives
+constexpr uint32_t kTdWarmSub = 3;
+
 int meter_args_ok(uint32_t channels, uint32_t rate)
 {
     // EbuR128::new: channels == 0 || > 64, rate < 16 || > 2_822_400 -> Error::NoMem
     if (channels == 0 || channels > 64) return SS_ERR_NOMEM;
     if (rate < 16 || rate > 2822400) return SS_ERR_NOMEM;
-    // sub-blocks shorter than one chunk are not supported by the chunked recurrence
-    if ((rate + 5) / 10 < (uint32_t)ssk::kTdChunk) return SS_ERR_UNSUPPORTED;
     return SS_OK;
 }
 
@@ -264,7 +265,7 @@ int handle_make_meter(ss_analyzer *h, uint32_t channels, uint32_t rate)
     if (rc) return rc;
     h->channels = channels;
     h->tp_factor = h->tp_cfg ? h->tp_cfg : sst::true_peak_factor_for_rate(rate);
-    rc = get_td_tables(rate, h->tp_factor, &h->td);
+    rc = get_td_tables(rate, h->tp_factor, channels, &h->td);
     if (rc) return rc;
     const uint64_t s100 = (rate + 5) / 10;
     uint64_t ring_frames = (uint64_t)rate * 3000 / 1000;
@@ -536,6 +537,7 @@ int ss_add_samples(ss_analyzer *h, const float *samples, size_t n)
         p.k = h->td->dev.p; p.state = h->state.p;
         p.subblocks = h->sub.p; p.sub_stride = 0; p.sub_cap = ss_analyzer::kSubCap;
         p.ring = h->ring.p; p.ring_frames = h->ring_frames; p.tp_factor = h->tp_factor;
+        p.s100 = (uint32_t)S; p.nseg = 1; p.seg_sub = 0; p.warm_sub = 0;
         HIPCHK(ssk::launch_time_domain(p, h->stream));
         const uint64_t sb0 = h->frames_fed / S, sb1 = (h->frames_fed + take) / S;
         if (sb1 > sb0) {
@@ -674,6 +676,7 @@ struct ss_batch {
     uint64_t first_start = 0;
     uint32_t wave_window = 0;
     uint32_t windows_per_block = 16;
+    uint32_t td_nseg = 1, td_seg_sub = 0;
     FftTables *ft = nullptr;
     BinTables *bt = nullptr;
     TdTables *td = nullptr;
@@ -760,10 +763,23 @@ int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
         b->tp_factor = (cfg->flags & SS_BATCH_TRUE_PEAK)
                            ? (cfg->true_peak_factor ? cfg->true_peak_factor : sst::true_peak_factor_for_rate(cfg->sample_rate))
                            : 0;
-        int rc = get_td_tables(cfg->sample_rate, b->tp_factor, &b->td);
+        int rc = get_td_tables(cfg->sample_rate, b->tp_factor, C, &b->td);
         if (rc) return rc;
         const uint64_t S = b->td->host.s100;
         L.n_subblocks = (uint32_t)(F / S);
+        // time segments per stream: enough waves to fill the chip (16 per CU x 256 CUs), each at
+        // least 8 sub-blocks long so the 3-sub-block filter run-in stays a small overhead
+        {
+            const uint32_t nsub = L.n_subblocks;
+            uint32_t want = (4096u + cfg->n_streams - 1) / cfg->n_streams;
+            if (want > nsub / 8) want = nsub / 8;
+            if (want < 1) want = 1;
+            uint32_t seg_sub = want > 1 ? (nsub + want - 1) / want : 0;
+            if (want > 1 && seg_sub < kTdWarmSub) { want = 1; seg_sub = 0; }
+            b->td_nseg = want > 1 ? (nsub + seg_sub - 1) / seg_sub : 1;
+            b->td_seg_sub = seg_sub;
+            if (b->td_nseg <= 1) { b->td_nseg = 1; b->td_seg_sub = 0; }
+        }
         HIPCHK(b->state.alloc(cfg->n_streams));
         HIPCHK(b->sub.alloc((size_t)cfg->n_streams * (L.n_subblocks ? L.n_subblocks : 1) * C));
         HIPCHK(b->hist.alloc((size_t)cfg->n_streams * 2 * sst::kHistBins));
@@ -892,6 +908,7 @@ int ss_batch_run(ss_batch *b)
         p.n_streams = c.n_streams; p.channels = C; p.k = b->td->dev.p; p.state = b->state.p;
         p.subblocks = b->sub.p; p.sub_cap = L.n_subblocks ? L.n_subblocks : 1;
         p.sub_stride = (uint64_t)p.sub_cap * C; p.ring = nullptr; p.ring_frames = 0; p.tp_factor = b->tp_factor;
+        p.s100 = b->td->host.s100; p.nseg = b->td_nseg; p.seg_sub = b->td_seg_sub; p.warm_sub = kTdWarmSub;
         HIPCHK(ssk::launch_time_domain(p, b->stream));
     }
     HIPCHK(rec(2 * SS_KERNEL_TIME_DOMAIN + 1));

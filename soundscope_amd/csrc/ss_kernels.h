@@ -10,8 +10,6 @@ namespace ssk {
 
 constexpr int kHistBins = 1000;
 constexpr int kMaxChannels = 64;
-constexpr int kTdChunk = 48;      // frames per sequential chunk in the time-domain kernel
-constexpr int kTdThreads = 256;
 constexpr int kTpHistMax = 24;    // longest polyphase branch (factor 2)
 
 // ---- spectrum ---------------------------------------------------------------
@@ -44,7 +42,7 @@ hipError_t launch_fft_generic(const FftBatchParams &p, int mode, hipStream_t s);
 // ---- time domain ------------------------------------------------------------
 struct TdConst {                 // one per (rate, true-peak factor), device resident
     double b[5], a[5];
-    double m_pow[8][16];         // (A^L)^(2^k), A = zero-input transition, L = kTdChunk
+    double m_pow[8][16];         // (A^L)^(2^k), A = zero-input transition, L = td_chunk_frames(C)
     float tp[3][kTpHistMax];     // polyphase branches 1..factor-1, coefficient of x[n - t]
     int32_t tp_factor;           // 0, 2, 4
     int32_t tp_len;              // taps per branch (12 or 24)
@@ -75,8 +73,14 @@ struct TdParams {
     double *ring;                // optional filtered-sample ring [ring_frames][channels] (handle API)
     uint64_t ring_frames;
     int32_t tp_factor;           // must equal k->tp_factor (selects the kernel instantiation)
+    uint32_t s100;               // must equal k->s100
+    uint32_t nseg;               // time segments per stream (1 for streaming calls)
+    uint32_t seg_sub;            // sub-blocks per segment (nseg > 1)
+    uint32_t warm_sub;           // run-in sub-blocks of segments > 0
 };
 hipError_t launch_time_domain(const TdParams &p, hipStream_t s);
+// frames per sequential chunk for a channel count (the constant block's m_pow must match)
+uint32_t td_chunk_frames(uint32_t channels, uint32_t s100);
 
 struct FinalizeParams {
     const TdConst *k;

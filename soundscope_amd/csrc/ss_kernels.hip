@@ -7,6 +7,9 @@
 // reference has no GPU code.
 #include "ss_kernels.h"
 
+#ifndef SS_TD_WAVES
+#define SS_TD_WAVES 4    // min waves per SIMD the time-domain kernel is register-allocated for
+#endif
 #ifndef SS_FFT_WAVES
 #define SS_FFT_WAVES 2   // min waves per SIMD the N=4096 kernel is register-allocated for
 #endif
@@ -318,21 +321,51 @@ hipError_t launch_fft_generic(const FftBatchParams &p, int mode, hipStream_t s)
 // ============================================================================
 //  Time domain: K-weighting IIR (f64), 100 ms sub-block energies, sample peak
 //  and polyphase true peak (f32) — EbuR128::add_frames_f32 of ebur128 0.1.10
-//  (called at analyzer.rs:140 and :176), re-cut for a GPU:
+//  (called at analyzer.rs:140 and :176), re-cut for CDNA4:
 //
-//  One workgroup owns one stream and walks it tile by tile; a tile is (a piece
-//  of) one 100 ms sub-block.  Inside a tile each thread owns one
-//  (chunk of L frames, channel).  The recurrence is broken by the linear-system
-//  identity  state_out = A^L state_in + zero_state_response:
-//    pass 1: per chunk, run the state recurrence from zero            (4 FMA)
-//    scan  : Hillis-Steele over chunks with the constant matrices (A^L)^(2^k)
-//    pass 2: rerun each chunk from its true initial state, accumulate y^2,
-//            and evaluate the polyphase FIR / peaks on the same samples.
-//  All f64 work keeps the reference's recurrence; only the association of the
-//  carried state (1e-16 relative) differs.
+//  Unit of work = one WAVE (64 lanes) walking one time segment of one stream,
+//  tile by tile; a tile is (a piece of) one 100 ms sub-block staged into the
+//  wave's private LDS slice in its natural interleaved layout behind a
+//  24-frame halo.  Waves never synchronise with each other: no s_barrier in
+//  the kernel, 16 waves per CU hide each other's LDS / HBM latency.
+//
+//  * Segments.  A stream is cut into `nseg` runs of whole sub-blocks so that a
+//    batch of a few hundred streams still fills 4096 wave slots.  Segment k > 0
+//    starts its filter `warm` sub-blocks (0.3 s) early from a zero state and
+//    discards that run-in: the K-weighting poles (|z| <= 0.99502 at 48 kHz,
+//    i.e. e^-240 per second at any rate) shrink the influence of the unknown
+//    initial state by e^-72 ~ 5e-32 — sixteen orders below f64 rounding — so the
+//    result equals the sequential recurrence to the last bit that f64 carries.
+//    Segment 0 (and every streaming call, nseg = 1) starts from the true state.
+//  * K-weighting on the f64 VALU.  Each lane owns one (chunk of L frames,
+//    channel); the recurrence is cut by  state_out = A^L state_in + zero_state:
+//      pass 1: per chunk, run the state recurrence from zero              (4 FMA)
+//      scan  : in-wave Hillis-Steele over chunks (ds_bpermute shuffles) with the
+//              constant matrices (A^L)^(2^k)
+//      pass 2: rerun each chunk from its true initial state, accumulate y^2.
+//    L is chosen with (L-1)*C = 0 (mod 32) so the per-lane walk through the
+//    interleaved tile is bank-conflict free without padding.
+//  * True peak on the f32 MATRIX pipe, concurrently with other waves' f64 VALU
+//    work: the polyphase FIR  y_f[n] = sum_t c_f[t] x[n-t]  over a block of BLK
+//    consecutive outputs is a banded-Toeplitz product
+//      D[(f,r), col] = sum_k A[(f,r), k] * B[k, col],
+//      A[(f,r), k] = c_f[HIST-1 + r - k],  B[k, col] = x[start_col - (HIST-1) + k],
+//    issued as v_mfma_f32_16x16x4_f32 (exact f32 fma chain).  Factor 4: 3 phases x 5
+//    outputs = 15 rows over a 16-sample window (4 MFMAs per 16 columns, 70 % of
+//    the MACs useful); factor 2: 16 outputs over a 39-sample window (10 MFMAs).
+//    Phase 0 of the interpolator is the identity tap: it equals the sample peak,
+//    which true_peak() maxes in anyway (analyzer.rs:159-164 -> ebur128 true_peak).
 // ============================================================================
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
 template <int FACTOR>
-struct TpCfg { static constexpr int HIST = (FACTOR == 2) ? 24 : 12; static constexpr int BR = (FACTOR == 4) ? 3 : (FACTOR == 2 ? 1 : 0); };
+struct TpCfg {
+    static constexpr int HIST = (FACTOR == 2) ? 24 : 12;     // taps per polyphase branch
+    static constexpr int NPH = (FACTOR == 4) ? 3 : (FACTOR == 2 ? 1 : 0);
+    static constexpr int BLK = (FACTOR == 4) ? 5 : 16;       // outputs per column
+    static constexpr int ROWS = NPH * BLK;                   // 15 or 16
+    static constexpr int KSTEPS = (BLK + HIST - 1 + 3) / 4;  // 4 or 10
+};
 
 __device__ __forceinline__ void mat4_apply_add(const double *__restrict__ M, const double (&x)[4], double (&z)[4])
 {
@@ -341,235 +374,427 @@ __device__ __forceinline__ void mat4_apply_add(const double *__restrict__ M, con
         z[r] = fma(M[r * 4 + 0], x[0], fma(M[r * 4 + 1], x[1], fma(M[r * 4 + 2], x[2], fma(M[r * 4 + 3], x[3], z[r]))));
 }
 
-template <int FACTOR, bool RING>
-__global__ __launch_bounds__(kTdThreads) void k_time_domain(TdParams p, uint32_t pst /*padded chunk stride, dwords*/)
-{
-    constexpr int L = kTdChunk;
-    constexpr int HIST = TpCfg<FACTOR>::HIST;
-    constexpr int BR = TpCfg<FACTOR>::BR;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // carve: scan buffers (2 x 256 x 4 f64), carry (64 x 4 f64), acc (64 f64), tile, halo, peaks
-    double *zsA = reinterpret_cast<double *>(smem);                 // 8192 B
-    double *zsB = zsA + kTdThreads * 4;                              // 8192 B
-    double *carry = zsB + kTdThreads * 4;                            // 2048 B
-    double *accs = carry + kMaxChannels * 4;                         //  512 B
-    unsigned *pk = reinterpret_cast<unsigned *>(accs + kMaxChannels); // 2 x 64 x 4 = 512 B
-    float *halo = reinterpret_cast<float *>(pk + 2 * kMaxChannels);  // (kTpHistMax-1) x C, sized for 64 ch: 5888 B
-    float *tile = halo + (kTpHistMax - 1) * kMaxChannels;
+constexpr int kTdHaloFrames = 24;     // >= HIST-1 of the longest branch; keeps the tile 16-B aligned
+constexpr int kTdTailFrames = 16;     // slack past the tile end for the last MFMA window
+constexpr int kTdWavesPerBlock = 4;
+constexpr int kTdPrefetch = 8;        // float4 per lane held in flight for the next tile
+constexpr int kTdBatch = 11;          // LDS reads issued together in the sequential passes
 
+// one K-weighting state step (DF-II, zero-based state v1..v4); the critical path is one FMA
+#define SS_KW_STATE(xd)                         \
+    double t_ = fma(-a2, v2, (xd));             \
+    t_ = fma(-a3, v3, t_);                      \
+    t_ = fma(-a4, v4, t_);                      \
+    const double v0_ = fma(-a1, v1, t_);
+#define SS_KW_SHIFT() v4 = v3; v3 = v2; v2 = v1; v1 = v0_;
+#define SS_KW_OUT()                              \
+    double u_ = b1 * v1;                         \
+    u_ = fma(b2, v2, u_);                        \
+    u_ = fma(b3, v3, u_);                        \
+    u_ = fma(b4, v4, u_);                        \
+    const double y_ = fma(b0, v0_, u_);
+
+// CT: compile-time channel count (0 = runtime)
+template <int FACTOR, bool RING, int CT>
+__global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_domain(TdParams p, uint32_t L, uint32_t tile_len,
+                                                                                      uint32_t wave_lds_floats)
+{
+    using Cfg = TpCfg<FACTOR>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave_in_block = threadIdx.x >> 6;
+    const uint32_t gw = blockIdx.x * kTdWavesPerBlock + wave_in_block;   // global wave = (stream, segment)
+    if (gw >= p.n_streams * p.nseg) return;                                // whole wave leaves (no barriers used)
+    const uint32_t stream = gw / p.nseg, sg = gw - stream * p.nseg;
+
+    float *tilebuf = reinterpret_cast<float *>(smem) + (size_t)wave_in_block * wave_lds_floats;
     const TdConst &K = *p.k;
-    const uint32_t C = p.channels;
-    const uint32_t S = K.s100;
-    const uint32_t nch = kTdThreads / C;
-    const uint32_t tile_cap = nch * L;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t chunk = tid / C, ch = tid - chunk * C;
+    const uint32_t C = CT ? (uint32_t)CT : p.channels;
+    const uint32_t S = p.s100;
+    const uint32_t nch = 64u / C;                       // chunks per tile (C <= 64)
+    const uint32_t chunk = lane / C, ch = lane - chunk * C;
     const bool lane_ok = chunk < nch;
-    const uint32_t stream = blockIdx.x;
+    float *tile = tilebuf + kTdHaloFrames * C;          // tile[f*C + c]; tile[-q*C + c] = x[-q]
+    unsigned *tpk = reinterpret_cast<unsigned *>(tilebuf + wave_lds_floats - kMaxChannels);   // per-channel peak slots
     TdState &st = p.state[stream];
     const float *src = p.pcm + (size_t)stream * p.stream_stride;
 
-    // ---- load per-stream state
-    if (tid < C) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) carry[tid * 4 + q] = st.v[tid][q];
-        accs[tid] = st.acc[tid];
-        pk[tid] = __float_as_uint(st.sample_peak[tid]);
-        pk[kMaxChannels + tid] = __float_as_uint(st.true_peak[tid]);
-        for (int q = 1; q < kTpHistMax; q++) halo[(q - 1) * C + tid] = st.tp_hist[tid][q - 1];   // halo[q-1] = x[-q]
+    // ---- this wave's frame range (relative to the call) and its run-in.
+    // Segment boundaries sit on the absolute sub-block grid so every sub-block has one owner.
+    // Multi-segment (batch) launches start from a reset meter by contract: segments must not read
+    // state another segment of the same launch writes at its end.
+    const bool carry_in = (p.nseg == 1);
+    const uint64_t fed0 = carry_in ? st.frames_fed : 0;
+    uint64_t seg_begin, seg_end;                        // frames of this call, [begin, end)
+    if (p.nseg == 1) { seg_begin = 0; seg_end = p.n_frames; }
+    else {
+        seg_begin = (uint64_t)sg * p.seg_sub * S;
+        seg_end = (sg + 1 == p.nseg) ? p.n_frames : (uint64_t)(sg + 1) * p.seg_sub * S;
+        if (seg_begin > p.n_frames) seg_begin = p.n_frames;
+        if (seg_end > p.n_frames) seg_end = p.n_frames;
     }
-    uint64_t abs_frame = st.frames_fed;
-    __syncthreads();
+    const uint64_t warm_frames = (sg == 0) ? 0 : (uint64_t)p.warm_sub * S;   // sg > 0 implies seg_begin >= warm
+    uint64_t pos = seg_begin - warm_frames;             // first frame this wave reads
+    uint32_t off = (uint32_t)((fed0 + pos) % S);        // position inside the current sub-block
+    uint64_t sb = (fed0 + pos) / S;                     // absolute sub-block index
 
+    // ---- initial state: the stream's carried state (streaming call) or zeros
+    double cv[4] = {0.0, 0.0, 0.0, 0.0};               // carry, held by every lane of channel `ch`
+    double e_run = 0.0;                                 // this lane's share of the current sub-block's energy
+    float sp_run = 0.0f, tp_run = 0.0f;
+    if (carry_in && lane_ok) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) cv[q] = st.v[ch][q];
+        if (lane < C) e_run = st.acc[lane];
+    }
+    if (lane < C) {
+        for (int q = 1; q <= kTdHaloFrames; q++)
+            tile[-(int)(q * C) + (int)lane] = (carry_in && q <= kTpHistMax) ? st.tp_hist[lane][q - 1] : 0.0f;
+    }
+    tpk[lane] = 0u;
+
+    // ---- constant A fragments of the banded-Toeplitz true-peak product, and this lane's column role
+    const int mrow = lane & 15, kq = lane >> 4;
+    float afrag[Cfg::KSTEPS > 0 ? Cfg::KSTEPS : 1];
+    const bool tp_fixed = (16u % C) == 0u;              // each lane's column always belongs to one channel
+    const uint32_t tp_bpg = 16u / (tp_fixed ? C : 1u);  // blocks per 16-column group
+    const uint32_t tp_c = (uint32_t)mrow % C;
+    int tp_lane_off = 0;                                // float offset of this lane's window inside group 0
+    if (FACTOR != 0) {
+        const int fph = mrow / Cfg::BLK, r = mrow - fph * Cfg::BLK;
+#pragma unroll
+        for (int s = 0; s < Cfg::KSTEPS; s++) {
+            const int k = 4 * s + kq;
+            const int t = Cfg::HIST - 1 + r - k;
+            afrag[s] = (mrow < Cfg::ROWS && t >= 0 && t < Cfg::HIST) ? K.tp[fph][t] : 0.0f;   // row 15 (factor 4) is all zero
+        }
+        tp_lane_off = ((int)((uint32_t)mrow / C) * Cfg::BLK - (Cfg::HIST - 1) + kq) * (int)C + (int)tp_c;
+    }
     const double a1 = K.a[1], a2 = K.a[2], a3 = K.a[3], a4 = K.a[4];
     const double b0 = K.b[0], b1 = K.b[1], b2 = K.b[2], b3 = K.b[3], b4 = K.b[4];
 
-    uint64_t pos = 0;
-    while (pos < p.n_frames) {
-        const uint32_t off = (uint32_t)(abs_frame % S);
-        uint64_t seg64 = S - off;
-        if (seg64 > tile_cap) seg64 = tile_cap;
-        if (seg64 > p.n_frames - pos) seg64 = p.n_frames - pos;
-        const uint32_t seg = (uint32_t)seg64;
+    // tile geometry: a tile never crosses a sub-block boundary of the absolute grid; a sub-block is
+    // cut into equal pieces of at most tile_len frames
+#define SS_TILE_FRAMES(at, off_in, out)                                     \
+    do {                                                                    \
+        uint64_t n_ = 0;                                                    \
+        if ((at) < seg_end) {                                               \
+            n_ = tile_len - ((off_in) % tile_len);                          \
+            if (n_ > S - (off_in)) n_ = S - (off_in);                       \
+            if (n_ > seg_end - (at)) n_ = seg_end - (at);                   \
+        }                                                                   \
+        (out) = (uint32_t)n_;                                               \
+    } while (0)
+    // register prefetch of a tile: kTdPrefetch float4 per lane (clamped index keeps it branch-free)
+#define SS_PREFETCH(at, frames)                                             \
+    do {                                                                    \
+        const float *g_ = src + (at) * C;                                   \
+        const uint32_t nv_ = ((frames) * C) >> 2;                           \
+        if (nv_ != 0 && (reinterpret_cast<uintptr_t>(g_) & 15u) == 0) {     \
+            const float4 *g4_ = reinterpret_cast<const float4 *>(g_);       \
+            _Pragma("unroll") for (int q_ = 0; q_ < kTdPrefetch; q_++) {    \
+                uint32_t i_ = lane + 64u * q_;                              \
+                i_ = i_ < nv_ ? i_ : nv_ - 1;                               \
+                pf[q_] = g4_[i_];                                           \
+            }                                                               \
+        }                                                                   \
+    } while (0)
+
+    float4 pf[kTdPrefetch];
+#pragma unroll
+    for (int q = 0; q < kTdPrefetch; q++) pf[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t seg;
+    SS_TILE_FRAMES(pos, off, seg);
+    SS_PREFETCH(pos, seg);
+
+    while (seg != 0) {
+        // keep the scan matrices in memory (scalar loads at the point of use): hoisting all of them
+        // out of the tile loop would cost 224 SGPRs
+        const double *mpow = &K.m_pow[0][0];
+        asm volatile("" : "+s"(mpow));
+        const bool warm = pos < seg_begin;              // run-in tile: filter only
         const uint32_t nchunks = (seg + L - 1) / L;
 
-        // ---- stage the tile: coalesced global reads, padded chunk-major LDS image
+        // ---- stage the tile from the prefetch registers (remainder / unaligned: direct)
         {
             const float *g = src + pos * C;
-            const uint32_t total = seg * C, lc = L * C;
-            uint32_t cidx = tid / lc, r = tid - cidx * lc;
-            const uint32_t dstep = kTdThreads / lc, rstep = kTdThreads - dstep * lc;
-            for (uint32_t i = tid; i < total; i += kTdThreads) {
-                tile[cidx * pst + r] = g[i];
-                cidx += dstep; r += rstep;
-                if (r >= lc) { r -= lc; cidx++; }
+            const uint32_t total = seg * C;
+            uint32_t done = 0;
+            if ((reinterpret_cast<uintptr_t>(g) & 15u) == 0) {
+                const uint32_t nv = total >> 2;
+                float4 *t4 = reinterpret_cast<float4 *>(tile);
+#pragma unroll
+                for (int q = 0; q < kTdPrefetch; q++) {
+                    const uint32_t i = lane + 64u * q;
+                    if (i < nv) t4[i] = pf[q];
+                }
+                const float4 *g4 = reinterpret_cast<const float4 *>(g);
+                for (uint32_t i = lane + 64u * kTdPrefetch; i < nv; i += 64u) t4[i] = g4[i];
+                done = nv << 2;
+            }
+            for (uint32_t i = done + lane; i < total; i += 64u) tile[i] = g[i];
+            for (uint32_t i = total + lane; i < total + kTdTailFrames * C; i += 64u) tile[i] = 0.0f;
+        }
+        // next tile's loads fly while this one is processed
+        const uint64_t npos = pos + seg;
+        uint32_t noff = off + seg;
+        const bool sub_done = (noff == S);
+        if (sub_done) noff = 0;
+        uint32_t nseg_frames;
+        SS_TILE_FRAMES(npos, noff, nseg_frames);
+        SS_PREFETCH(npos, nseg_frames);
+        __builtin_amdgcn_wave_barrier();               // LDS is in-order per wave: only ordering is needed
+
+        // ---- true peak on the matrix pipe (not during the run-in)
+        if (FACTOR != 0 && !warm) {
+            const uint32_t nblk = (seg + Cfg::BLK - 1) / Cfg::BLK;     // blocks per channel
+            const uint32_t ncol = nblk * C;
+            const uint32_t ngroups = (ncol + 15) >> 4;
+            if (tp_fixed) {
+                constexpr int GS = 16 * Cfg::BLK;                      // floats per group (16 columns x BLK outputs)
+                const uint32_t nfull = seg / (tp_bpg * Cfg::BLK);      // groups whose every output lies inside the tile
+                const float *bp = tile + tp_lane_off;
+                uint32_t gi = 0;
+                for (; gi + 2 <= nfull; gi += 2, bp += 2 * GS) {
+                    floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                    float bv0[Cfg::KSTEPS], bv1[Cfg::KSTEPS];
+#pragma unroll
+                    for (int s = 0; s < Cfg::KSTEPS; s++) { bv0[s] = bp[4 * s * (int)C]; bv1[s] = bp[GS + 4 * s * (int)C]; }
+#pragma unroll
+                    for (int s = 0; s < Cfg::KSTEPS; s++) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s], bv0[s], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s], bv1[s], acc1, 0, 0, 0);
+                    }
+                    tp_run = fmaxf(fmaxf(tp_run, fmaxf(fabsf(acc0[0]), fabsf(acc0[1]))), fmaxf(fabsf(acc0[2]), fabsf(acc0[3])));
+                    tp_run = fmaxf(fmaxf(tp_run, fmaxf(fabsf(acc1[0]), fabsf(acc1[1]))), fmaxf(fabsf(acc1[2]), fabsf(acc1[3])));
+                }
+                for (; gi < ngroups; gi++, bp += GS) {                 // odd full group and the masked tail
+                    const uint32_t bi = gi * tp_bpg + (uint32_t)mrow / C;
+                    const bool col_ok = (gi * 16 + (uint32_t)mrow) < ncol;
+                    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < Cfg::KSTEPS; s++)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s], col_ok ? bp[4 * s * (int)C] : 0.0f, acc, 0, 0, 0);
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        const int row = 4 * kq + reg;
+                        const bool ok = col_ok && (bi * Cfg::BLK + (uint32_t)(row % Cfg::BLK)) < seg;
+                        tp_run = fmaxf(tp_run, ok ? fabsf(acc[reg]) : 0.0f);
+                    }
+                }
+            } else {
+                for (uint32_t gi = 0; gi < ngroups; gi++) {             // channel counts that do not divide 16
+                    const uint32_t q = gi * 16 + (uint32_t)mrow;
+                    const uint32_t bi = q / C, c = q - bi * C;
+                    const bool col_ok = q < ncol;
+                    const float *bp = tile + ((int)(bi * Cfg::BLK) - (Cfg::HIST - 1) + kq) * (int)C + (int)c;
+                    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < Cfg::KSTEPS; s++)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s], col_ok ? bp[4 * s * (int)C] : 0.0f, acc, 0, 0, 0);
+                    float m = 0.0f;
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        const int row = 4 * kq + reg;
+                        const bool ok = col_ok && (bi * Cfg::BLK + (uint32_t)(row % Cfg::BLK)) < seg;
+                        m = fmaxf(m, ok ? fabsf(acc[reg]) : 0.0f);
+                    }
+                    if (col_ok) atomicMax(&tpk[c], __float_as_uint(m));
+                }
             }
         }
-        __syncthreads();
 
         const bool active = lane_ok && chunk < nchunks;
-        const uint32_t len = active ? ((seg - chunk * L) < (uint32_t)L ? (seg - chunk * L) : (uint32_t)L) : 0u;
-        const float *xs = tile + chunk * pst + ch;
+        const uint32_t len = active ? ((seg - chunk * L) < L ? (seg - chunk * L) : L) : 0u;
+        const float *xs = tile + (size_t)chunk * L * C + ch;
+        const uint32_t nb_full = L / kTdBatch;          // whole batches in a full chunk
 
         // ---- pass 1: zero-state response of the state recurrence
         double z[4] = {0.0, 0.0, 0.0, 0.0};
-        if (active) {
+        {
             double v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0;
-            for (uint32_t i = 0; i < len; i++) {
-                const double x = (double)xs[i * C];
-                const double v0 = x - a1 * v1 - a2 * v2 - a3 * v3 - a4 * v4;
-                v4 = v3; v3 = v2; v2 = v1; v1 = v0;
-            }
-            z[0] = v1; z[1] = v2; z[2] = v3; z[3] = v4;
-            if (chunk == 0) {
-                const double cin[4] = {carry[ch * 4 + 0], carry[ch * 4 + 1], carry[ch * 4 + 2], carry[ch * 4 + 3]};
-                mat4_apply_add(K.m_pow[0], cin, z);
-            }
-        }
-        // ---- scan over chunks (ping-pong, one barrier per step)
-        double *cur = zsA, *nxt = zsB;
+            uint32_t i = 0;
+            if (len == L) {                             // full chunk: batched, predicate-free
+                const float *xp = xs;
+                for (uint32_t bq = 0; bq < nb_full; bq++, xp += kTdBatch * C) {
+                    float xb[kTdBatch];
 #pragma unroll
-        for (int q = 0; q < 4; q++) cur[tid * 4 + q] = z[q];
-        __syncthreads();
-        for (int kstep = 0; (1u << kstep) < nchunks; kstep++) {
-            const uint32_t d = 1u << kstep;
-            if (active && chunk >= d) {
-                const uint32_t ptid = tid - d * C;
-                const double xin[4] = {cur[ptid * 4 + 0], cur[ptid * 4 + 1], cur[ptid * 4 + 2], cur[ptid * 4 + 3]};
-                mat4_apply_add(K.m_pow[kstep], xin, z);
-            }
+                    for (int u = 0; u < kTdBatch; u++) xb[u] = xp[u * (int)C];
 #pragma unroll
-            for (int q = 0; q < 4; q++) nxt[tid * 4 + q] = z[q];
-            __syncthreads();
-            double *tmp = cur; cur = nxt; nxt = tmp;
-        }
-        // cur[i] = state after chunk i (valid for full chunks)
-
-        // ---- pass 2: true-state rerun + energy + peaks
-        double e = 0.0;
-        double v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0;
-        if (active) {
-            if (chunk == 0) { v1 = carry[ch * 4 + 0]; v2 = carry[ch * 4 + 1]; v3 = carry[ch * 4 + 2]; v4 = carry[ch * 4 + 3]; }
-            else { const uint32_t ptid = tid - C; v1 = cur[ptid * 4 + 0]; v2 = cur[ptid * 4 + 1]; v3 = cur[ptid * 4 + 2]; v4 = cur[ptid * 4 + 3]; }
-            float sp = 0.0f, tp = 0.0f;
-            float h[HIST];
-            if (FACTOR != 0) {
-                // h[(i - t) mod HIST] = x[i - t]; before the chunk: slot HIST - t holds x[-t]
-#pragma unroll
-                for (int tt = 1; tt < HIST; tt++) {
-                    float hv;
-                    if (chunk == 0) hv = halo[(tt - 1) * C + ch];
-                    else hv = (tile + (chunk - 1) * pst + ch)[(L - tt) * C];
-                    h[HIST - tt] = hv;
+                    for (int u = 0; u < kTdBatch; u++) { SS_KW_STATE((double)xb[u]) SS_KW_SHIFT() }
                 }
-                h[0] = 0.0f;
+                i = nb_full * kTdBatch;
             }
-            const uint64_t ring_base = abs_frame + (uint64_t)chunk * L;
-            for (uint32_t i0 = 0; i0 < (uint32_t)L; i0 += HIST) {
+            for (; i < len; i++) { SS_KW_STATE((double)xs[i * C]) SS_KW_SHIFT() }
+            z[0] = v1; z[1] = v2; z[2] = v3; z[3] = v4;
+            if (active && chunk == 0) mat4_apply_add(mpow, cv, z);
+        }
+        // ---- in-wave scan over chunks: z_i += (A^L)^(2^k) z_{i - 2^k}
+        for (int kstep = 0; (1u << kstep) < nchunks; kstep++) {
+            const uint32_t d = (1u << kstep) * C;
+            const double xin[4] = {__shfl_up(z[0], d, 64), __shfl_up(z[1], d, 64), __shfl_up(z[2], d, 64), __shfl_up(z[3], d, 64)};
+            if (active && lane >= d) mat4_apply_add(mpow + 16 * kstep, xin, z);
+        }
+        // z = state after this lane's chunk (valid for full chunks); initial state = previous chunk's
+        double v1, v2, v3, v4;
+        {
+            const double p0 = __shfl_up(z[0], C, 64), p1 = __shfl_up(z[1], C, 64), p2 = __shfl_up(z[2], C, 64), p3 = __shfl_up(z[3], C, 64);
+            const bool first = chunk == 0;
+            v1 = first ? cv[0] : p0; v2 = first ? cv[1] : p1; v3 = first ? cv[2] : p2; v4 = first ? cv[3] : p3;
+        }
+
+        // ---- pass 2: true-state rerun + energy + sample peak
+        {
+            double e = 0.0;
+            float sp = 0.0f;
+            uint32_t i = 0;
+            const uint64_t ring_base = fed0 + pos + (uint64_t)chunk * L;
+            if (len == L) {
+                const float *xp = xs;
+                for (uint32_t bq = 0; bq < nb_full; bq++, xp += kTdBatch * C) {
+                    float xb[kTdBatch];
 #pragma unroll
-                for (int u = 0; u < HIST; u++) {
-                    const uint32_t i = i0 + u;
-                    if (i < len) {
-                        const float xf = xs[i * C];
-                        sp = fmaxf(sp, fabsf(xf));
-                        if (FACTOR != 0) {
-                            h[u] = xf;
+                    for (int u = 0; u < kTdBatch; u++) xb[u] = xp[u * (int)C];
 #pragma unroll
-                            for (int f = 0; f < BR; f++) {
-                                float acc = 0.0f;
-#pragma unroll
-                                for (int tt = 0; tt < HIST; tt++) acc = fmaf(h[(u - tt + HIST) % HIST], K.tp[f][tt], acc);
-                                tp = fmaxf(tp, fabsf(acc));
-                            }
-                        }
-                        const double x = (double)xf;
-                        const double v0 = x - a1 * v1 - a2 * v2 - a3 * v3 - a4 * v4;
-                        const double y = b0 * v0 + b1 * v1 + b2 * v2 + b3 * v3 + b4 * v4;
-                        v4 = v3; v3 = v2; v2 = v1; v1 = v0;
-                        e = fma(y, y, e);
-                        if (RING) p.ring[((ring_base + i) % p.ring_frames) * C + ch] = y;
+                    for (int u = 0; u < kTdBatch; u++) {
+                        sp = fmaxf(sp, fabsf(xb[u]));
+                        SS_KW_STATE((double)xb[u]) SS_KW_OUT() SS_KW_SHIFT()
+                        e = fma(y_, y_, e);
+                        if (RING) p.ring[((ring_base + bq * kTdBatch + u) % p.ring_frames) * C + ch] = y_;
                     }
                 }
+                i = nb_full * kTdBatch;
             }
-            atomicMax(&pk[ch], __float_as_uint(sp));
-            if (FACTOR != 0) atomicMax(&pk[kMaxChannels + ch], __float_as_uint(tp));
-        }
-        __syncthreads();   // all reads of cur / carry / halo / tile-history done
-        // carry-out: exact state after the last valid sample
-        if (active && chunk == nchunks - 1) { carry[ch * 4 + 0] = v1; carry[ch * 4 + 1] = v2; carry[ch * 4 + 2] = v3; carry[ch * 4 + 3] = v4; }
-        // new halo: x[end - q], q = 1..kTpHistMax-1
-        if (tid < C) {
-            float nh[kTpHistMax - 1];
-#pragma unroll
-            for (int q = 1; q < kTpHistMax; q++) {
-                float hv;
-                if ((uint32_t)q <= seg) { const uint32_t f = seg - q; hv = tile[(f / L) * pst + (f % L) * C + tid]; }
-                else hv = halo[(q - seg - 1) * C + tid];
-                nh[q - 1] = hv;
+            for (; i < len; i++) {
+                const float xf = xs[i * C];
+                sp = fmaxf(sp, fabsf(xf));
+                SS_KW_STATE((double)xf) SS_KW_OUT() SS_KW_SHIFT()
+                e = fma(y_, y_, e);
+                if (RING) p.ring[((ring_base + i) % p.ring_frames) * C + ch] = y_;
             }
-#pragma unroll
-            for (int q = 0; q < kTpHistMax - 1; q++) halo[q * C + tid] = nh[q];
+            if (!warm) { e_run += e; sp_run = fmaxf(sp_run, sp); }
         }
-        // ---- deterministic tree reduction of the chunk energies per channel
-        double *es = zsA;     // both scan buffers are free now
-        es[tid] = e;
-        __syncthreads();
-        for (uint32_t sft = 128; sft >= 1; sft >>= 1) {
-            if (lane_ok && chunk < sft && chunk + sft < nchunks) es[tid] += es[tid + sft * C];
-            __syncthreads();
+        // carry-out: exact state after the last valid sample, broadcast to every lane of the channel
+        {
+            const uint32_t src_lane = (nchunks - 1) * C + ch;
+            cv[0] = __shfl(v1, src_lane, 64); cv[1] = __shfl(v2, src_lane, 64);
+            cv[2] = __shfl(v3, src_lane, 64); cv[3] = __shfl(v4, src_lane, 64);
         }
-        if (tid < C) {
-            double a = accs[tid] + es[tid];
-            if (off + seg == S) {
-                const uint64_t sb = abs_frame / S;
-                p.subblocks[(size_t)stream * p.sub_stride + (size_t)(sb % p.sub_cap) * C + tid] = a;
-                a = 0.0;
+        // ---- sub-block complete: deterministic tree over the lanes' energy shares (fixed shape)
+        if (sub_done) {
+            if (!warm) {
+                double e = e_run;
+                for (uint32_t d = 32; d >= 1; d >>= 1) {
+                    const double o = __shfl_down(e, d * C, 64);
+                    if (lane + d * C < 64u) e += o;
+                }
+                if (lane < C) p.subblocks[(size_t)stream * p.sub_stride + (size_t)(sb % p.sub_cap) * C + lane] = e;
             }
-            accs[tid] = a;
+            e_run = 0.0;
+            sb++;
         }
-        __syncthreads();
-        abs_frame += seg;
-        pos += seg;
+        // ---- new halo: the kTdHaloFrames frames before the tile end (a contiguous copy; when the tile
+        // is shorter than the halo the source reaches into the old halo).  Ascending order is safe:
+        // the source of element j sits seg*C floats above its destination, beyond anything written so far.
+        {
+            const uint32_t hn = kTdHaloFrames * C;
+            float *dst = tile - hn;
+            const float *srcp = dst + (size_t)seg * C;
+            for (uint32_t j = lane; j < hn; j += 64u) {
+                const float v = srcp[j];
+                __builtin_amdgcn_wave_barrier();
+                dst[j] = v;
+            }
+        }
+        pos = npos;
+        off = noff;
+        seg = nseg_frames;
     }
 
-    // ---- store state
-    if (tid < C) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) st.v[tid][q] = carry[tid * 4 + q];
-        st.acc[tid] = accs[tid];
-        st.sample_peak[tid] = __uint_as_float(pk[tid]);
-        st.true_peak[tid] = __uint_as_float(pk[kMaxChannels + tid]);
-        for (int q = 1; q < kTpHistMax; q++) st.tp_hist[tid][q - 1] = halo[(q - 1) * C + tid];
-        if (tid == 0) st.frames_fed = abs_frame;
+    // ---- fold this wave's results into the stream state
+    // energy of the trailing incomplete sub-block: reduce the lanes' shares (streaming calls carry it over)
+    {
+        double e = e_run;
+        for (uint32_t d = 32; d >= 1; d >>= 1) {
+            const double o = __shfl_down(e, d * C, 64);
+            if (lane + d * C < 64u) e += o;
+        }
+        e_run = e;
     }
+    for (uint32_t d = 32; d >= 1; d >>= 1) {
+        const float o = __shfl_down(sp_run, d * C, 64);
+        if (lane + d * C < 64u) sp_run = fmaxf(sp_run, o);
+    }
+    if (FACTOR != 0 && tp_fixed) atomicMax(&tpk[tp_c], __float_as_uint(tp_run));
+    if (lane < C) {
+        if (FACTOR != 0) atomicMax(reinterpret_cast<unsigned *>(&st.true_peak[lane]), tpk[lane]);
+        atomicMax(reinterpret_cast<unsigned *>(&st.sample_peak[lane]), __float_as_uint(sp_run));
+    }
+    if (sg + 1 == p.nseg) {                              // the last segment owns the carried filter state
+        if (lane_ok && chunk == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) st.v[ch][q] = cv[q];
+        }
+        if (lane < C) {
+            st.acc[lane] = e_run;
+            for (int q = 1; q <= kTpHistMax; q++) st.tp_hist[lane][q - 1] = tile[-(int)(q * C) + (int)lane];
+        }
+        if (lane == 0) st.frames_fed = fed0 + p.n_frames;
+    }
+#undef SS_TILE_FRAMES
+#undef SS_PREFETCH
 }
 
-static uint32_t td_padded_stride(uint32_t C)
+// Chunk length L: (L-1)*C = 0 (mod 32) makes the per-lane walk through the interleaved tile touch
+// lane-linear banks; among the candidates pick the one with the fewest sequential steps per
+// sub-block (pieces * L, pieces = tiles a sub-block is cut into).
+uint32_t td_chunk_frames(uint32_t C, uint32_t s100)
 {
-    const uint32_t lc = kTdChunk * C;
-    const uint32_t pad = (C + 32 - (lc % 32)) % 32;   // chunk stride == C (mod 32): lane-linear banks
-    return lc + pad;
+    const uint32_t nch = 64u / C;
+    uint32_t best = 33, best_cost = 0xFFFFFFFFu;
+    for (uint32_t L : {33u, 49u, 65u}) {
+        if (((L - 1) * C) % 32u) continue;
+        const uint32_t cap = nch * L;
+        const uint32_t pieces = (s100 + cap - 1) / cap;
+        const uint32_t cost = pieces * L + 8 * pieces;       // per-tile fixed work ~ 8 steps
+        if (cost < best_cost) { best_cost = cost; best = L; }
+    }
+    return best;
 }
 
-template <int FACTOR, bool RING>
+template <int FACTOR, bool RING, int CT>
 static hipError_t td_launch(const TdParams &p, hipStream_t s)
 {
     const uint32_t C = p.channels;
-    const uint32_t pst = td_padded_stride(C);
-    const uint32_t nch = kTdThreads / C;
-    const size_t fixed = (size_t)kTdThreads * 4 * 8 * 2 + kMaxChannels * 4 * 8 + kMaxChannels * 8 +
-                         2 * kMaxChannels * 4 + (size_t)(kTpHistMax - 1) * kMaxChannels * 4;
-    const size_t lds = fixed + (size_t)nch * pst * 4;
-    auto fn = k_time_domain<FACTOR, RING>;
+    const uint32_t S = p.s100;
+    const uint32_t L = td_chunk_frames(C, S);
+    const uint32_t nch = 64u / C;
+    const uint32_t cap = nch * L;                                   // frames one wave can scan at once
+    const uint32_t pieces = (S + cap - 1) / cap;                    // equal tiles per sub-block
+    uint32_t tile_len = (S + pieces - 1) / pieces;
+    if (tile_len > cap) tile_len = cap;
+    // per-wave LDS: halo + tile + slack + 64 peak slots
+    uint32_t wave_floats = (kTdHaloFrames + tile_len + kTdTailFrames) * C + kMaxChannels;
+    wave_floats = (wave_floats + 3u) & ~3u;
+    const size_t lds = (size_t)wave_floats * 4 * kTdWavesPerBlock;
+    auto fn = k_time_domain<FACTOR, RING, CT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(fn, dim3(p.n_streams), dim3(kTdThreads), lds, s, p, pst);
+    const uint32_t waves = p.n_streams * p.nseg;
+    const uint32_t blocks = (waves + kTdWavesPerBlock - 1) / kTdWavesPerBlock;
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * kTdWavesPerBlock), lds, s, p, L, tile_len, wave_floats);
     return hipGetLastError();
+}
+
+template <int FACTOR, bool RING>
+static hipError_t td_launch_c(const TdParams &p, hipStream_t s)
+{
+    return p.channels == 2 ? td_launch<FACTOR, RING, 2>(p, s) : td_launch<FACTOR, RING, 0>(p, s);
 }
 
 hipError_t launch_time_domain(const TdParams &p, hipStream_t s)
@@ -578,9 +803,9 @@ hipError_t launch_time_domain(const TdParams &p, hipStream_t s)
     const int factor = p.tp_factor;
     const bool ring = p.ring != nullptr;
     switch (factor) {
-        case 4: return ring ? td_launch<4, true>(p, s) : td_launch<4, false>(p, s);
-        case 2: return ring ? td_launch<2, true>(p, s) : td_launch<2, false>(p, s);
-        default: return ring ? td_launch<0, true>(p, s) : td_launch<0, false>(p, s);
+        case 4: return ring ? td_launch_c<4, true>(p, s) : td_launch_c<4, false>(p, s);
+        case 2: return ring ? td_launch_c<2, true>(p, s) : td_launch_c<2, false>(p, s);
+        default: return ring ? td_launch_c<0, true>(p, s) : td_launch_c<0, false>(p, s);
     }
 }
 
