@@ -163,6 +163,8 @@ typedef struct ss_batch_layout {
     uint32_t first_bin;         /* FFT bin index of retained bin 0 */
     uint32_t n_wave_points;     /* per stream: 2 per decimation bin */
     uint32_t n_subblocks;       /* complete 100 ms sub-blocks per stream */
+    uint32_t fft_bin_stride;    /* floats between spectrum rows on the device (n_bins rounded up to 4) */
+    uint32_t reserved;
     uint64_t input_bytes;       /* device bytes of the input corpus */
     uint64_t fft_bytes;         /* device bytes of the spectrum output */
 } ss_batch_layout;
@@ -185,7 +187,8 @@ int ss_batch_run(ss_batch *b);
 int ss_batch_sync(ss_batch *b);
 /* results (after ss_batch_sync) */
 int ss_batch_results(ss_batch *b, ss_stream_result *out, uint32_t cap);
-/* spectrum of one stream: [n_windows][fft_channels][n_bins] f32 dB (pink-compensated) */
+/* spectrum of one stream: compact [n_windows][fft_channels][n_bins] f32 dB (pink-compensated);
+ * on the device the rows are fft_bin_stride floats apart */
 int ss_batch_download_fft(ss_batch *b, uint32_t stream, float *out, size_t cap_floats);
 /* chart_x / frequency / pink compensation per retained bin (f64, n_bins each; any may be NULL) */
 int ss_batch_bin_tables(const ss_batch *b, double *chart_x, double *freq, double *pink_db);

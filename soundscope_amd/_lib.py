@@ -53,6 +53,7 @@ class StreamResult(C.Structure):
 class BatchLayout(C.Structure):
     _fields_ = [("n_windows", C.c_uint32), ("fft_channels", C.c_uint32), ("n_bins", C.c_uint32),
                 ("first_bin", C.c_uint32), ("n_wave_points", C.c_uint32), ("n_subblocks", C.c_uint32),
+                ("fft_bin_stride", C.c_uint32), ("reserved", C.c_uint32),
                 ("input_bytes", C.c_uint64), ("fft_bytes", C.c_uint64)]
 
 

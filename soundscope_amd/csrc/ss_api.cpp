@@ -164,7 +164,7 @@ int get_bin_tables(uint32_t rate, size_t n, BinTables **out)
     auto t = std::make_unique<BinTables>();
     t->count = sst::fft_bins(rate, n, &t->first);
     sst::bin_tables(rate, n, t->freq, t->pink, t->chart_x);
-    std::vector<float> pf(t->count);
+    std::vector<float> pf((t->count + 3) & ~(size_t)3, 0.0f);    // padded to the output row stride
     for (size_t i = 0; i < t->count; i++) pf[i] = (float)t->pink[i];
     HIPCHK(t->pink_dev.upload(pf));
     *out = t.get();
@@ -428,7 +428,7 @@ int ss_get_fft(const ss_analyzer *hc, const float *samples, size_t n,
     p.tw_n = ft->tw_n.p; p.tw_256 = ft->tw_256.p; p.pink = nullptr;
     p.frames_per_stream = n; p.first_start = 0; p.n_streams = 1; p.channels = 1;
     p.n_windows = 1; p.hop = 0; p.n = (uint32_t)n;
-    p.first_bin = (uint32_t)bt->first; p.n_bins = (uint32_t)bt->count; p.windows_per_block = 1;
+    p.first_bin = (uint32_t)bt->first; p.n_bins = (uint32_t)bt->count; p.bin_stride = p.n_bins; p.windows_per_block = 1;
     p.db_offset = (float)(20.0 * std::log10(4.0 / (double)n));
     HIPCHK(ssk::launch_fft_generic(p, 0, h->stream));
     std::vector<float> db(bt->count);
@@ -756,7 +756,8 @@ int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
         L.n_bins = (uint32_t)b->bt->count;
         L.first_bin = (uint32_t)b->bt->first;
         b->fft_fast = (C == 2 && n == 4096 && hop % 256 == 0);
-        L.fft_bytes = (uint64_t)cfg->n_streams * L.n_windows * L.fft_channels * L.n_bins * sizeof(float);
+        L.fft_bin_stride = (L.n_bins + 3u) & ~3u;        // rows start 16-B aligned: 16-byte stores
+        L.fft_bytes = (uint64_t)cfg->n_streams * L.n_windows * L.fft_channels * L.fft_bin_stride * sizeof(float);
         HIPCHK(b->fft.alloc((size_t)(L.fft_bytes / sizeof(float))));
     }
     if (cfg->flags & (SS_BATCH_LUFS | SS_BATCH_TRUE_PEAK)) {
@@ -883,7 +884,7 @@ int ss_batch_run(ss_batch *b)
         p.tw_n = b->ft->tw_n.p; p.tw_256 = b->ft->tw_256.p; p.pink = b->bt->pink_dev.p;
         p.frames_per_stream = c.frames_per_stream; p.first_start = b->first_start;
         p.n_streams = c.n_streams; p.channels = C; p.n_windows = L.n_windows; p.hop = c.hop_frames;
-        p.n = c.fft_n; p.first_bin = L.first_bin; p.n_bins = L.n_bins;
+        p.n = c.fft_n; p.first_bin = L.first_bin; p.n_bins = L.n_bins; p.bin_stride = L.fft_bin_stride;
         p.windows_per_block = b->windows_per_block;
         if (b->fft_fast) {
             p.db_offset = (float)(10.0 * std::log10(4.0 / ((double)c.fft_n * (double)c.fft_n)));
@@ -980,10 +981,15 @@ int ss_batch_results(ss_batch *b, ss_stream_result *out, uint32_t cap)
 int ss_batch_download_fft(ss_batch *b, uint32_t stream, float *out, size_t cap)
 {
     if (!b || !out || stream >= b->cfg.n_streams) return SS_ERR_INVALID_ARG;
-    const size_t per = (size_t)b->lay.n_windows * b->lay.fft_channels * b->lay.n_bins;
+    const size_t rows = (size_t)b->lay.n_windows * b->lay.fft_channels;
+    const size_t per = rows * b->lay.n_bins;
     if (cap < per) return SS_ERR_CAPACITY;
     if (!per) return SS_OK;
-    HIPCHK(hipMemcpyAsync(out, b->fft.p + (size_t)stream * per, per * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    // device rows are padded to fft_bin_stride floats; hand back the compact [window][channel][bin] array
+    HIPCHK(hipMemcpy2DAsync(out, (size_t)b->lay.n_bins * sizeof(float),
+                            b->fft.p + (size_t)stream * rows * b->lay.fft_bin_stride,
+                            (size_t)b->lay.fft_bin_stride * sizeof(float), (size_t)b->lay.n_bins * sizeof(float), rows,
+                            hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return SS_OK;
 }

@@ -20,7 +20,7 @@ struct FftBatchParams {
     const float *half_window;    // N (4096 kernel)   — 0.5 * Hann
     const float2 *tw_n;          // W_N^k, k < N  (4096 kernel uses k < 3841; generic k < N/2)
     const float2 *tw_256;        // W_256^k, k < 256 (4096 kernel)
-    const float *pink;           // n_bins f32, or nullptr for raw dBFS
+    const float *pink;           // bin_stride f32 (zero padded), or nullptr for raw dBFS
     uint64_t frames_per_stream;
     uint64_t first_start;        // frame index where window 0 starts
     uint32_t n_streams;
@@ -29,6 +29,7 @@ struct FftBatchParams {
     uint32_t hop;
     uint32_t n;                  // FFT length
     uint32_t first_bin, n_bins;
+    uint32_t bin_stride;         // floats between output rows (n_bins rounded up to 4: 16-B aligned rows)
     uint32_t windows_per_block;  // 4096 kernel
     float db_offset;             // 10*log10(4/N^2) (4096) or 20*log10(4/N) (generic)
 };

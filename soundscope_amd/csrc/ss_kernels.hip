@@ -95,11 +95,65 @@ __device__ __forceinline__ float db_from_sq(float q, float off)
 constexpr int kX1Stride = 272;   // 256 + 16: de-phases the 4 ka-groups of a wave across banks
 constexpr int kX2Stride = 17;    // row of 16 padded to 17: conflict-free b64 row reads
 
+// dB epilogue of one window.  xb holds the full spectrum Z[0..4095] in natural order; a thread
+// owns groups of FOUR consecutive retained bins (g = t, t + 256), so both output rows are written
+// with 16-byte stores (rows are padded to a multiple of 4 floats): the 4-byte-per-lane stores of
+// a stride-256 ownership were store-issue bound (1.6 ms of 4.7 ms at the config-3 size).
+__device__ __forceinline__ void fft4096_epilogue(const float2 *xb, int t, uint32_t first_bin, uint32_t n_bins,
+                                                 float db_offset, const float *__restrict__ pink,
+                                                 float *o_mid, float *o_side)
+{
+    const uint32_t ngroups = (n_bins + 3) >> 2;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const uint32_t g = (uint32_t)t + 256u * i;
+        if (g < ngroups) {
+            const uint32_t k0 = first_bin + 4 * g;
+            float rm[4], rs[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t k = k0 + e;                       // k <= 2051 < 4096: the mirror index stays positive
+                const float2 zk = xb[k];
+                const float2 zm = xb[4096 - k];                  // Z[N - k]
+                const float ar = zk.x + zm.x, ai = zk.y - zm.y;  // 2 * M
+                const float br = zk.y + zm.y, bi = zk.x - zm.x;  // 2 * S (up to sign / swap)
+                const float qm = fmaf(ar, ar, ai * ai);
+                const float qs = fmaf(br, br, bi * bi);
+                const float pk = pink ? pink[4 * g + e] : 0.0f;  // table padded to the row stride
+                rm[e] = db_from_sq(qm, db_offset) + pk;
+                rs[e] = db_from_sq(qs, db_offset) + pk;
+            }
+#if defined(SS_ABL) && SS_ABL == 1      /* ablation: no output stores */
+            asm volatile("" ::"v"(rm[0]), "v"(rm[1]), "v"(rm[2]), "v"(rm[3]), "v"(rs[0]), "v"(rs[1]), "v"(rs[2]), "v"(rs[3]));
+            (void)o_mid; (void)o_side;
+#else
+            reinterpret_cast<float4 *>(o_mid)[g] = make_float4(rm[0], rm[1], rm[2], rm[3]);
+            reinterpret_cast<float4 *>(o_side)[g] = make_float4(rs[0], rs[1], rs[2], rs[3]);
+#endif
+        }
+    }
+}
+
+// HS = hop / 256.  A workgroup iteration transforms TWO consecutive windows: they share the
+// sliding sample registers (16 + HS slots) and every per-thread constant, and every barrier
+// phase carries two independent radix-16 problems (half the barriers per window, twice the
+// instruction-level parallelism to cover LDS latency).
+#if defined(SS_ABL) && SS_ABL == 4      /* ablation: no butterflies */
+#define SS_FFT16(z) asm volatile("" : "+v"(z[0].x), "+v"(z[5].y), "+v"(z[10].x), "+v"(z[15].y))
+#else
+#define SS_FFT16(z) fft16(z)
+#endif
+#if defined(SS_ABL) && SS_ABL == 5      /* ablation: no barriers (racy, timing only) */
+#define SS_SYNC() __builtin_amdgcn_wave_barrier()
+#else
+#define SS_SYNC() __syncthreads()
+#endif
 template <int HS>
 __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams p)
 {
-    __shared__ __attribute__((aligned(16))) float2 xbuf[16 * kX1Stride];   // 34816 B
-    __shared__ __attribute__((aligned(16))) float2 tw2s[256];              //  2048 B
+    constexpr int NS = 16 + HS;                                              // sample slots held
+    __shared__ __attribute__((aligned(16))) float2 xbuf[2][16 * kX1Stride];  // 2 x 34816 B
+    __shared__ __attribute__((aligned(16))) float2 tw2s[256];                //  2048 B
 
     const int t = threadIdx.x;
     const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
@@ -122,93 +176,150 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
     tw2s[t] = p.tw_256[t];
 
     const int tb = t & 15, hi = t >> 4;
-    const uint32_t last_bin = p.first_bin + p.n_bins - 1;
-    const size_t out_win_stride = (size_t)2 * p.n_bins;
+    const size_t out_win_stride = (size_t)2 * p.bin_stride;
     float *outp = p.out + ((size_t)stream * p.n_windows + w_begin) * out_win_stride;
 
-    // raw sums/differences: sd[j] = (l + r, l - r) of frame t + 256 j
-    float sm[16], df[16];
+    // raw sums / differences of frame t + 256 j of the first window: (l + r, l - r)
+    float sm[NS], df[NS];
+    const bool two0 = (w_begin + 1 < w_end);
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        float2 v = src[t + 256 * j];
+    for (int j = 0; j < NS; j++) {
+        float2 v = make_float2(0.f, 0.f);
+        if (j < 16 || two0) v = src[t + 256 * j];
         sm[j] = v.x + v.y;
         df[j] = v.x - v.y;
     }
 
-    for (uint32_t w = w_begin; w < w_end; ++w) {
-        // prefetch the HS new slots of the next window (consumed after the epilogue)
-        float2 nx[HS > 0 ? HS : 1];
-        const bool more = (w + 1 < w_end);
-        if (HS > 0 && more) {
+    for (uint32_t w = w_begin; w < w_end; w += 2) {
+        const bool two = (w + 1 < w_end);
+        // prefetch the 2*HS new slots of the next pair (consumed after the epilogue)
+        float2 nx[2 * HS];
+        const bool more = (w + 2 < w_end), more2 = (w + 3 < w_end);
+        const float2 *nsrc = src + (size_t)(w - w_begin) * p.hop + t;
 #pragma unroll
-            for (int q = 0; q < HS; q++) nx[q] = src[(size_t)(w + 1 - w_begin) * p.hop + t + 256 * (16 - HS + q)];
+        for (int q = 0; q < 2 * HS; q++) {
+            nx[q] = make_float2(0.f, 0.f);
+            if (q < HS ? more : more2) nx[q] = nsrc[256 * (NS + q)];
         }
 
+        float2 z0[16], z1[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            z0[j] = make_float2(sm[j] * hw[j], df[j] * hw[j]);
+            z1[j] = make_float2(sm[j + HS] * hw[j], df[j + HS] * hw[j]);
+        }
+        // ---- pass 1
+        SS_FFT16(z0);
+        SS_FFT16(z1);
+        SS_SYNC();                       // previous pair's mirror reads are done
+        xbuf[0][t] = z0[R16(0)];
+        xbuf[1][t] = z1[R16(0)];
+#pragma unroll
+        for (int ka = 1; ka < 16; ka++) {
+            xbuf[0][ka * kX1Stride + t] = cmul(z0[R16(ka)], tw1[ka]);
+            xbuf[1][ka * kX1Stride + t] = cmul(z1[R16(ka)], tw1[ka]);
+        }
+        SS_SYNC();
+        // ---- pass 2 (thread = tb + 16 ka)
+#pragma unroll
+        for (int ta = 0; ta < 16; ta++) {
+            z0[ta] = xbuf[0][hi * kX1Stride + tb + 16 * ta];
+            z1[ta] = xbuf[1][hi * kX1Stride + tb + 16 * ta];
+        }
+        SS_FFT16(z0);
+        SS_FFT16(z1);
+        SS_SYNC();
+        xbuf[0][hi * kX2Stride + tb] = z0[R16(0)];
+        xbuf[1][hi * kX2Stride + tb] = z1[R16(0)];
+#pragma unroll
+        for (int kb = 1; kb < 16; kb++) {
+            const float2 wv = tw2s[tb * kb];
+            xbuf[0][kb * kX1Stride + hi * kX2Stride + tb] = cmul(z0[R16(kb)], wv);
+            xbuf[1][kb * kX1Stride + hi * kX2Stride + tb] = cmul(z1[R16(kb)], wv);
+        }
+        SS_SYNC();
+        // ---- pass 3 (thread = ka + 16 kb): ka = tb, kb = hi
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            z0[q] = xbuf[0][hi * kX1Stride + tb * kX2Stride + q];
+            z1[q] = xbuf[1][hi * kX1Stride + tb * kX2Stride + q];
+        }
+        SS_FFT16(z0);
+        SS_FFT16(z1);
+        SS_SYNC();
+        // ---- publish the whole spectrum in natural order: Z[t + 256 kc]
+#pragma unroll
+        for (int kc = 0; kc < 16; kc++) {
+            xbuf[0][kc * 256 + t] = z0[R16(kc)];
+            xbuf[1][kc * 256 + t] = z1[R16(kc)];
+        }
+        SS_SYNC();
+        // ---- epilogue: groups of four consecutive bins per thread, 16-byte stores
+        float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
+        fft4096_epilogue(xbuf[0], t, p.first_bin, p.n_bins, p.db_offset, p.pink, o_mid, o_mid + p.bin_stride);
+        if (two) fft4096_epilogue(xbuf[1], t, p.first_bin, p.n_bins, p.db_offset, p.pink, o_mid + out_win_stride,
+                                  o_mid + out_win_stride + p.bin_stride);
+        // ---- slide the sample registers by two hops
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < NS - 2 * HS; j++) { sm[j] = sm[j + 2 * HS]; df[j] = df[j + 2 * HS]; }
+#pragma unroll
+            for (int q = 0; q < 2 * HS; q++) {
+                if (NS - 2 * HS + q >= 0) { sm[NS - 2 * HS + q] = nx[q].x + nx[q].y; df[NS - 2 * HS + q] = nx[q].x - nx[q].y; }
+            }
+        }
+    }
+}
+
+// generic hop (not a multiple of 256 or >= N/2 slots): one window per iteration, full reload
+__global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms_anyhop(FftBatchParams p)
+{
+    __shared__ __attribute__((aligned(16))) float2 xbuf[16 * kX1Stride];
+    __shared__ __attribute__((aligned(16))) float2 tw2s[256];
+    const int t = threadIdx.x;
+    const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
+    const uint32_t stream = blockIdx.x / groups;
+    const uint32_t grp = blockIdx.x - stream * groups;
+    const uint32_t w_begin = grp * p.windows_per_block;
+    uint32_t w_end = w_begin + p.windows_per_block;
+    if (w_end > p.n_windows) w_end = p.n_windows;
+    const float2 *src = reinterpret_cast<const float2 *>(p.pcm) + (size_t)stream * p.frames_per_stream +
+                        p.first_start + (size_t)w_begin * p.hop;
+    tw2s[t] = p.tw_256[t];
+    const int tb = t & 15, hi = t >> 4;
+    const size_t out_win_stride = (size_t)2 * p.bin_stride;
+    float *outp = p.out + ((size_t)stream * p.n_windows + w_begin) * out_win_stride;
+    for (uint32_t w = w_begin; w < w_end; ++w) {
         float2 z[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) z[j] = make_float2(sm[j] * hw[j], df[j] * hw[j]);
-
-        // ---- pass 1
+        for (int j = 0; j < 16; j++) {
+            const float2 v = src[(size_t)(w - w_begin) * p.hop + t + 256 * j];
+            const float hwj = p.half_window[t + 256 * j];
+            z[j] = make_float2((v.x + v.y) * hwj, (v.x - v.y) * hwj);
+        }
         fft16(z);
-        __syncthreads();                       // previous window's mirror reads are done
+        __syncthreads();
         xbuf[t] = z[R16(0)];
 #pragma unroll
-        for (int ka = 1; ka < 16; ka++) xbuf[ka * kX1Stride + t] = cmul(z[R16(ka)], tw1[ka]);
+        for (int ka = 1; ka < 16; ka++) xbuf[ka * kX1Stride + t] = cmul(z[R16(ka)], p.tw_n[t * ka]);
         __syncthreads();
-        // ---- pass 2 (thread = tb + 16 ka)
 #pragma unroll
         for (int ta = 0; ta < 16; ta++) z[ta] = xbuf[hi * kX1Stride + tb + 16 * ta];
         fft16(z);
         __syncthreads();
         xbuf[hi * kX2Stride + tb] = z[R16(0)];
 #pragma unroll
-        for (int kb = 1; kb < 16; kb++)
-            xbuf[kb * kX1Stride + hi * kX2Stride + tb] = cmul(z[R16(kb)], tw2s[tb * kb]);
+        for (int kb = 1; kb < 16; kb++) xbuf[kb * kX1Stride + hi * kX2Stride + tb] = cmul(z[R16(kb)], tw2s[tb * kb]);
         __syncthreads();
-        // ---- pass 3 (thread = ka + 16 kb): ka = tb, kb = hi
 #pragma unroll
         for (int q = 0; q < 16; q++) z[q] = xbuf[hi * kX1Stride + tb * kX2Stride + q];
         fft16(z);
         __syncthreads();
-        // ---- mirror exchange: publish slots kc = 8..15
 #pragma unroll
-        for (int kc = 8; kc < 16; kc++) xbuf[(kc - 8) * 256 + t] = z[R16(kc)];
+        for (int kc = 0; kc < 16; kc++) xbuf[kc * 256 + t] = z[R16(kc)];
         __syncthreads();
-        // ---- epilogue: bins k = t + 256 kc, kc = 0..7
         float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
-        float *o_side = o_mid + p.n_bins;
-#pragma unroll
-        for (int kc = 0; kc < 8; kc++) {
-            const uint32_t k = (uint32_t)t + 256u * kc;
-            if (k >= p.first_bin && k <= last_bin) {
-                const float2 zk = z[R16(kc)];
-                const float2 zm = xbuf[(8 - kc) * 256 - t];      // Z[N - k]
-                const float ar = zk.x + zm.x, ai = zk.y - zm.y;  // 2 * M
-                const float br = zk.y + zm.y, bi = zk.x - zm.x;  // 2 * S (up to sign/swap)
-                const float qm = fmaf(ar, ar, ai * ai);
-                const float qs = fmaf(br, br, bi * bi);
-                const uint32_t idx = k - p.first_bin;
-                const float pk = p.pink ? p.pink[idx] : 0.0f;
-                o_mid[idx] = db_from_sq(qm, p.db_offset) + pk;
-                o_side[idx] = db_from_sq(qs, p.db_offset) + pk;
-            }
-        }
-        // ---- slide the sample registers
-        if (more) {
-            if (HS > 0) {
-#pragma unroll
-                for (int j = 0; j < 16 - HS; j++) { sm[j] = sm[j + HS]; df[j] = df[j + HS]; }
-#pragma unroll
-                for (int q = 0; q < HS; q++) { sm[16 - HS + q] = nx[q].x + nx[q].y; df[16 - HS + q] = nx[q].x - nx[q].y; }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    float2 v = src[(size_t)(w + 1 - w_begin) * p.hop + t + 256 * j];
-                    sm[j] = v.x + v.y;
-                    df[j] = v.x - v.y;
-                }
-            }
-        }
+        fft4096_epilogue(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.pink, o_mid, o_mid + p.bin_stride);
     }
 }
 
@@ -220,7 +331,7 @@ hipError_t launch_fft4096_ms(const FftBatchParams &p, hipStream_t s)
     if (p.hop == 1024) hipLaunchKernelGGL(k_fft4096_ms<4>, grid, block, 0, s, p);
     else if (p.hop == 512) hipLaunchKernelGGL(k_fft4096_ms<2>, grid, block, 0, s, p);
     else if (p.hop == 2048) hipLaunchKernelGGL(k_fft4096_ms<8>, grid, block, 0, s, p);
-    else hipLaunchKernelGGL(k_fft4096_ms<0>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(k_fft4096_ms_anyhop, grid, block, 0, s, p);
     return hipGetLastError();
 }
 
@@ -273,7 +384,7 @@ __global__ __launch_bounds__(256) void k_fft_generic(FftBatchParams p, int mode,
         }
     }
     __syncthreads();
-    float *o = p.out + (((size_t)stream * p.n_windows + w) * fft_ch + ch) * p.n_bins;
+    float *o = p.out + (((size_t)stream * p.n_windows + w) * fft_ch + ch) * p.bin_stride;
     for (uint32_t idx = threadIdx.x; idx < p.n_bins; idx += blockDim.x) {
         const uint32_t k = p.first_bin + idx;
         float xr, xi;

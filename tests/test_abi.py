@@ -50,10 +50,10 @@ def test_no_cpu_fallback_without_device():
 
 
 def test_struct_sizes_match_header():
-    # ss_batch_config: 8 x u32 + u64 + f64; ss_stream_result: 6 f64 + 2 u32; ss_batch_layout: 6 u32 + 2 u64
+    # ss_batch_config: 8 x u32 + u64 + f64; ss_stream_result: 6 f64 + 2 u32; ss_batch_layout: 8 u32 + 2 u64
     assert ctypes.sizeof(L.BatchConfig) == 48
     assert ctypes.sizeof(L.StreamResult) == 56
-    assert ctypes.sizeof(L.BatchLayout) == 40
+    assert ctypes.sizeof(L.BatchLayout) == 48
 
 
 def test_corpus_gate_host_helpers_match_oracle(oracle):
