@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -756,6 +757,17 @@ int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
         L.n_bins = (uint32_t)b->bt->count;
         L.first_bin = (uint32_t)b->bt->first;
         b->fft_fast = (C == 2 && n == 4096 && hop % 256 == 0);
+        {
+            // windows per workgroup: long runs amortise the per-workgroup constants and the 3-hop halo,
+            // but keep >= ~4096 workgroups (8 rounds of the 512 resident ones) for load balance
+            uint32_t tgt = (4096u + cfg->n_streams - 1) / cfg->n_streams;
+            if (tgt > L.n_windows / 16) tgt = L.n_windows / 16;
+            if (tgt < 1) tgt = 1;
+            uint32_t wpb = (L.n_windows + tgt - 1) / tgt;
+            wpb = (wpb + 1) & ~1u;
+            b->windows_per_block = wpb < 2 ? 2 : wpb;
+        }
+        if (const char *e = std::getenv("SS_FFT_WPB")) { int v = std::atoi(e); if (v >= 2 && v <= 4096) b->windows_per_block = (uint32_t)(v & ~1); }   // tuning knob
         L.fft_bin_stride = (L.n_bins + 3u) & ~3u;        // rows start 16-B aligned: 16-byte stores
         L.fft_bytes = (uint64_t)cfg->n_streams * L.n_windows * L.fft_channels * L.fft_bin_stride * sizeof(float);
         HIPCHK(b->fft.alloc((size_t)(L.fft_bytes / sizeof(float))));

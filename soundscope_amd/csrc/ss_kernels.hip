@@ -92,10 +92,21 @@ __device__ __forceinline__ float db_from_sq(float q, float off)
 //  which then owns bins v + 256 kc — stride-256, so output stores coalesce and
 //  the mirror bin N-k lives at thread 256-v, slot 15-kc.
 // ============================================================================
-constexpr int kX1Stride = 272;   // 256 + 16: de-phases the 4 ka-groups of a wave across banks
-constexpr int kX2Stride = 17;    // row of 16 padded to 17: conflict-free b64 row reads
+constexpr int kX1Stride = 272;   // anyhop kernel: 256 + 16 de-phases the 4 ka-groups of a wave across banks
+constexpr int kX2Stride = 17;    // anyhop kernel: row of 16 padded to 17, conflict-free b64 row reads
+// pair kernel: both exchanges store rows of 16 complex padded to 18 (144 B): the reader's row is
+// 16-B aligned and contiguous (8 x ds_read_b128), 16-lane write groups and 16-lane read groups both
+// land on 16 distinct 4-bank slots (36*i mod 64 is a permutation of the multiples of 4).
+constexpr int kRow = 18;
+constexpr int kPlane = 16 * kRow;   // 288 complex per outer index; 16 planes = 4608 complex = 36864 B
 
-// dB epilogue of one window.  xb holds the full spectrum Z[0..4095] in natural order; a thread
+// Published spectrum layout: bin k lives at k with bit 1 flipped when bit 6 is set.  A lane that owns four
+// consecutive bins reads them as two aligned 16-byte pairs; the flip spreads the 16-lane groups of
+// ds_read_b128 (and the 32-lane groups of the mirror's ds_read_b64) over distinct banks, while the
+// publishing writes (16 consecutive k per 16-lane group) stay conflict-free.
+#define SPEC_POS(k) ((k) ^ ((((k) >> 6) & 1) << 1))
+
+// dB epilogue of one window.  xb holds the full spectrum Z[0..4095] in that order; a thread
 // owns groups of FOUR consecutive retained bins (g = t, t + 256), so both output rows are written
 // with 16-byte stores (rows are padded to a multiple of 4 floats): the 4-byte-per-lane stores of
 // a stride-256 ownership were store-issue bound (1.6 ms of 4.7 ms at the config-3 size).
@@ -113,8 +124,8 @@ __device__ __forceinline__ void fft4096_epilogue(const float2 *xb, int t, uint32
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const uint32_t k = k0 + e;                       // k <= 2051 < 4096: the mirror index stays positive
-                const float2 zk = xb[k];
-                const float2 zm = xb[4096 - k];                  // Z[N - k]
+                const float2 zk = xb[SPEC_POS(k)];
+                const float2 zm = xb[SPEC_POS(4096 - k)];        // Z[N - k]
                 const float ar = zk.x + zm.x, ai = zk.y - zm.y;  // 2 * M
                 const float br = zk.y + zm.y, bi = zk.x - zm.x;  // 2 * S (up to sign / swap)
                 const float qm = fmaf(ar, ar, ai * ai);
@@ -152,7 +163,14 @@ template <int HS>
 __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams p)
 {
     constexpr int NS = 16 + HS;                                              // sample slots held
-    __shared__ __attribute__((aligned(16))) float2 xbuf[2][16 * kX1Stride];  // 2 x 34816 B
+    __shared__ __attribute__((aligned(16))) float2 xbuf[2][16 * kPlane];     // 2 x 36864 B
+    // exchange 1: element (ka; tb, ta) at ka*272 + (tb + 16 ta): lane-linear b64 writes; the reader's 4
+    // ka-groups per wave are de-phased by the +16 pad (conflict-free b64 reads)
+#define X1W(ka, tb_, ta_) ((ka) * kX1Stride + (tb_) + 16 * (ta_))
+    // exchange 2: element (kb, ka; tb) in rows of 16 padded to 18 (144 B): contiguous b64 writes, and the
+    // reader's row is 16-B aligned and contiguous (8 x ds_read_b128; 36*i mod 64 is a permutation of the
+    // multiples of 4, so every 16-lane read group hits 16 distinct 4-bank slots)
+#define X2W(kb, ka_, tb_) ((kb) * kPlane + (ka_) * kRow + (tb_))
     __shared__ __attribute__((aligned(16))) float2 tw2s[256];                //  2048 B
 
     const int t = threadIdx.x;
@@ -176,6 +194,7 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
     tw2s[t] = p.tw_256[t];
 
     const int tb = t & 15, hi = t >> 4;
+    const int tsw = SPEC_POS(t);
     const size_t out_win_stride = (size_t)2 * p.bin_stride;
     float *outp = p.out + ((size_t)stream * p.n_windows + w_begin) * out_win_stride;
 
@@ -202,57 +221,54 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
             if (q < HS ? more : more2) nx[q] = nsrc[256 * (NS + q)];
         }
 
+        // Every exchange is ordered  [reads] barrier [butterflies of window 0] [writes 0]
+        // [butterflies of window 1] [writes 1] barrier [reads]:  the write-after-read barrier sits
+        // right behind the reads, so one window's LDS writes drain while the other's butterflies issue.
         float2 z0[16], z1[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            z0[j] = make_float2(sm[j] * hw[j], df[j] * hw[j]);
-            z1[j] = make_float2(sm[j + HS] * hw[j], df[j + HS] * hw[j]);
-        }
-        // ---- pass 1
+        for (int j = 0; j < 16; j++) z0[j] = make_float2(sm[j] * hw[j], df[j] * hw[j]);
+        // ---- pass 1 (the loop-end barrier has retired the previous pair's epilogue reads)
         SS_FFT16(z0);
-        SS_FFT16(z1);
-        SS_SYNC();                       // previous pair's mirror reads are done
-        xbuf[0][t] = z0[R16(0)];
-        xbuf[1][t] = z1[R16(0)];
+        xbuf[0][X1W(0, tb, hi)] = z0[R16(0)];
 #pragma unroll
-        for (int ka = 1; ka < 16; ka++) {
-            xbuf[0][ka * kX1Stride + t] = cmul(z0[R16(ka)], tw1[ka]);
-            xbuf[1][ka * kX1Stride + t] = cmul(z1[R16(ka)], tw1[ka]);
-        }
+        for (int ka = 1; ka < 16; ka++) xbuf[0][X1W(ka, tb, hi)] = cmul(z0[R16(ka)], tw1[ka]);
+#pragma unroll
+        for (int j = 0; j < 16; j++) z1[j] = make_float2(sm[j + HS] * hw[j], df[j + HS] * hw[j]);
+        SS_FFT16(z1);
+        xbuf[1][X1W(0, tb, hi)] = z1[R16(0)];
+#pragma unroll
+        for (int ka = 1; ka < 16; ka++) xbuf[1][X1W(ka, tb, hi)] = cmul(z1[R16(ka)], tw1[ka]);
         SS_SYNC();
         // ---- pass 2 (thread = tb + 16 ka)
 #pragma unroll
         for (int ta = 0; ta < 16; ta++) {
-            z0[ta] = xbuf[0][hi * kX1Stride + tb + 16 * ta];
-            z1[ta] = xbuf[1][hi * kX1Stride + tb + 16 * ta];
+            z0[ta] = xbuf[0][X1W(hi, tb, ta)];
+            z1[ta] = xbuf[1][X1W(hi, tb, ta)];
         }
-        SS_FFT16(z0);
-        SS_FFT16(z1);
         SS_SYNC();
-        xbuf[0][hi * kX2Stride + tb] = z0[R16(0)];
-        xbuf[1][hi * kX2Stride + tb] = z1[R16(0)];
+        SS_FFT16(z0);
+        xbuf[0][X2W(0, hi, tb)] = z0[R16(0)];
 #pragma unroll
-        for (int kb = 1; kb < 16; kb++) {
-            const float2 wv = tw2s[tb * kb];
-            xbuf[0][kb * kX1Stride + hi * kX2Stride + tb] = cmul(z0[R16(kb)], wv);
-            xbuf[1][kb * kX1Stride + hi * kX2Stride + tb] = cmul(z1[R16(kb)], wv);
-        }
+        for (int kb = 1; kb < 16; kb++) xbuf[0][X2W(kb, hi, tb)] = cmul(z0[R16(kb)], tw2s[tb * kb]);
+        SS_FFT16(z1);
+        xbuf[1][X2W(0, hi, tb)] = z1[R16(0)];
+#pragma unroll
+        for (int kb = 1; kb < 16; kb++) xbuf[1][X2W(kb, hi, tb)] = cmul(z1[R16(kb)], tw2s[tb * kb]);
         SS_SYNC();
         // ---- pass 3 (thread = ka + 16 kb): ka = tb, kb = hi
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-            z0[q] = xbuf[0][hi * kX1Stride + tb * kX2Stride + q];
-            z1[q] = xbuf[1][hi * kX1Stride + tb * kX2Stride + q];
+            z0[q] = xbuf[0][X2W(hi, tb, q)];
+            z1[q] = xbuf[1][X2W(hi, tb, q)];
         }
-        SS_FFT16(z0);
-        SS_FFT16(z1);
         SS_SYNC();
-        // ---- publish the whole spectrum in natural order: Z[t + 256 kc]
+        SS_FFT16(z0);
+        // ---- publish the whole spectrum in (swizzled) natural order: Z[t + 256 kc] at SPEC_POS(k)
 #pragma unroll
-        for (int kc = 0; kc < 16; kc++) {
-            xbuf[0][kc * 256 + t] = z0[R16(kc)];
-            xbuf[1][kc * 256 + t] = z1[R16(kc)];
-        }
+        for (int kc = 0; kc < 16; kc++) xbuf[0][kc * 256 + tsw] = z0[R16(kc)];
+        SS_FFT16(z1);
+#pragma unroll
+        for (int kc = 0; kc < 16; kc++) xbuf[1][kc * 256 + tsw] = z1[R16(kc)];
         SS_SYNC();
         // ---- epilogue: groups of four consecutive bins per thread, 16-byte stores
         float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
@@ -268,8 +284,11 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
                 if (NS - 2 * HS + q >= 0) { sm[NS - 2 * HS + q] = nx[q].x + nx[q].y; df[NS - 2 * HS + q] = nx[q].x - nx[q].y; }
             }
         }
+        SS_SYNC();                             // epilogue reads are done before the next pair's pass-1 writes
     }
 }
+#undef X1W
+#undef X2W
 
 // generic hop (not a multiple of 256 or >= N/2 slots): one window per iteration, full reload
 __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms_anyhop(FftBatchParams p)
@@ -316,7 +335,7 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms_anyhop(FftBatc
         fft16(z);
         __syncthreads();
 #pragma unroll
-        for (int kc = 0; kc < 16; kc++) xbuf[kc * 256 + t] = z[R16(kc)];
+        for (int kc = 0; kc < 16; kc++) xbuf[kc * 256 + SPEC_POS(t)] = z[R16(kc)];
         __syncthreads();
         float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
         fft4096_epilogue(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.pink, o_mid, o_mid + p.bin_stride);
