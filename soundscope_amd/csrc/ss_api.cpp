@@ -678,6 +678,8 @@ struct ss_batch {
     uint32_t wave_window = 0;
     uint32_t windows_per_block = 16;
     uint32_t td_nseg = 1, td_seg_sub = 0;
+    bool wave_fused = false;     // decimation runs inside the time-domain kernel
+    uint32_t wave_halo = 0;
     FftTables *ft = nullptr;
     BinTables *bt = nullptr;
     TdTables *td = nullptr;
@@ -822,6 +824,14 @@ int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
         }
         L.n_wave_points = (uint32_t)(2 * bins);
         HIPCHK(b->wave.alloc((size_t)cfg->n_streams * (W ? 2 * W : 2)));
+        // fuse into the time-domain pass when that pass runs and a bin (plus its shared edge sample)
+        // fits the per-wave halo; otherwise the standalone kernel handles it
+        if (b->td && W > 0 && spp >= 16.0 && spp <= 1000.0) {
+            const uint32_t need = ((uint32_t)std::ceil(spp) + 2 + C - 1) / C;
+            uint32_t halo = need < 24 ? 24 : need;
+            halo = (halo + 3u) & ~3u;
+            if (halo <= 512) { b->wave_fused = true; b->wave_halo = halo; }
+        }
     }
     for (auto &e : b->ev) HIPCHK(hipEventCreate(&e));
     b->ev_ready = true;
@@ -922,6 +932,7 @@ int ss_batch_run(ss_batch *b)
         p.subblocks = b->sub.p; p.sub_cap = L.n_subblocks ? L.n_subblocks : 1;
         p.sub_stride = (uint64_t)p.sub_cap * C; p.ring = nullptr; p.ring_frames = 0; p.tp_factor = b->tp_factor;
         p.s100 = b->td->host.s100; p.nseg = b->td_nseg; p.seg_sub = b->td_seg_sub; p.warm_sub = kTdWarmSub;
+        if (b->wave_fused) { p.wave_out = b->wave.p; p.wave_stride = (uint64_t)2 * b->wave_window; p.wave_window = b->wave_window; p.halo_frames = b->wave_halo; }
         HIPCHK(ssk::launch_time_domain(p, b->stream));
     }
     HIPCHK(rec(2 * SS_KERNEL_TIME_DOMAIN + 1));
@@ -943,7 +954,7 @@ int ss_batch_run(ss_batch *b)
     HIPCHK(rec(2 * SS_KERNEL_FINALIZE + 1));
 
     HIPCHK(rec(2 * SS_KERNEL_WAVEFORM));
-    if ((c.flags & SS_BATCH_WAVEFORM) && b->wave_window) {
+    if ((c.flags & SS_BATCH_WAVEFORM) && b->wave_window && !b->wave_fused) {
         ssk::WaveParams p{};
         p.pcm = b->pcm.p; p.stream_stride = c.frames_per_stream * C; p.n_samples = c.frames_per_stream * C;
         p.n_streams = c.n_streams; p.window = b->wave_window; p.out = b->wave.p; p.out_stride = (uint64_t)2 * b->wave_window;

@@ -78,6 +78,11 @@ struct TdParams {
     uint32_t nseg;               // time segments per stream (1 for streaming calls)
     uint32_t seg_sub;            // sub-blocks per segment (nseg > 1)
     uint32_t warm_sub;           // run-in sub-blocks of segments > 0
+    // fused min-max decimation (batch only; nullptr = off): out[stream][bin] = (min, max)
+    float *wave_out;
+    uint64_t wave_stride;        // floats between streams
+    uint32_t wave_window;        // number of decimation bins W
+    uint32_t halo_frames;        // frames kept in front of each tile: >= longest bin, multiple of 4
 };
 hipError_t launch_time_domain(const TdParams &p, hipStream_t s);
 // frames per sequential chunk for a channel count (the constant block's m_pow must match)

@@ -504,7 +504,7 @@ __device__ __forceinline__ void mat4_apply_add(const double *__restrict__ M, con
         z[r] = fma(M[r * 4 + 0], x[0], fma(M[r * 4 + 1], x[1], fma(M[r * 4 + 2], x[2], fma(M[r * 4 + 3], x[3], z[r]))));
 }
 
-constexpr int kTdHaloFrames = 24;     // >= HIST-1 of the longest branch; keeps the tile 16-B aligned
+constexpr int kTdHaloFrames = 24;     // minimum halo: >= HIST-1 of the longest branch (multiple of 4: the tile stays 16-B aligned)
 constexpr int kTdTailFrames = 16;     // slack past the tile end for the last MFMA window
 constexpr int kTdWavesPerBlock = 4;
 constexpr int kTdPrefetch = 8;        // float4 per lane held in flight for the next tile
@@ -525,9 +525,9 @@ constexpr int kTdBatch = 11;          // LDS reads issued together in the sequen
     const double y_ = fma(b0, v0_, u_);
 
 // CT: compile-time channel count (0 = runtime)
-template <int FACTOR, bool RING, int CT>
+template <int FACTOR, bool RING, int CT, bool WAVE>
 __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_domain(TdParams p, uint32_t L, uint32_t tile_len,
-                                                                                      uint32_t wave_lds_floats)
+                                                                                      uint32_t wave_lds_floats, uint32_t halo_frames)
 {
     using Cfg = TpCfg<FACTOR>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
     const uint32_t nch = 64u / C;                       // chunks per tile (C <= 64)
     const uint32_t chunk = lane / C, ch = lane - chunk * C;
     const bool lane_ok = chunk < nch;
-    float *tile = tilebuf + kTdHaloFrames * C;          // tile[f*C + c]; tile[-q*C + c] = x[-q]
+    float *tile = tilebuf + halo_frames * C;            // tile[f*C + c]; tile[-q*C + c] = x[-q]
     unsigned *tpk = reinterpret_cast<unsigned *>(tilebuf + wave_lds_floats - kMaxChannels);   // per-channel peak slots
     TdState &st = p.state[stream];
     const float *src = p.pcm + (size_t)stream * p.stream_stride;
@@ -578,10 +578,29 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
         if (lane < C) e_run = st.acc[lane];
     }
     if (lane < C) {
-        for (int q = 1; q <= kTdHaloFrames; q++)
-            tile[-(int)(q * C) + (int)lane] = (carry_in && q <= kTpHistMax) ? st.tp_hist[lane][q - 1] : 0.0f;
+        for (uint32_t q = 1; q <= halo_frames; q++)
+            tile[-(int)(q * C) + (int)lane] = (carry_in && q <= (uint32_t)kTpHistMax) ? st.tp_hist[lane][q - 1] : 0.0f;
     }
     tpk[lane] = 0u;
+
+    // ---- min-max decimation cursor (Analyzer::get_waveform fused into this pass): a bin is produced by
+    // the wave whose tile holds the bin's LAST sample; its first samples may sit in the halo.
+    const uint64_t wv_len = p.n_frames * C;
+    const double wv_spp = WAVE ? (double)wv_len / (double)p.wave_window : 0.0;
+    uint32_t wv_cur = 0;
+    if (WAVE && sg != 0) {
+        const uint64_t b0 = seg_begin * C;               // first interleaved index this wave owns
+        double gq = floor((double)b0 / wv_spp) - 2.0;
+        uint32_t g = gq > 0.0 ? (uint32_t)gq : 0u;
+        for (;;) {                                        // first bin whose end lies beyond b0
+            const double ed = ceil((double)(g + 1) * wv_spp);
+            uint64_t e = (uint64_t)ed;
+            if (e > wv_len) e = wv_len;
+            if (e > b0 || g >= p.wave_window) break;
+            g++;
+        }
+        wv_cur = g;
+    }
 
     // ---- constant A fragments of the banded-Toeplitz true-peak product, and this lane's column role
     const int mrow = lane & 15, kq = lane >> 4;
@@ -674,6 +693,45 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
         SS_TILE_FRAMES(npos, noff, nseg_frames);
         SS_PREFETCH(npos, nseg_frames);
         __builtin_amdgcn_wave_barrier();               // LDS is in-order per wave: only ordering is needed
+
+        // ---- min-max decimation of the bins that END inside this tile (analyzer.rs:107-137): bin i =
+        // [floor(i*spp), min(ceil((i+1)*spp), len)), the same f64 expressions as the reference; 16 lanes
+        // per bin, IEEE minNum/maxNum seeded with NaN (f32::min/max ignore NaN; an all-NaN bin stays NaN)
+        if (WAVE && !warm) {
+            const uint64_t t0 = pos * C, t1 = (pos + seg) * C;    // interleaved index range of the tile
+            const uint32_t lane16 = lane & 15u;
+            for (;;) {
+                const uint32_t i = wv_cur + (lane >> 4);
+                const double sd = (double)i * wv_spp;
+                const double ed = ceil((double)(i + 1) * wv_spp);
+                const uint64_t bs = (uint64_t)sd;
+                uint64_t be = (uint64_t)ed;
+                if (be > wv_len) be = wv_len;
+                const bool valid = i < p.wave_window && be <= t1 && bs < wv_len;
+                float mn = __builtin_nanf(""), mx = __builtin_nanf("");
+                if (valid) {
+                    const float *bp = tile + (ptrdiff_t)((int64_t)bs - (int64_t)t0);   // may reach into the halo
+                    const uint32_t n = (uint32_t)(be - bs);
+                    for (uint32_t j = lane16; j < n; j += 16u) {
+                        const float v = bp[j];
+                        mn = fminf(mn, v);
+                        mx = fmaxf(mx, v);
+                    }
+                }
+#pragma unroll
+                for (int ofs = 8; ofs >= 1; ofs >>= 1) {
+                    mn = fminf(mn, __shfl_xor(mn, ofs, 16));
+                    mx = fmaxf(mx, __shfl_xor(mx, ofs, 16));
+                }
+                if (valid && lane16 == 0) {
+                    float2 *o = reinterpret_cast<float2 *>(p.wave_out + (size_t)stream * p.wave_stride) + i;
+                    *o = make_float2(mn, mx);
+                }
+                const uint32_t nvalid = (uint32_t)__popcll(__ballot(valid && lane16 == 0));
+                wv_cur += nvalid;
+                if (nvalid < 4u) break;                   // the next bin ends beyond this tile
+            }
+        }
 
         // ---- true peak on the matrix pipe (not during the run-in)
         if (FACTOR != 0 && !warm) {
@@ -823,11 +881,11 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
             e_run = 0.0;
             sb++;
         }
-        // ---- new halo: the kTdHaloFrames frames before the tile end (a contiguous copy; when the tile
+        // ---- new halo: the halo_frames frames before the tile end (a contiguous copy; when the tile
         // is shorter than the halo the source reaches into the old halo).  Ascending order is safe:
         // the source of element j sits seg*C floats above its destination, beyond anything written so far.
         {
-            const uint32_t hn = kTdHaloFrames * C;
+            const uint32_t hn = halo_frames * C;
             float *dst = tile - hn;
             const float *srcp = dst + (size_t)seg * C;
             for (uint32_t j = lane; j < hn; j += 64u) {
@@ -892,7 +950,7 @@ uint32_t td_chunk_frames(uint32_t C, uint32_t s100)
     return best;
 }
 
-template <int FACTOR, bool RING, int CT>
+template <int FACTOR, bool RING, int CT, bool WAVE>
 static hipError_t td_launch(const TdParams &p, hipStream_t s)
 {
     const uint32_t C = p.channels;
@@ -904,10 +962,11 @@ static hipError_t td_launch(const TdParams &p, hipStream_t s)
     uint32_t tile_len = (S + pieces - 1) / pieces;
     if (tile_len > cap) tile_len = cap;
     // per-wave LDS: halo + tile + slack + 64 peak slots
-    uint32_t wave_floats = (kTdHaloFrames + tile_len + kTdTailFrames) * C + kMaxChannels;
+    const uint32_t halo = WAVE ? p.halo_frames : (uint32_t)kTdHaloFrames;
+    uint32_t wave_floats = (halo + tile_len + kTdTailFrames) * C + kMaxChannels;
     wave_floats = (wave_floats + 3u) & ~3u;
     const size_t lds = (size_t)wave_floats * 4 * kTdWavesPerBlock;
-    auto fn = k_time_domain<FACTOR, RING, CT>;
+    auto fn = k_time_domain<FACTOR, RING, CT, WAVE>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
@@ -917,14 +976,17 @@ static hipError_t td_launch(const TdParams &p, hipStream_t s)
     }
     const uint32_t waves = p.n_streams * p.nseg;
     const uint32_t blocks = (waves + kTdWavesPerBlock - 1) / kTdWavesPerBlock;
-    hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * kTdWavesPerBlock), lds, s, p, L, tile_len, wave_floats);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * kTdWavesPerBlock), lds, s, p, L, tile_len, wave_floats, halo);
     return hipGetLastError();
 }
 
 template <int FACTOR, bool RING>
 static hipError_t td_launch_c(const TdParams &p, hipStream_t s)
 {
-    return p.channels == 2 ? td_launch<FACTOR, RING, 2>(p, s) : td_launch<FACTOR, RING, 0>(p, s);
+    if (!RING && p.wave_out)      // fused decimation is a batch feature (never together with the ring)
+        return p.channels == 2 ? td_launch<FACTOR, false, 2, true>(p, s) : td_launch<FACTOR, false, 0, true>(p, s);
+    return p.channels == 2 ? td_launch<FACTOR, RING, 2, false>(p, s) : td_launch<FACTOR, RING, 0, false>(p, s);
 }
 
 hipError_t launch_time_domain(const TdParams &p, hipStream_t s)
