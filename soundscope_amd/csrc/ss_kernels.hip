@@ -523,6 +523,33 @@ constexpr int kTdBatch = 11;          // LDS reads issued together in the sequen
     u_ = fma(b3, v3, u_);                        \
     u_ = fma(b4, v4, u_);                        \
     const double y_ = fma(b0, v0_, u_);
+// Look-ahead form of the same recurrence for full chunks: the terms that do not involve the newest
+// state are folded into partial sums one, two and three samples ahead, so every step issues four
+// independent FMAs and the loop-carried dependency is a single FMA (v_i = r1 - a1 v_{i-1}).
+//   r1 = x_i     - a2 v_{i-2} - a3 v_{i-3} - a4 v_{i-4}
+//   r2 = x_{i+1} - a3 v_{i-2} - a4 v_{i-3}
+//   r3 = x_{i+2} - a4 v_{i-2}
+#define SS_KW_LA_INIT(x0, x1, x2)                                   \
+    double r1 = fma(-a4, v4, fma(-a3, v3, fma(-a2, v2, (x0))));      \
+    double r2 = fma(-a4, v3, fma(-a3, v2, (x1)));                    \
+    double r3 = fma(-a4, v2, (x2));
+#define SS_KW_LA_STEP(xn)                        \
+    const double v0_ = fma(-a1, v1, r1);         \
+    r1 = fma(-a2, v1, r2);                       \
+    r2 = fma(-a3, v1, r3);                       \
+    r3 = fma(-a4, v1, (xn));
+// output taps as partial sums too: y_i = b0 v_i + u1, every update depends on v_i only
+#define SS_KW_LA_OUT_INIT()                                          \
+    double u1 = fma(b4, v4, fma(b3, v3, fma(b2, v2, b1 * v1)));      \
+    double u2 = fma(b4, v3, fma(b3, v2, b2 * v1));                   \
+    double u3 = fma(b4, v2, b3 * v1);                                \
+    double u4 = b4 * v1;
+#define SS_KW_LA_OUT()                           \
+    const double y_ = fma(b0, v0_, u1);          \
+    u1 = fma(b1, v0_, u2);                       \
+    u2 = fma(b2, v0_, u3);                       \
+    u3 = fma(b3, v0_, u4);                       \
+    u4 = b4 * v0_;
 
 // CT: compile-time channel count (0 = runtime)
 template <int FACTOR, bool RING, int CT, bool WAVE>
@@ -802,16 +829,18 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
         {
             double v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0;
             uint32_t i = 0;
-            if (len == L) {                             // full chunk: batched, predicate-free
-                const float *xp = xs;
+            if (len == L) {                             // full chunk: batched, predicate-free, look-ahead form
+                const float *xp = xs + 3 * C;           // the batch loop consumes x[i + 3]
+                SS_KW_LA_INIT((double)xs[0], (double)xs[C], (double)xs[2 * C])
                 for (uint32_t bq = 0; bq < nb_full; bq++, xp += kTdBatch * C) {
                     float xb[kTdBatch];
 #pragma unroll
-                    for (int u = 0; u < kTdBatch; u++) xb[u] = xp[u * (int)C];
+                    for (int u = 0; u < kTdBatch; u++) xb[u] = xp[u * (int)C];   // reaches <= 3 frames past the chunk (slack)
 #pragma unroll
-                    for (int u = 0; u < kTdBatch; u++) { SS_KW_STATE((double)xb[u]) SS_KW_SHIFT() }
+                    for (int u = 0; u < kTdBatch; u++) { SS_KW_LA_STEP((double)xb[u]) SS_KW_SHIFT() }
                 }
                 i = nb_full * kTdBatch;
+                for (; i < len; i++) { SS_KW_LA_STEP((double)xs[(i + 3) * C]) SS_KW_SHIFT() }
             }
             for (; i < len; i++) { SS_KW_STATE((double)xs[i * C]) SS_KW_SHIFT() }
             z[0] = v1; z[1] = v2; z[2] = v3; z[3] = v4;
@@ -838,7 +867,13 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
             uint32_t i = 0;
             const uint64_t ring_base = fed0 + pos + (uint64_t)chunk * L;
             if (len == L) {
-                const float *xp = xs;
+                // sample peak over x[0 .. L+2]: the three look-ahead samples are the next chunk's (or the
+                // zeroed slack behind the tile), so including them cannot change the channel's maximum
+                const float *xp = xs + 3 * C;
+                const float xa = xs[0], xb1 = xs[C], xc = xs[2 * C];
+                sp = fmaxf(fmaxf(fabsf(xa), fabsf(xb1)), fabsf(xc));
+                SS_KW_LA_INIT((double)xa, (double)xb1, (double)xc)
+                SS_KW_LA_OUT_INIT()
                 for (uint32_t bq = 0; bq < nb_full; bq++, xp += kTdBatch * C) {
                     float xb[kTdBatch];
 #pragma unroll
@@ -846,12 +881,19 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
 #pragma unroll
                     for (int u = 0; u < kTdBatch; u++) {
                         sp = fmaxf(sp, fabsf(xb[u]));
-                        SS_KW_STATE((double)xb[u]) SS_KW_OUT() SS_KW_SHIFT()
+                        SS_KW_LA_STEP((double)xb[u]) SS_KW_LA_OUT() SS_KW_SHIFT()
                         e = fma(y_, y_, e);
                         if (RING) p.ring[((ring_base + bq * kTdBatch + u) % p.ring_frames) * C + ch] = y_;
                     }
                 }
                 i = nb_full * kTdBatch;
+                for (; i < len; i++) {
+                    const float xn = xs[(i + 3) * C];
+                    sp = fmaxf(sp, fabsf(xn));
+                    SS_KW_LA_STEP((double)xn) SS_KW_LA_OUT() SS_KW_SHIFT()
+                    e = fma(y_, y_, e);
+                    if (RING) p.ring[((ring_base + i) % p.ring_frames) * C + ch] = y_;
+                }
             }
             for (; i < len; i++) {
                 const float xf = xs[i * C];

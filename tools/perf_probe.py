@@ -11,7 +11,11 @@ from soundscope_amd import _lib as L
 
 streams = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-b = ssa.Batch(48000, 2, streams, 480000, 4096, 1024)
+flags = L.SS_BATCH_ALL
+for a in sys.argv:
+    if a.startswith('--flags='):
+        flags = int(a.split('=')[1])
+b = ssa.Batch(48000, 2, streams, 480000, 4096, 1024, flags=flags)
 b.synthesize(0x5EED0000, 0)
 for _ in range(2):
     b.run(); b.sync()
