@@ -725,31 +725,43 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
         // [floor(i*spp), min(ceil((i+1)*spp), len)), the same f64 expressions as the reference; 16 lanes
         // per bin, IEEE minNum/maxNum seeded with NaN (f32::min/max ignore NaN; an all-NaN bin stays NaN)
         if (WAVE && !warm) {
-            const uint64_t t0 = pos * C, t1 = (pos + seg) * C;    // interleaved index range of the tile
+            // (the host only fuses when the stream length fits 31 bits, so 32-bit indices are exact)
+            const uint32_t t0 = (uint32_t)(pos * C), t1 = (uint32_t)((pos + seg) * C);   // tile's interleaved index range
+            const uint32_t wlen = (uint32_t)wv_len;
             const uint32_t lane16 = lane & 15u;
             for (;;) {
                 const uint32_t i = wv_cur + (lane >> 4);
-                const double sd = (double)i * wv_spp;
-                const double ed = ceil((double)(i + 1) * wv_spp);
-                const uint64_t bs = (uint64_t)sd;
-                uint64_t be = (uint64_t)ed;
-                if (be > wv_len) be = wv_len;
-                const bool valid = i < p.wave_window && be <= t1 && bs < wv_len;
+                const uint32_t bs = (uint32_t)((double)i * wv_spp);
+                uint32_t be = (uint32_t)ceil((double)(i + 1) * wv_spp);
+                if (be > wlen) be = wlen;
+                const bool valid = i < p.wave_window && be <= t1 && bs < wlen;
                 float mn = __builtin_nanf(""), mx = __builtin_nanf("");
                 if (valid) {
-                    const float *bp = tile + (ptrdiff_t)((int64_t)bs - (int64_t)t0);   // may reach into the halo
-                    const uint32_t n = (uint32_t)(be - bs);
-                    for (uint32_t j = lane16; j < n; j += 16u) {
+                    const float *bp = tile + ((int)bs - (int)t0);      // may reach into the halo
+                    const uint32_t n = be - bs;                       // >= 1
+                    // seven clamped reads cover n <= 112 without predicates (a repeated element cannot
+                    // change a min/max); longer bins finish in the loop
+#pragma unroll
+                    for (int it = 0; it < 7; it++) {
+                        uint32_t j = lane16 + 16u * it;
+                        j = j < n ? j : n - 1;
+                        const float v = bp[j];
+                        mn = fminf(mn, v);
+                        mx = fmaxf(mx, v);
+                    }
+                    for (uint32_t j = lane16 + 112u; j < n; j += 16u) {
                         const float v = bp[j];
                         mn = fminf(mn, v);
                         mx = fmaxf(mx, v);
                     }
                 }
-#pragma unroll
-                for (int ofs = 8; ofs >= 1; ofs >>= 1) {
-                    mn = fminf(mn, __shfl_xor(mn, ofs, 16));
-                    mx = fmaxf(mx, __shfl_xor(mx, ofs, 16));
-                }
+                // 16-lane all-reduce with DPP row rotations (VALU rate; ds_bpermute costs ~8x more)
+#define SS_ROW_ROR(x, n_) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x120 | (n_), 0xF, 0xF, false))
+                mn = fminf(mn, SS_ROW_ROR(mn, 8)); mx = fmaxf(mx, SS_ROW_ROR(mx, 8));
+                mn = fminf(mn, SS_ROW_ROR(mn, 4)); mx = fmaxf(mx, SS_ROW_ROR(mx, 4));
+                mn = fminf(mn, SS_ROW_ROR(mn, 2)); mx = fmaxf(mx, SS_ROW_ROR(mx, 2));
+                mn = fminf(mn, SS_ROW_ROR(mn, 1)); mx = fmaxf(mx, SS_ROW_ROR(mx, 1));
+#undef SS_ROW_ROR
                 if (valid && lane16 == 0) {
                     float2 *o = reinterpret_cast<float2 *>(p.wave_out + (size_t)stream * p.wave_stride) + i;
                     *o = make_float2(mn, mx);
