@@ -27,37 +27,87 @@ __device__ __forceinline__ float2 cmul_cs(float2 a, float c, float s) { return m
 // a * (-i)
 __device__ __forceinline__ float2 cmul_mi(float2 a) { return make_float2(a.y, -a.x); }
 
-// forward radix-4 butterfly on (a0,a1,a2,a3) in place: A_k = sum_j a_j (-i)^(jk)
-__device__ __forceinline__ void radix4(float2 &a0, float2 &a1, float2 &a2, float2 &a3)
+// ---- packed-f32 complex arithmetic -------------------------------------------------------------
+// A complex number lives in an even-aligned VGPR pair (re, im) and is processed with VOP3P packed
+// f32 instructions, two flops per lane per instruction.  Measured on gfx950 (tools/ubench3.hip):
+// v_pk_add_f32 issues in 5.7 cycles per wave-instruction at 2 waves/SIMD against 3.9 for v_add_f32,
+// i.e. 27 % fewer issue cycles per complex add.  The swizzles a radix-4 butterfly needs (multiply by
+// -i / +i, complex multiply) are expressed with op_sel / neg modifiers, which the compiler's SLP
+// packer does not find (it pays ~30 % v_mov to pair registers instead — hence -fno-slp-vectorize).
+typedef float v2f __attribute__((ext_vector_type(2)));
+// a - i b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ v2f pk_sub_ib(v2f a, v2f b)
 {
-    float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = csub(a1, a3);
-    a0 = cadd(t0, t2);
-    a2 = csub(t0, t2);
-    a1 = make_float2(t1.x + t3.y, t1.y - t3.x);   // t1 - i t3
-    a3 = make_float2(t1.x - t3.y, t1.y + t3.x);   // t1 + i t3
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + i b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ v2f pk_add_ib(v2f a, v2f b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a * w (complex): m = (a.y w.y, a.y w.x); r = (a.x w.x - m.x, a.x w.y + m.y)
+__device__ __forceinline__ v2f pk_cmul(v2f a, v2f w)
+{
+    v2f m, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(m) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,0]"
+        : "=v"(r) : "v"(a), "v"(w), "v"(m));
+    return r;
+}
+// (a.x + a.y, a.y - a.x) = a - i a      [times R gives a * W16^2]
+__device__ __forceinline__ v2f pk_w2pre(v2f a) { return pk_sub_ib(a, a); }
+// (a.y - a.x, -(a.x + a.y))             [times R gives a * W16^6]
+__device__ __forceinline__ v2f pk_w6pre(v2f a)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(r) : "v"(a));
+    return r;
+}
+// a * (-i) = (a.y, -a.x)
+__device__ __forceinline__ v2f pk_mul_mi(v2f a)
+{
+    v2f r;
+    const v2f zero = {0.0f, 0.0f};
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(zero), "v"(a));
+    return r;
 }
 
-// Forward 16-point DFT in registers.  Input a[j] natural order; output
+// forward radix-4 butterfly on (a0,a1,a2,a3) in place: A_k = sum_j a_j (-i)^(jk)  — 8 packed adds
+__device__ __forceinline__ void radix4(v2f &a0, v2f &a1, v2f &a2, v2f &a3)
+{
+    const v2f t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = a1 - a3;
+    a0 = t0 + t2;
+    a2 = t0 - t2;
+    a1 = pk_sub_ib(t1, t3);   // t1 - i t3
+    a3 = pk_add_ib(t1, t3);   // t1 + i t3
+}
+
+// Forward 16-point DFT in registers (81 packed instructions).  Input a[j] natural order; output
 // X[k] is left in a[R16(k)] with R16(k) = ((k & 3) << 2) | (k >> 2).
 #define R16(k) ((((k) & 3) << 2) | ((k) >> 2))
-__device__ __forceinline__ void fft16(float2 (&a)[16])
+__device__ __forceinline__ void fft16(v2f (&a)[16])
 {
     constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R = 0.70710678118654752f;
+    const v2f w1 = {C1, -S1}, w3 = {S1, -C1}, w9 = {-C1, S1};
     // stage 1: 4-point DFTs over q of a[r + 4q]; result p lands in a[r + 4p]
     radix4(a[0], a[4], a[8], a[12]);
     radix4(a[1], a[5], a[9], a[13]);
     radix4(a[2], a[6], a[10], a[14]);
     radix4(a[3], a[7], a[11], a[15]);
     // twiddle a[r + 4p] *= W16^(r p)
-    a[5] = cmul_cs(a[5], C1, S1);                                      // r=1,p=1: W^1
-    a[9] = make_float2((a[9].x + a[9].y) * R, (a[9].y - a[9].x) * R);  // r=1,p=2: W^2
-    a[13] = cmul_cs(a[13], S1, C1);                                    // r=1,p=3: W^3
-    a[6] = make_float2((a[6].x + a[6].y) * R, (a[6].y - a[6].x) * R);  // r=2,p=1: W^2
-    a[10] = cmul_mi(a[10]);                                            // r=2,p=2: W^4
-    a[14] = make_float2((a[14].y - a[14].x) * R, -(a[14].x + a[14].y) * R); // r=2,p=3: W^6 = (-R,-R)
-    a[7] = cmul_cs(a[7], S1, C1);                                      // r=3,p=1: W^3
-    a[11] = make_float2((a[11].y - a[11].x) * R, -(a[11].x + a[11].y) * R); // r=3,p=2: W^6
-    a[15] = cmul_cs(a[15], -C1, -S1);                                  // r=3,p=3: W^9 = (-C1, +S1)
+    a[5] = pk_cmul(a[5], w1);            // r=1,p=1: W^1
+    a[9] = pk_w2pre(a[9]) * R;           // r=1,p=2: W^2
+    a[13] = pk_cmul(a[13], w3);          // r=1,p=3: W^3
+    a[6] = pk_w2pre(a[6]) * R;           // r=2,p=1: W^2
+    a[10] = pk_mul_mi(a[10]);            // r=2,p=2: W^4 = -i
+    a[14] = pk_w6pre(a[14]) * R;         // r=2,p=3: W^6 = (-R,-R)
+    a[7] = pk_cmul(a[7], w3);            // r=3,p=1: W^3
+    a[11] = pk_w6pre(a[11]) * R;         // r=3,p=2: W^6
+    a[15] = pk_cmul(a[15], w9);          // r=3,p=3: W^9 = (-C1, +S1)
     // stage 2: 4-point DFTs over r of a[r + 4p]; result s lands in a[s + 4p] = X[p + 4s]
     radix4(a[0], a[1], a[2], a[3]);
     radix4(a[4], a[5], a[6], a[7]);
@@ -110,7 +160,7 @@ constexpr int kPlane = 16 * kRow;   // 288 complex per outer index; 16 planes = 
 // owns groups of FOUR consecutive retained bins (g = t, t + 256), so both output rows are written
 // with 16-byte stores (rows are padded to a multiple of 4 floats): the 4-byte-per-lane stores of
 // a stride-256 ownership were store-issue bound (1.6 ms of 4.7 ms at the config-3 size).
-__device__ __forceinline__ void fft4096_epilogue(const float2 *xb, int t, uint32_t first_bin, uint32_t n_bins,
+__device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t first_bin, uint32_t n_bins,
                                                  float db_offset, const float *__restrict__ pink,
                                                  float *o_mid, float *o_side)
 {
@@ -124,12 +174,13 @@ __device__ __forceinline__ void fft4096_epilogue(const float2 *xb, int t, uint32
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const uint32_t k = k0 + e;                       // k <= 2051 < 4096: the mirror index stays positive
-                const float2 zk = xb[SPEC_POS(k)];
-                const float2 zm = xb[SPEC_POS(4096 - k)];        // Z[N - k]
-                const float ar = zk.x + zm.x, ai = zk.y - zm.y;  // 2 * M
-                const float br = zk.y + zm.y, bi = zk.x - zm.x;  // 2 * S (up to sign / swap)
-                const float qm = fmaf(ar, ar, ai * ai);
-                const float qs = fmaf(br, br, bi * bi);
+                const v2f zk = xb[SPEC_POS(k)];
+                const v2f zm = xb[SPEC_POS(4096 - k)];           // Z[N - k]
+                v2f m2, s2;                                      // 2*M = (zk.x+zm.x, zk.y-zm.y); 2*S ~ (zk.y+zm.y, zk.x-zm.x)
+                asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,0] neg_hi:[0,1]" : "=v"(m2) : "v"(zk), "v"(zm));
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(s2) : "v"(zk), "v"(zm));
+                const float qm = fmaf(m2.x, m2.x, m2.y * m2.y);
+                const float qs = fmaf(s2.x, s2.x, s2.y * s2.y);
                 const float pk = pink ? pink[4 * g + e] : 0.0f;  // table padded to the row stride
                 rm[e] = db_from_sq(qm, db_offset) + pk;
                 rs[e] = db_from_sq(qs, db_offset) + pk;
@@ -150,7 +201,7 @@ __device__ __forceinline__ void fft4096_epilogue(const float2 *xb, int t, uint32
 // phase carries two independent radix-16 problems (half the barriers per window, twice the
 // instruction-level parallelism to cover LDS latency).
 #if defined(SS_ABL) && SS_ABL == 4      /* ablation: no butterflies */
-#define SS_FFT16(z) asm volatile("" : "+v"(z[0].x), "+v"(z[5].y), "+v"(z[10].x), "+v"(z[15].y))
+#define SS_FFT16(z) asm volatile("" : "+v"(z[0]), "+v"(z[5]), "+v"(z[10]), "+v"(z[15]))
 #else
 #define SS_FFT16(z) fft16(z)
 #endif
@@ -163,7 +214,7 @@ template <int HS>
 __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams p)
 {
     constexpr int NS = 16 + HS;                                              // sample slots held
-    __shared__ __attribute__((aligned(16))) float2 xbuf[2][16 * kPlane];     // 2 x 36864 B
+    __shared__ __attribute__((aligned(16))) v2f xbuf[2][16 * kPlane];     // 2 x 36864 B
     // exchange 1: element (ka; tb, ta) at ka*272 + (tb + 16 ta): lane-linear b64 writes; the reader's 4
     // ka-groups per wave are de-phased by the +16 pad (conflict-free b64 reads)
 #define X1W(ka, tb_, ta_) ((ka) * kX1Stride + (tb_) + 16 * (ta_))
@@ -171,7 +222,7 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
     // reader's row is 16-B aligned and contiguous (8 x ds_read_b128; 36*i mod 64 is a permutation of the
     // multiples of 4, so every 16-lane read group hits 16 distinct 4-bank slots)
 #define X2W(kb, ka_, tb_) ((kb) * kPlane + (ka_) * kRow + (tb_))
-    __shared__ __attribute__((aligned(16))) float2 tw2s[256];                //  2048 B
+    __shared__ __attribute__((aligned(16))) v2f tw2s[256];                //  2048 B
 
     const int t = threadIdx.x;
     const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
@@ -188,10 +239,10 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
     float hw[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) hw[j] = p.half_window[t + 256 * j];
-    float2 tw1[16];
+    v2f tw1[16];
 #pragma unroll
-    for (int ka = 1; ka < 16; ka++) tw1[ka] = p.tw_n[t * ka];
-    tw2s[t] = p.tw_256[t];
+    for (int ka = 1; ka < 16; ka++) tw1[ka] = reinterpret_cast<const v2f *>(p.tw_n)[t * ka];
+    tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[t];
 
     const int tb = t & 15, hi = t >> 4;
     const int tsw = SPEC_POS(t);
@@ -224,20 +275,20 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
         // Every exchange is ordered  [reads] barrier [butterflies of window 0] [writes 0]
         // [butterflies of window 1] [writes 1] barrier [reads]:  the write-after-read barrier sits
         // right behind the reads, so one window's LDS writes drain while the other's butterflies issue.
-        float2 z0[16], z1[16];
+        v2f z0[16], z1[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) z0[j] = make_float2(sm[j] * hw[j], df[j] * hw[j]);
+        for (int j = 0; j < 16; j++) z0[j] = v2f{sm[j] * hw[j], df[j] * hw[j]};
         // ---- pass 1 (the loop-end barrier has retired the previous pair's epilogue reads)
         SS_FFT16(z0);
         xbuf[0][X1W(0, tb, hi)] = z0[R16(0)];
 #pragma unroll
-        for (int ka = 1; ka < 16; ka++) xbuf[0][X1W(ka, tb, hi)] = cmul(z0[R16(ka)], tw1[ka]);
+        for (int ka = 1; ka < 16; ka++) xbuf[0][X1W(ka, tb, hi)] = pk_cmul(z0[R16(ka)], tw1[ka]);
 #pragma unroll
-        for (int j = 0; j < 16; j++) z1[j] = make_float2(sm[j + HS] * hw[j], df[j + HS] * hw[j]);
+        for (int j = 0; j < 16; j++) z1[j] = v2f{sm[j + HS] * hw[j], df[j + HS] * hw[j]};
         SS_FFT16(z1);
         xbuf[1][X1W(0, tb, hi)] = z1[R16(0)];
 #pragma unroll
-        for (int ka = 1; ka < 16; ka++) xbuf[1][X1W(ka, tb, hi)] = cmul(z1[R16(ka)], tw1[ka]);
+        for (int ka = 1; ka < 16; ka++) xbuf[1][X1W(ka, tb, hi)] = pk_cmul(z1[R16(ka)], tw1[ka]);
         SS_SYNC();
         // ---- pass 2 (thread = tb + 16 ka)
 #pragma unroll
@@ -249,11 +300,11 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
         SS_FFT16(z0);
         xbuf[0][X2W(0, hi, tb)] = z0[R16(0)];
 #pragma unroll
-        for (int kb = 1; kb < 16; kb++) xbuf[0][X2W(kb, hi, tb)] = cmul(z0[R16(kb)], tw2s[tb * kb]);
+        for (int kb = 1; kb < 16; kb++) xbuf[0][X2W(kb, hi, tb)] = pk_cmul(z0[R16(kb)], tw2s[tb * kb]);
         SS_FFT16(z1);
         xbuf[1][X2W(0, hi, tb)] = z1[R16(0)];
 #pragma unroll
-        for (int kb = 1; kb < 16; kb++) xbuf[1][X2W(kb, hi, tb)] = cmul(z1[R16(kb)], tw2s[tb * kb]);
+        for (int kb = 1; kb < 16; kb++) xbuf[1][X2W(kb, hi, tb)] = pk_cmul(z1[R16(kb)], tw2s[tb * kb]);
         SS_SYNC();
         // ---- pass 3 (thread = ka + 16 kb): ka = tb, kb = hi
 #pragma unroll
@@ -293,8 +344,8 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
 // generic hop (not a multiple of 256 or >= N/2 slots): one window per iteration, full reload
 __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms_anyhop(FftBatchParams p)
 {
-    __shared__ __attribute__((aligned(16))) float2 xbuf[16 * kX1Stride];
-    __shared__ __attribute__((aligned(16))) float2 tw2s[256];
+    __shared__ __attribute__((aligned(16))) v2f xbuf[16 * kX1Stride];
+    __shared__ __attribute__((aligned(16))) v2f tw2s[256];
     const int t = threadIdx.x;
     const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
     const uint32_t stream = blockIdx.x / groups;
@@ -304,23 +355,23 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms_anyhop(FftBatc
     if (w_end > p.n_windows) w_end = p.n_windows;
     const float2 *src = reinterpret_cast<const float2 *>(p.pcm) + (size_t)stream * p.frames_per_stream +
                         p.first_start + (size_t)w_begin * p.hop;
-    tw2s[t] = p.tw_256[t];
+    tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[t];
     const int tb = t & 15, hi = t >> 4;
     const size_t out_win_stride = (size_t)2 * p.bin_stride;
     float *outp = p.out + ((size_t)stream * p.n_windows + w_begin) * out_win_stride;
     for (uint32_t w = w_begin; w < w_end; ++w) {
-        float2 z[16];
+        v2f z[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const float2 v = src[(size_t)(w - w_begin) * p.hop + t + 256 * j];
             const float hwj = p.half_window[t + 256 * j];
-            z[j] = make_float2((v.x + v.y) * hwj, (v.x - v.y) * hwj);
+            z[j] = v2f{(v.x + v.y) * hwj, (v.x - v.y) * hwj};
         }
         fft16(z);
         __syncthreads();
         xbuf[t] = z[R16(0)];
 #pragma unroll
-        for (int ka = 1; ka < 16; ka++) xbuf[ka * kX1Stride + t] = cmul(z[R16(ka)], p.tw_n[t * ka]);
+        for (int ka = 1; ka < 16; ka++) xbuf[ka * kX1Stride + t] = pk_cmul(z[R16(ka)], reinterpret_cast<const v2f *>(p.tw_n)[t * ka]);
         __syncthreads();
 #pragma unroll
         for (int ta = 0; ta < 16; ta++) z[ta] = xbuf[hi * kX1Stride + tb + 16 * ta];
@@ -328,7 +379,7 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms_anyhop(FftBatc
         __syncthreads();
         xbuf[hi * kX2Stride + tb] = z[R16(0)];
 #pragma unroll
-        for (int kb = 1; kb < 16; kb++) xbuf[kb * kX1Stride + hi * kX2Stride + tb] = cmul(z[R16(kb)], tw2s[tb * kb]);
+        for (int kb = 1; kb < 16; kb++) xbuf[kb * kX1Stride + hi * kX2Stride + tb] = pk_cmul(z[R16(kb)], tw2s[tb * kb]);
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 16; q++) z[q] = xbuf[hi * kX1Stride + tb * kX2Stride + q];
