@@ -1092,7 +1092,7 @@ int ss_batch_timing_read(ss_batch *b, int kernel, double *total_ms, uint64_t *la
 const char *ss_kernel_name(int kernel)
 {
     switch (kernel) {
-        case SS_KERNEL_FFT: return "k_fft4096_ms";
+        case SS_KERNEL_FFT: return "k_fft4096_ms1";
         case SS_KERNEL_TIME_DOMAIN: return "k_time_domain";
         case SS_KERNEL_FINALIZE: return "k_finalize";
         case SS_KERNEL_WAVEFORM: return "k_waveform";
