@@ -70,6 +70,7 @@ struct FftTables {
     std::vector<float> window_host;
     DevBuf<float> window, half_window;
     DevBuf<float2> tw_n, tw_256;
+    const float2 *core_tw4096 = nullptr, *core_tw256 = nullptr;   // n == 16384: tables of the 4096-point core
 };
 
 struct BinTables {
@@ -149,6 +150,31 @@ int get_fft_tables(size_t n, FftTables **out)
         std::vector<float2> t256(256);
         for (size_t i = 0; i < 256; i++) t256[i] = make_float2(tw[2 * i], tw[2 * i + 1]);
         HIPCHK(t->tw_256.upload(t256));
+    }
+    if (n == 16384) {
+        // (the mutex is not recursive: build the core tables inline)
+        auto it4 = c.fft.find(4096);
+        if (it4 == c.fft.end()) {
+            auto t4 = std::make_unique<FftTables>();
+            t4->n = 4096;
+            t4->window_host = sst::hann_window(4096);
+            std::vector<float> half4(4096);
+            for (size_t i = 0; i < 4096; i++) half4[i] = 0.5f * t4->window_host[i];
+            HIPCHK(t4->window.upload(t4->window_host));
+            HIPCHK(t4->half_window.upload(half4));
+            std::vector<float> tw4;
+            sst::twiddles(4096, 4096, tw4);
+            std::vector<float2> v4(4096);
+            for (size_t i = 0; i < 4096; i++) v4[i] = make_float2(tw4[2 * i], tw4[2 * i + 1]);
+            HIPCHK(t4->tw_n.upload(v4));
+            sst::twiddles(256, 256, tw4);
+            std::vector<float2> v256(256);
+            for (size_t i = 0; i < 256; i++) v256[i] = make_float2(tw4[2 * i], tw4[2 * i + 1]);
+            HIPCHK(t4->tw_256.upload(v256));
+            it4 = c.fft.emplace(4096, std::move(t4)).first;
+        }
+        t->core_tw4096 = it4->second->tw_n.p;
+        t->core_tw256 = it4->second->tw_256.p;
     }
     *out = t.get();
     c.fft[n] = std::move(t);
@@ -431,7 +457,12 @@ int ss_get_fft(const ss_analyzer *hc, const float *samples, size_t n,
     p.n_windows = 1; p.hop = 0; p.n = (uint32_t)n;
     p.first_bin = (uint32_t)bt->first; p.n_bins = (uint32_t)bt->count; p.bin_stride = p.n_bins; p.windows_per_block = 1;
     p.db_offset = (float)(20.0 * std::log10(4.0 / (double)n));
-    HIPCHK(ssk::launch_fft_generic(p, 0, h->stream));
+    if (n == 16384) {
+        p.tw_core = ft->core_tw4096; p.tw_256 = ft->core_tw256;
+        HIPCHK(ssk::launch_fft16k(p, 0, h->stream));
+    } else {
+        HIPCHK(ssk::launch_fft_generic(p, 0, h->stream));
+    }
     std::vector<float> db(bt->count);
     HIPCHK(hipMemcpyAsync(db.data(), h->fft_out.p, bt->count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -913,7 +944,12 @@ int ss_batch_run(ss_batch *b)
             HIPCHK(ssk::launch_fft4096_ms(p, b->stream));
         } else {
             p.db_offset = (float)(20.0 * std::log10(4.0 / (double)c.fft_n));
-            HIPCHK(ssk::launch_fft_generic(p, b->fft_mode, b->stream));
+            if (c.fft_n == 16384) {
+                p.tw_core = b->ft->core_tw4096; p.tw_256 = b->ft->core_tw256;
+                HIPCHK(ssk::launch_fft16k(p, b->fft_mode, b->stream));
+            } else {
+                HIPCHK(ssk::launch_fft_generic(p, b->fft_mode, b->stream));
+            }
         }
     }
     HIPCHK(rec(2 * SS_KERNEL_FFT + 1));

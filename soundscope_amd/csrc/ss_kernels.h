@@ -19,7 +19,8 @@ struct FftBatchParams {
     const float *window;         // N (generic kernel) — full Hann
     const float *half_window;    // N (4096 kernel)   — 0.5 * Hann
     const float2 *tw_n;          // W_N^k, k < N  (4096 kernel uses k < 3841; generic k < N/2)
-    const float2 *tw_256;        // W_256^k, k < 256 (4096 kernel)
+    const float2 *tw_256;        // W_256^k, k < 256 (4096 / 16384 kernels)
+    const float2 *tw_core;       // W_4096^k, k < 4096 (16384 kernel)
     const float *pink;           // bin_stride f32 (zero padded), or nullptr for raw dBFS
     uint64_t frames_per_stream;
     uint64_t first_start;        // frame index where window 0 starts
@@ -39,6 +40,8 @@ hipError_t launch_fft4096_ms(const FftBatchParams &p, hipStream_t s);
 // any power-of-two N in [2, 32768]; mode 0: mono buffers (channels == 1),
 // 1: stereo -> mid/side, 2: per channel
 hipError_t launch_fft_generic(const FftBatchParams &p, int mode, hipStream_t s);
+// N = 16384 real FFT per channel (two radix-16 4096-point halves); same modes as the generic kernel
+hipError_t launch_fft16k(const FftBatchParams &p, int mode, hipStream_t s);
 
 // ---- time domain ------------------------------------------------------------
 struct TdConst {                 // one per (rate, true-peak factor), device resident

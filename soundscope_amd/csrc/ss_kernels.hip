@@ -494,6 +494,135 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms_anyhop(FftBatc
     }
 }
 
+// ============================================================================
+//  Spectrum, N = 16384 (the reference's native window, tui.rs:1488), one REAL channel per
+//  512-thread workgroup: real FFT through an 8192-point complex FFT, split by one radix-2
+//  decimation-in-frequency step into two 4096-point problems that reuse the radix-16 machinery:
+//    z[i] = (xw[2i], xw[2i+1]),  y_q[i] = (z[i] + (-1)^q z[i+4096]) W_8192^(i q),  Z[2k+q] = FFT_4096(y_q)[k]
+//    X[b] = (Z[b] + conj Z[8192-b])/2 - (i/2) W_16384^b (Z[b] - conj Z[8192-b])
+//  Threads 0-255 run q = 0, threads 256-511 run q = 1; the mirror 8192-b has the parity of b, so each
+//  half only mirrors inside its own published spectrum.  mode 0: mono buffer, 1: stereo -> mid/side
+//  (audio_player.rs:400-419), 2: channel `ch` of an interleaved buffer.
+// ============================================================================
+__global__ __launch_bounds__(512, 2) void k_fft16k(FftBatchParams p, int midside, uint32_t fft_ch)
+{
+    __shared__ __attribute__((aligned(16))) v2f xbuf2[2][16 * kPlane];       // 2 x 36864 B
+    __shared__ __attribute__((aligned(16))) v2f tw2s[256];
+#define X1W(ka, tb_, ta_) ((ka) * kX1Stride + (tb_) + 16 * (ta_))
+#define X2W(kb, ka_, tb_) ((kb) * kPlane + (ka_) * kRow + (tb_))
+    const int q = threadIdx.x >> 8;                 // which half-problem
+    const int t = threadIdx.x & 255;
+    v2f *xbuf = xbuf2[q];
+    uint32_t bid = blockIdx.x;
+    const uint32_t ch = bid % fft_ch; bid /= fft_ch;
+    const uint32_t w = bid % p.n_windows;
+    const uint32_t stream = bid / p.n_windows;
+    const size_t start = p.first_start + (size_t)w * p.hop;
+    const float *base = p.pcm + ((size_t)stream * p.frames_per_stream + start) * p.channels;
+    const v2f *tw16k = reinterpret_cast<const v2f *>(p.tw_n);       // W_16384^k, k < 8192
+    const v2f *tw4k = reinterpret_cast<const v2f *>(p.tw_core);     // W_4096^k
+    if (threadIdx.x < 256) tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[t];
+
+    // windowed real samples 2i, 2i+1 as one complex value
+    auto zload = [&](uint32_t i) -> v2f {
+        float x0, x1;
+        if (midside) {
+            const float2 va = reinterpret_cast<const float2 *>(base)[2 * (size_t)i];       // frames 2i, 2i+1: (l,r)
+            const float2 vb = reinterpret_cast<const float2 *>(base)[2 * (size_t)i + 1];
+            x0 = ch == 0 ? (va.x + va.y) * 0.5f : (va.x - va.y) * 0.5f;
+            x1 = ch == 0 ? (vb.x + vb.y) * 0.5f : (vb.x - vb.y) * 0.5f;
+        } else {
+            x0 = base[(size_t)(2 * i) * p.channels + ch];       // mono buffers have fft_ch == 1 => ch == 0
+            x1 = base[(size_t)(2 * i + 1) * p.channels + ch];
+        }
+        const float2 hw = *reinterpret_cast<const float2 *>(p.window + 2 * (size_t)i);
+        return v2f{x0 * hw.x, x1 * hw.y};
+    };
+    v2f z[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint32_t i = (uint32_t)t + 256u * j;
+        const v2f a = zload(i), b = zload(i + 4096u);
+        z[j] = q ? pk_cmul(a - b, tw16k[2 * i]) : a + b;             // W_8192^i = W_16384^(2i)
+    }
+    const int tb = t & 15, hi = t >> 4;
+    // ---- the 4096-point transform of y_q (same passes and LDS layouts as k_fft4096_ms)
+    // pass-1 twiddles W^(t ka) from six gathered ones: W^(t ka) = W^(t (ka & 3)) * W^(t (ka & 12))
+    // (scattered 8-byte gathers are the expensive part of this one-window-per-workgroup kernel)
+    v2f twg[16];
+    twg[1] = tw4k[t]; twg[2] = tw4k[2 * t]; twg[3] = tw4k[3 * t];
+    twg[4] = tw4k[4 * t]; twg[8] = tw4k[8 * t]; twg[12] = tw4k[12 * t];
+    fft16(z);
+    xbuf[X1W(0, tb, hi)] = z[R16(0)];
+#pragma unroll
+    for (int ka = 1; ka < 16; ka++) {
+        v2f v = z[R16(ka)];
+        if (ka & 3) v = pk_cmul(v, twg[ka & 3]);
+        if (ka & 12) v = pk_cmul(v, twg[ka & 12]);
+        xbuf[X1W(ka, tb, hi)] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ta = 0; ta < 16; ta++) z[ta] = xbuf[X1W(hi, tb, ta)];
+    __syncthreads();
+    fft16(z);
+    xbuf[X2W(0, hi, tb)] = z[R16(0)];
+#pragma unroll
+    for (int kb = 1; kb < 16; kb++) xbuf[X2W(kb, hi, tb)] = pk_cmul(z[R16(kb)], tw2s[tb * kb]);
+    __syncthreads();
+#pragma unroll
+    for (int qq = 0; qq < 16; qq++) z[qq] = xbuf[X2W(hi, tb, qq)];
+    __syncthreads();
+    fft16(z);
+    // publish Z_q[k] = Z[2k + q] at position k (natural order)
+#pragma unroll
+    for (int kc = 0; kc < 16; kc++) xbuf[kc * 256 + t] = z[R16(kc)];
+    __syncthreads();
+    // ---- real-FFT recombination + dB for the retained bins; consecutive threads own consecutive bins
+    float *o = p.out + (((size_t)stream * p.n_windows + w) * fft_ch + ch) * p.bin_stride;
+    for (uint32_t idx = threadIdx.x; idx < p.n_bins; idx += 512u) {
+        const uint32_t b = p.first_bin + idx;
+        float xr, xi;
+        if (b == 8192u) {                                           // Nyquist of the real signal
+            const v2f z0 = xbuf2[0][0];
+            xr = z0.x - z0.y; xi = 0.0f;
+        } else {
+            const uint32_t qb = b & 1u, k = b >> 1;
+            const uint32_t km = qb ? (4095u - k) : ((4096u - k) & 4095u);   // index of Z[8192 - b] in its half
+            const v2f zk = xbuf2[qb][k];
+            const v2f zc = xbuf2[qb][km];
+            const float sr = (zk.x + zc.x) * 0.5f, si = (zk.y - zc.y) * 0.5f;
+            const float dr = (zk.x - zc.x) * 0.5f, di = (zk.y + zc.y) * 0.5f;
+            const v2f wv = tw16k[b];
+            const float tr = wv.x * dr - wv.y * di;
+            const float ti = wv.x * di + wv.y * dr;
+            xr = sr + ti;
+            xi = si - tr;
+        }
+        const float qv = fmaf(xr, xr, xi * xi);
+        float r = fmaf(__log2f(qv), 3.01029995663981195f, p.db_offset);
+        r = (qv == 0.0f) ? -150.0f : r;
+        o[idx] = r + (p.pink ? p.pink[idx] : 0.0f);
+    }
+#undef X1W
+#undef X2W
+}
+
+hipError_t launch_fft16k(const FftBatchParams &p, int mode, hipStream_t s)
+{
+    if (p.n_windows == 0 || p.n_streams == 0 || p.n_bins == 0) return hipSuccess;
+    const uint32_t fft_ch = (mode == 0) ? 1u : (mode == 1 ? 2u : p.channels);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft16k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 0);
+        (void)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_fft16k, dim3(p.n_streams * p.n_windows * fft_ch), dim3(512), 0, s, p, mode == 1 ? 1 : 0, fft_ch);
+    return hipGetLastError();
+}
+
 hipError_t launch_fft4096_ms(const FftBatchParams &p, hipStream_t s)
 {
     if (p.n_windows == 0 || p.n_streams == 0) return hipSuccess;
