@@ -106,6 +106,8 @@ def main():
         b.run()
         b.histograms_to_device(hist.data_ptr())      # syncs the batch's stream
         allreduce_histograms(hist)                     # RCCL over xGMI when world > 1
+        if world > 1:
+            torch.cuda.current_stream().synchronize()  # the next step refills `hist`: the collective must be done
 
     def fence():
         torch.cuda.synchronize()

@@ -289,7 +289,8 @@ def test_batch_fast_path_matches_oracle(oracle, frames):
     assert ssa.corpus_integrated_lufs(hb) == oracle.gated_loudness_hist(hb)
 
 
-@pytest.mark.parametrize("rate,fft_n,hop", [(44100, 16384, 1024), (48000, 2048, 512), (48000, 4096, 1000), (48000, 4096, 512)])
+@pytest.mark.parametrize("rate,fft_n,hop", [(44100, 16384, 1024), (48000, 2048, 512), (48000, 4096, 1000), (48000, 4096, 512),
+                                             (48000, 4096, 2048), (48000, 16384, 2048), (96000, 8192, 1024)])
 def test_batch_other_shapes_match_oracle(oracle, rate, fft_n, hop):
     frames = rate * 2 + 77
     xs = [make_stereo(7 + i, frames, rate) for i in range(2)]
@@ -346,3 +347,45 @@ def test_spectrum_linearity_property():
     assert np.abs((c - a) - 20 * np.log10(2)).max() < 1e-3
     r = b.results()
     assert r[1].integrated_lufs - r[0].integrated_lufs == pytest.approx(20 * np.log10(2), abs=0.11)  # 0.1 LU bins
+
+
+def test_batch_mono_and_reference_native_window(oracle):
+    """Mono batch (per-channel spectrum, no mid/side) and the reference's own cadence: N = 16384, hop 1024
+    (tui.rs:1488, audio_player.rs:65) on a stereo stream; a sample of windows is compared bin by bin."""
+    rate, frames = 48000, 48000 * 3
+    x = make_multich(17, frames, 1, rate)
+    b = ssa.Batch(rate, 1, 1, frames, 4096, 1024)
+    b.upload(0, x)
+    b.run(); b.sync()
+    lay = b.layout
+    assert lay.fft_channels == 1
+    fft = b.fft(0)
+    for w in (0, lay.n_windows - 1):
+        start = (w + 1) * 1024
+        assert db_close(fft[w, 0], oracle.get_fft(rate, x[start:start + 4096])[:, 1], TOL_DB)
+    m = oracle.Meter(1, rate); m.add_frames(x)
+    assert lufs_close(b.results()[0].integrated_lufs, m.integrated())
+
+    xs = make_stereo(23, 48000 * 10, rate)
+    b = ssa.Batch(rate, 2, 1, 48000 * 10, 16384, 1024, flags=L.SS_BATCH_FFT)
+    b.upload(0, xs)
+    b.run(); b.sync()
+    assert b.layout.n_windows == 452 and b.layout.n_bins == 6820         # SURVEY section 8 counts
+    mid, side = oracle.mid_side(xs)
+    fft = b.fft(0)
+    for w in (0, 200, 451):
+        start = (w + 1) * 1024
+        assert db_close(fft[w, 0], oracle.get_fft(rate, mid[start:start + 16384])[:, 1], TOL_DB)
+        assert db_close(fft[w, 1], oracle.get_fft(rate, side[start:start + 16384])[:, 1], TOL_DB)
+
+
+def test_large_single_feed_and_many_small_feeds_agree(oracle):
+    """One 20 s add_samples call (split internally into <= 32-sub-block pieces) equals the oracle."""
+    rate = 44100
+    x = make_stereo(31, rate * 20, rate, gap=True)
+    an = ssa.Analyzer(); an.create_loudness_meter(2, rate)
+    an.add_samples(x)
+    m = oracle.Meter(2, rate); m.add_frames(x)
+    assert lufs_close(an.get_integrated_lufs(), m.integrated())
+    assert abs(an.get_loudness_range() - m.loudness_range()) <= TOL_DB
+    assert lufs_close(an.get_shortterm_lufs(), m.shortterm())
