@@ -118,6 +118,37 @@ int ss_get_sample_peak_channel(ss_analyzer *h, uint32_t channel, double *out);
 int ss_analyzer_set_true_peak_factor(ss_analyzer *h, int factor);
 
 /* ------------------------------------------------------------------------ *
+ *  PCM ingest: the step before the path.  The reference decodes a
+ *  file with symphonia into one interleaved Vec<f32> (audio_player.rs:169-267,
+ *  SampleBuffer::<f32>::copy_interleaved_ref); for RIFF/WAVE PCM that is a
+ *  sample-format conversion, done here on the device:
+ *    u8: s/128 - 1   s16: s/32768   s24: s/8388608   s32: (f32)(s/2147483648.0)
+ *    f32: as is      f64: (f32)s          (all divisions are exact powers of two)
+ * ------------------------------------------------------------------------ */
+typedef enum ss_pcm_format {
+    SS_PCM_U8 = 1, SS_PCM_S16 = 2, SS_PCM_S24 = 3, SS_PCM_S32 = 4, SS_PCM_F32 = 5, SS_PCM_F64 = 6
+} ss_pcm_format;
+
+typedef struct ss_wav_info {
+    uint32_t format;        /* ss_pcm_format */
+    uint32_t channels;
+    uint32_t sample_rate;
+    uint32_t bits_per_sample;
+    uint64_t data_offset;   /* byte offset of the first sample in the file image */
+    uint64_t data_bytes;    /* bytes of sample data actually present            */
+    uint64_t frames;        /* whole frames in the data chunk                   */
+} ss_wav_info;
+
+/* Parse a RIFF/WAVE image held in memory (little-endian PCM / IEEE float, incl.
+ * WAVE_FORMAT_EXTENSIBLE).  Host logic only; no device needed.
+ * SS_ERR_INVALID_ARG: not a WAVE file / truncated header; SS_ERR_UNSUPPORTED: other codecs. */
+int ss_wav_parse(const void *file_bytes, size_t len, ss_wav_info *out);
+/* bytes per sample of a format (0 if unknown) */
+size_t ss_pcm_sample_bytes(int format);
+/* interleaved little-endian PCM -> interleaved f32 (host in, host out, converted on the device) */
+int ss_pcm_decode(const void *pcm, size_t n_samples, int format, float *out);
+
+/* ------------------------------------------------------------------------ *
  *  Batch extension (NOT in the reference): many independent streams of equal
  *  length analysed in one pass — the data-parallel form of
  *  receive_audio_file + analyze_audio_file_samples (tui.rs:1207-1241,
@@ -176,6 +207,9 @@ int ss_batch_layout_get(const ss_batch *b, ss_batch_layout *out);
  * count*frames_per_stream*channels floats */
 int ss_batch_upload(ss_batch *b, uint32_t first, uint32_t count, const float *pcm);
 int ss_batch_download_input(ss_batch *b, uint32_t stream, float *pcm, size_t cap_floats);
+/* same as ss_batch_upload for raw PCM of `format`: the bytes are copied to the GPU and converted
+ * there straight into the resident f32 corpus (no host-side f32 copy) */
+int ss_batch_upload_pcm(ss_batch *b, uint32_t first, uint32_t count, const void *pcm, int format);
 /* device pointer of the resident corpus ([stream][frame][channel] f32) for
  * producers that already hold data on the GPU */
 void *ss_batch_input_device_ptr(ss_batch *b);

@@ -32,6 +32,7 @@ def _load(native: bool = False):
     lib.so_get_fft_ex.argtypes = [C.c_uint32, f32p, C.c_size_t, f64p, f32p, C.c_size_t, szp, C.c_int]
     lib.so_get_waveform.argtypes = [f32p, C.c_size_t, C.c_double, f64p, C.c_size_t]
     lib.so_get_waveform.restype = C.c_size_t
+    lib.so_pcm_to_f32.argtypes = [C.c_char_p, C.c_size_t, C.c_int, f32p]
     lib.so_mid_side.argtypes = [f32p, C.c_size_t, f32p, f32p]
     lib.so_mid_side.restype = C.c_size_t
     vp = C.c_void_p
@@ -130,6 +131,14 @@ def get_waveform(x, window_s):
     out = np.empty((2 * w + 2, 2), np.float64)
     n = lib().so_get_waveform(xp, x.size, float(window_s), out.ctypes.data_as(C.POINTER(C.c_double)), 2 * w + 2)
     return out[:n].copy()
+
+
+def pcm_to_f32(raw: bytes, fmt: int):
+    sb = {1: 1, 2: 2, 3: 3, 4: 4, 5: 4, 6: 8}[fmt]
+    n = len(raw) // sb
+    out = np.empty(n, np.float32)
+    lib().so_pcm_to_f32(raw, n, fmt, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
 
 
 def mid_side(x):

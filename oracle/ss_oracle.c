@@ -291,6 +291,28 @@ size_t so_get_waveform(const float *x, size_t n, double window_s,
     return np;
 }
 
+/* PCM sample conversion to f32 as symphonia 0.5 performs it for SampleBuffer::<f32>
+ * (audio_player.rs:236-247 copy_interleaved_ref) [crate not vendored: conversions restated from its
+ * documented FromSample impls; every scale is an exact power of two]:
+ * fmt 1 u8, 2 s16, 3 s24 (packed LE), 4 s32, 5 f32, 6 f64 */
+void so_pcm_to_f32(const unsigned char *src, size_t n, int fmt, float *dst)
+{
+    for (size_t i = 0; i < n; i++) {
+        float v;
+        switch (fmt) {
+            case 1: v = (float)src[i] / 128.0f - 1.0f; break;
+            case 2: { short s; memcpy(&s, src + 2 * i, 2); v = (float)s / 32768.0f; break; }
+            case 3: { const unsigned char *q = src + 3 * i;
+                      int s = (int)q[0] | ((int)q[1] << 8) | ((int)(signed char)q[2] << 16);
+                      v = (float)s / 8388608.0f; break; }
+            case 4: { int s; memcpy(&s, src + 4 * i, 4); v = (float)((double)s / 2147483648.0); break; }
+            case 5: memcpy(&v, src + 4 * i, 4); break;
+            default: { double d; memcpy(&d, src + 8 * i, 8); v = (float)d; break; }
+        }
+        dst[i] = v;
+    }
+}
+
 /* get_mid_and_side_samples, audio_player.rs:400-419 */
 size_t so_mid_side(const float *s, size_t n, float *mid, float *side)
 {

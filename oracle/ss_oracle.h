@@ -62,6 +62,9 @@ int so_get_fft_ex(uint32_t sample_rate, const float *x, size_t n,
 size_t so_get_waveform(const float *x, size_t n, double window_s,
                        double *out_xy, size_t cap_pairs);
 
+/* ---- PCM ingest (audio_player.rs:169-267 via symphonia) ---- */
+void so_pcm_to_f32(const unsigned char *src, size_t n, int fmt, float *dst);
+
 /* ---- mid/side (audio_player.rs:400-419) ---- */
 size_t so_mid_side(const float *interleaved, size_t n, float *mid, float *side);
 

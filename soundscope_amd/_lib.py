@@ -26,6 +26,7 @@ SYMBOLS = [
     "ss_batch_download_fft", "ss_batch_bin_tables", "ss_batch_download_waveform", "ss_batch_download_subblocks",
     "ss_batch_histograms", "ss_batch_histograms_device", "ss_corpus_integrated_lufs", "ss_corpus_loudness_range",
     "ss_batch_timing_enable", "ss_batch_timing_read", "ss_kernel_name",
+    "ss_wav_parse", "ss_pcm_sample_bytes", "ss_pcm_decode", "ss_batch_upload_pcm",
 ]
 
 SS_OK = 0
@@ -34,6 +35,7 @@ SS_ERR_TOO_FEW_SAMPLES, SS_ERR_NAN, SS_ERR_INFINITY, SS_ERR_NOT_POW2, SS_ERR_FRE
 SS_ERR_CAPACITY, SS_ERR_UNSUPPORTED, SS_ERR_INVALID_ARG, SS_ERR_DEVICE = 20, 21, 22, 30
 
 SS_BATCH_FFT, SS_BATCH_LUFS, SS_BATCH_TRUE_PEAK, SS_BATCH_WAVEFORM, SS_BATCH_ALL = 1, 2, 4, 8, 15
+SS_PCM_U8, SS_PCM_S16, SS_PCM_S24, SS_PCM_S32, SS_PCM_F32, SS_PCM_F64 = 1, 2, 3, 4, 5, 6
 SS_KERNEL_FFT, SS_KERNEL_TIME_DOMAIN, SS_KERNEL_FINALIZE, SS_KERNEL_WAVEFORM, SS_KERNEL_COUNT = 0, 1, 2, 3, 4
 
 
@@ -48,6 +50,12 @@ class StreamResult(C.Structure):
     _fields_ = [("integrated_lufs", C.c_double), ("loudness_range", C.c_double),
                 ("true_peak", C.c_double * 2), ("sample_peak", C.c_double * 2),
                 ("n_gating_blocks", C.c_uint32), ("n_st_blocks", C.c_uint32)]
+
+
+class WavInfo(C.Structure):
+    _fields_ = [("format", C.c_uint32), ("channels", C.c_uint32), ("sample_rate", C.c_uint32),
+                ("bits_per_sample", C.c_uint32), ("data_offset", C.c_uint64), ("data_bytes", C.c_uint64),
+                ("frames", C.c_uint64)]
 
 
 class BatchLayout(C.Structure):
@@ -113,6 +121,10 @@ def _bind(lib):
         "ss_batch_timing_enable": (C.c_int, [vp, C.c_int]),
         "ss_batch_timing_read": (C.c_int, [vp, C.c_int, f64p, u64p]),
         "ss_kernel_name": (C.c_char_p, [C.c_int]),
+        "ss_wav_parse": (C.c_int, [vp, C.c_size_t, C.POINTER(WavInfo)]),
+        "ss_pcm_sample_bytes": (C.c_size_t, [C.c_int]),
+        "ss_pcm_decode": (C.c_int, [vp, C.c_size_t, C.c_int, f32p]),
+        "ss_batch_upload_pcm": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

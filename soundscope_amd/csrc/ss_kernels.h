@@ -123,6 +123,8 @@ struct WaveParams {
 hipError_t launch_waveform(const WaveParams &p, hipStream_t s);
 
 // ---- utilities --------------------------------------------------------------
+// raw little-endian PCM -> f32 (format: 1 u8, 2 s16, 3 s24, 4 s32, 5 f32, 6 f64)
+hipError_t launch_pcm_to_f32(const void *src, size_t n_samples, int format, float *dst, hipStream_t s);
 hipError_t launch_mid_side(const float *interleaved, size_t frames, float *mid, float *side, hipStream_t s);
 hipError_t launch_synth(float *pcm, uint32_t n_streams, uint64_t frames, uint32_t channels,
                         uint32_t rate, uint64_t seed, uint32_t first_id, hipStream_t s);

@@ -1614,6 +1614,39 @@ hipError_t launch_mid_side(const float *interleaved, size_t frames, float *mid, 
     return hipGetLastError();
 }
 
+// PCM ingest: symphonia's sample conversions to f32 (audio_player.rs:169-267 decodes through
+// SampleBuffer::<f32>::copy_interleaved_ref).  Every scale is an exact power of two.
+__global__ __launch_bounds__(256) void k_pcm_to_f32(const unsigned char *src, size_t n, int format, float *dst)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float v;
+        switch (format) {
+            case 1: v = (float)src[i] / 128.0f - 1.0f; break;
+            case 2: v = (float)reinterpret_cast<const short *>(src)[i] / 32768.0f; break;
+            case 3: {
+                const unsigned char *q = src + 3 * i;
+                int s = (int)q[0] | ((int)q[1] << 8) | ((int)(signed char)q[2] << 16);
+                v = (float)s / 8388608.0f;
+                break;
+            }
+            case 4: v = (float)((double)reinterpret_cast<const int *>(src)[i] / 2147483648.0); break;
+            case 5: v = reinterpret_cast<const float *>(src)[i]; break;
+            default: v = (float)reinterpret_cast<const double *>(src)[i]; break;
+        }
+        dst[i] = v;
+    }
+}
+
+hipError_t launch_pcm_to_f32(const void *src, size_t n_samples, int format, float *dst, hipStream_t s)
+{
+    if (!n_samples) return hipSuccess;
+    size_t blocks = (n_samples + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_pcm_to_f32, dim3((uint32_t)blocks), dim3(256), 0, s,
+                       static_cast<const unsigned char *>(src), n_samples, format, dst);
+    return hipGetLastError();
+}
+
 // Synthetic corpus: per stream two sines + uniform noise, level
 // spread over ~20 dB, 5 % of streams carry a 3 s near-silent segment.
 __device__ __forceinline__ uint32_t mix32(uint64_t x)
