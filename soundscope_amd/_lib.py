@@ -141,6 +141,11 @@ def lib():
     global _LIB
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
+            try:                      # build on demand (hipcc cross-compiles gfx950 without a GPU)
+                build()
+            except Exception:
+                pass
+        if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} is missing: the HIP extension has not been built "
                 "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C soundscope_amd/csrc`). "

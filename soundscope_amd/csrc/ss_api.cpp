@@ -277,7 +277,7 @@ struct ss_analyzer {
     DevBuf<double> ring;            // ring_frames x C
     DevBuf<double> weights;
     DevBuf<uint32_t> counts;
-    DevBuf<double> out2;
+    DevBuf<double> out2, ring_scratch;
     DevBuf<float> in, fft_out;
     uint64_t ring_frames = 0;
     uint64_t frames_fed = 0;
@@ -305,6 +305,7 @@ int handle_make_meter(ss_analyzer *h, uint32_t channels, uint32_t rate)
     HIPCHK(h->ring.alloc(ring_frames * channels));
     HIPCHK(h->counts.alloc(2));
     HIPCHK(h->out2.alloc(2));
+    HIPCHK(h->ring_scratch.alloc(128));
     std::vector<double> w(channels);
     sst::channel_weights(channels, w.data());
     HIPCHK(h->weights.upload(w));
@@ -682,7 +683,7 @@ static int ring_loudness(ss_analyzer *h, uint64_t frames, double *out)
     if (!h->meter_ok) return SS_ERR_INVALID_MODE;
     if (frames > h->ring_frames) return SS_ERR_INVALID_MODE;
     HIPCHK(ssk::launch_ring_energy(h->ring.p, h->ring_frames, h->channels, h->frames_fed, frames,
-                                   h->weights.p, h->out2.p, h->stream));
+                                   h->weights.p, h->out2.p, h->ring_scratch.p, h->stream));
     double r[2];
     HIPCHK(hipMemcpyAsync(r, h->out2.p, sizeof r, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

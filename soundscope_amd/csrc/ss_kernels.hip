@@ -1507,17 +1507,19 @@ hipError_t launch_hist_eval(const uint64_t *hist2000, const double *energies, co
 }
 
 // mean square over the last `frames` frames of the filtered ring, channel-weighted
-// (calc_gating_block on the ring "as is": loudness_shortterm / loudness_momentary)
+// (calc_gating_block on the ring "as is": loudness_shortterm / loudness_momentary).
+// Two stages with a fixed reduction shape (bit-reproducible): kRingBlocks partial sums, then one block.
+constexpr int kRingBlocks = 96;
 __global__ __launch_bounds__(256) void k_ring_energy(const double *ring, uint64_t ring_frames, uint32_t C,
                                                      uint64_t end_frame, uint64_t frames,
-                                                     const double *weights, double *out)
+                                                     const double *weights, double *partial)
 {
     __shared__ double red[256];
     double acc = 0.0;
     const uint64_t total = frames * C;
     // ring position of absolute frame f is f % ring_frames; frames before 0 are the zeroed ring
     const uint64_t begin = end_frame + ring_frames * 4 - frames;    // keep the subtraction non-negative
-    for (uint64_t i = threadIdx.x; i < total; i += 256) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)kRingBlocks * 256) {
         const uint64_t f = i / C; const uint32_t c = (uint32_t)(i - f * C);
         const double w = weights[c];
         const double y = ring[((begin + f) % ring_frames) * C + c];
@@ -1526,6 +1528,18 @@ __global__ __launch_bounds__(256) void k_ring_energy(const double *ring, uint64_
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(128) void k_ring_final(const double *partial, uint64_t frames, double *out)
+{
+    __shared__ double red[128];
+    red[threadIdx.x] = threadIdx.x < kRingBlocks ? partial[threadIdx.x] : 0.0;
+    __syncthreads();
+    for (int s = 64; s >= 1; s >>= 1) {
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
@@ -1538,10 +1552,11 @@ __global__ __launch_bounds__(256) void k_ring_energy(const double *ring, uint64_
 
 hipError_t launch_ring_energy(const double *ring, uint64_t ring_frames, uint32_t channels,
                               uint64_t end_frame, uint64_t frames, const double *weights,
-                              double *out, hipStream_t s)
+                              double *out, double *scratch, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_ring_energy, dim3(1), dim3(256), 0, s, ring, ring_frames, channels,
-                       end_frame % ring_frames, frames, weights, out);
+    hipLaunchKernelGGL(k_ring_energy, dim3(kRingBlocks), dim3(256), 0, s, ring, ring_frames, channels,
+                       end_frame % ring_frames, frames, weights, scratch);
+    hipLaunchKernelGGL(k_ring_final, dim3(1), dim3(128), 0, s, scratch, frames, out);
     return hipGetLastError();
 }
 

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Latency of one reference tick (tui.rs:1482-1552) through the C ABI: get_fft(mid) + get_fft(side)
+(N = 16384) + add_samples(last 16384 interleaved samples) + get_shortterm_lufs."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import soundscope_amd as ssa
+from conftest import make_stereo
+rate = 48000
+x = make_stereo(1, rate * 12, rate)
+mid, side = ssa.get_mid_and_side_samples(x)
+an = ssa.Analyzer(); an.create_loudness_meter(2, rate)
+t_fft, t_add, t_st, t_all = [], [], [], []
+for tick, pos in enumerate(range(16384 * 2 + 2048, x.size, 2048)):
+    fpos = pos // 2
+    t0 = time.perf_counter()
+    an.get_fft(mid[fpos - 16384:fpos]); an.get_fft(side[fpos - 16384:fpos])
+    t1 = time.perf_counter()
+    an.add_samples(x[pos - 16384:pos])
+    t2 = time.perf_counter()
+    an.get_shortterm_lufs()
+    t3 = time.perf_counter()
+    if tick >= 20:
+        t_fft.append(t1 - t0); t_add.append(t2 - t1); t_st.append(t3 - t2); t_all.append(t3 - t0)
+    if tick > 300:
+        break
+f = lambda v: f"median {np.median(v) * 1e6:.0f} us, p99 {np.percentile(v, 99) * 1e6:.0f} us"
+print("2 x get_fft(16384):", f(t_fft)); print("add_samples(16384):", f(t_add)); print("get_shortterm_lufs:", f(t_st))
+print("whole tick        :", f(t_all), "(budget: 8 ms TUI loop + 21 ms between ticks at 48 kHz)")
+t0 = time.perf_counter(); w = ssa.Analyzer.get_waveform(x, 12.0); t1 = time.perf_counter()
+v = an.calculate_integrated_lufs(2, x); t2 = time.perf_counter()
+print(f"file load (12 s stereo): get_waveform {(t1 - t0) * 1e3:.2f} ms, calculate_integrated_lufs {(t2 - t1) * 1e3:.2f} ms")
