@@ -77,6 +77,7 @@ struct BinTables {
     size_t first = 0, count = 0;
     std::vector<double> freq, pink, chart_x;
     DevBuf<float> pink_dev;
+    DevBuf<float> offpink4096_dev;      // db_offset(4096) + pink, for the N = 4096 kernels
 };
 
 struct TdTables {
@@ -195,6 +196,12 @@ int get_bin_tables(uint32_t rate, size_t n, BinTables **out)
     std::vector<float> pf((t->count + 3) & ~(size_t)3, 0.0f);    // padded to the output row stride
     for (size_t i = 0; i < t->count; i++) pf[i] = (float)t->pink[i];
     HIPCHK(t->pink_dev.upload(pf));
+    if (n == 4096) {
+        const float off = (float)(10.0 * std::log10(4.0 / (4096.0 * 4096.0)));
+        std::vector<float> op(pf.size());
+        for (size_t i = 0; i < pf.size(); i++) op[i] = off + pf[i];
+        HIPCHK(t->offpink4096_dev.upload(op));
+    }
     *out = t.get();
     c.bins[key] = std::move(t);
     return SS_OK;
@@ -1039,6 +1046,18 @@ int ss_batch_run(ss_batch *b)
         p.windows_per_block = b->windows_per_block;
         if (b->fft_fast) {
             p.db_offset = (float)(10.0 * std::log10(4.0 / ((double)c.fft_n * (double)c.fft_n)));
+            p.offpink = b->bt->offpink4096_dev.p;
+            {
+                const uint32_t lo = L.first_bin, hi = L.first_bin + L.n_bins - 1;      // retained bins and their mirrors
+                uint32_t mask = 0;
+                for (uint32_t kc = 0; kc < 16; kc++) {
+                    const uint32_t a0 = 256 * kc, a1 = a0 + 255;
+                    const bool direct = a0 <= hi + 3 && a1 >= lo;                       // +3: the last group of four may run past
+                    const bool mirror = a0 <= 4096 - lo && a1 + 3 >= 4096 - hi - 3;
+                    if (direct || mirror) mask |= 1u << kc;
+                }
+                p.publish_mask = mask;
+            }
             HIPCHK(ssk::launch_fft4096_ms(p, b->stream));
         } else {
             p.db_offset = (float)(20.0 * std::log10(4.0 / (double)c.fft_n));

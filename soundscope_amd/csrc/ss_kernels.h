@@ -21,7 +21,8 @@ struct FftBatchParams {
     const float2 *tw_n;          // W_N^k, k < N  (4096 kernel uses k < 3841; generic k < N/2)
     const float2 *tw_256;        // W_256^k, k < 256 (4096 / 16384 kernels)
     const float2 *tw_core;       // W_4096^k, k < 4096 (16384 kernel)
-    const float *pink;           // bin_stride f32 (zero padded), or nullptr for raw dBFS
+    const float *pink;           // bin_stride f32 (zero padded), or nullptr for raw dBFS (generic / 16k kernels)
+    const float *offpink;        // bin_stride f32: db_offset + pink[bin] (4096 kernels)
     uint64_t frames_per_stream;
     uint64_t first_start;        // frame index where window 0 starts
     uint32_t n_streams;
@@ -33,6 +34,7 @@ struct FftBatchParams {
     uint32_t bin_stride;         // floats between output rows (n_bins rounded up to 4: 16-B aligned rows)
     uint32_t windows_per_block;  // 4096 kernel
     float db_offset;             // 10*log10(4/N^2) (4096) or 20*log10(4/N) (generic)
+    uint32_t publish_mask;       // 4096 kernels: bit kc set when bins [256kc, 256kc+255] hold a retained bin or a mirror
 };
 
 // mid/side packed N=4096 kernel (stereo only).  hop must be a multiple of 256.
