@@ -248,6 +248,68 @@ int ss_batch_timing_enable(ss_batch *b, int enable);
 int ss_batch_timing_read(ss_batch *b, int kernel, double *total_ms, uint64_t *launches);
 const char *ss_kernel_name(int kernel);
 
+/* ------------------------------------------------------------------------- *
+ *  Tick drivers: the per-file / per-device state of the
+ *  reference's App and its per-tick analysis, with the audio resident in HBM.
+ *    ss_session_open_file     receive_audio_file            tui.rs:1207-1241
+ *                             (+ AudioFile::from_file's mid/side and duration,
+ *                              audio_player.rs:150-166)
+ *    ss_session_tick_file     analyze_audio_file_samples    tui.rs:1482-1552
+ *    ss_session_open_capture  device selection              tui.rs:1780-1808
+ *    ss_session_tick_capture  analyze_microphone_input      tui.rs:1427-1480
+ *    ss_session_restart       play / seek handlers          tui.rs:1586-1614
+ *  A tick is ONE call, one stream, one synchronisation: nothing is uploaded for
+ *  a file tick (the file was uploaded at open), the capture tick uploads the
+ *  30*rate-sample capture ring.  The session owns its analyzer (file_analyzer /
+ *  device_analyzer) and the 300-entry short-term history (tui.rs:420,463).
+ * ------------------------------------------------------------------------- */
+typedef struct ss_session ss_session;
+
+#define SS_LUFS_HISTORY 300
+#define SS_TICK_WINDOW 16384      /* tui.rs:1488 / :1431: FFT window; :1529 / :1466: LUFS slice (samples) */
+
+typedef struct ss_tick_result {
+    uint64_t playhead;         /* pos / channels (tui.rs:1484-1485); capture: 0                     */
+    int32_t fft_ran;           /* 0: the reference skips the FFT block (left bound == 0)            */
+    int32_t mid_status;        /* status of get_fft(mid); != 0 => the reference stores [(0., 0.)]   */
+    int32_t side_status;
+    uint32_t n_mid, n_side;    /* pairs written to mid_xy / side_xy (1 = the (0,0) fallback)        */
+    int32_t lufs_ran;          /* 0: LUFS block skipped (left bound == 0): history not shifted      */
+    int32_t fed;               /* 1: add_samples + get_shortterm_lufs ran (bounds check passed)     */
+    int32_t add_status;        /* status of add_samples                                             */
+    int32_t shortterm_status;  /* status of get_shortterm_lufs; != 0 => lufs[299] = 0.0             */
+    uint32_t reserved;
+    double shortterm;          /* lufs[299] after this tick                                         */
+} ss_tick_result;              /* 56 bytes */
+
+/* interleaved: the decoded file (AudioFile::samples), n_samples floats; channels: the file's channel
+ * count (AudioFile::channels — used only for pos / channels, mid/side always pair samples 2i, 2i+1);
+ * the meter is created with 2 channels like the reference (tui.rs:1217-1221). */
+int ss_session_open_file(const float *interleaved, size_t n_samples, uint32_t channels,
+                         uint32_t sample_rate, ss_session **out);
+/* device_analyzer.create_loudness_meter(channels, rate) + a 30*rate capture ring */
+int ss_session_open_capture(uint32_t channels, uint32_t sample_rate, ss_session **out);
+void ss_session_close(ss_session *s);
+/* the session's Analyzer (for get_integrated_lufs / get_true_peak / get_loudness_range reads) */
+ss_analyzer *ss_session_analyzer(ss_session *s);
+/* waveform.audio_file_chart = get_waveform(samples, duration_s) (tui.rs:1213-1216) */
+int ss_session_waveform(ss_session *s, double *out_xy, size_t cap_pairs, size_t *out_n);
+/* fft_gain_compensation_db = FFT_TARGET_LUFS(-13) - integrated as f32, or 0 (tui.rs:1229-1238) */
+int ss_session_gain_db(ss_session *s, float *out);
+/* AudioFile::duration in ms (audio_player.rs:154) */
+int ss_session_duration_ms(ss_session *s, uint64_t *out);
+/* pos: the playback position in interleaved samples as passed to analyze_audio_file_samples */
+int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side_xy,
+                         size_t cap_pairs, ss_tick_result *res);
+/* latest: the capture ring oldest-first (latest_captured_samples.to_vec()), n must be 30 * rate.
+ * wave_xy receives waveform.microphone_input_chart = get_waveform(mid, 15.) */
+int ss_session_tick_capture(ss_session *s, const float *latest, size_t n, double *mid_xy,
+                            double *side_xy, size_t cap_pairs, double *wave_xy,
+                            size_t wave_cap_pairs, size_t *wave_n, ss_tick_result *res);
+/* lufs = [-100.; 300]; analyzer.reset() */
+int ss_session_restart(ss_session *s);
+int ss_session_lufs_history(ss_session *s, double *out300);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,9 @@ SYMBOLS = [
     "ss_batch_histograms", "ss_batch_histograms_device", "ss_corpus_integrated_lufs", "ss_corpus_loudness_range",
     "ss_batch_timing_enable", "ss_batch_timing_read", "ss_kernel_name",
     "ss_wav_parse", "ss_pcm_sample_bytes", "ss_pcm_decode", "ss_batch_upload_pcm",
+    "ss_session_open_file", "ss_session_open_capture", "ss_session_close", "ss_session_analyzer",
+    "ss_session_waveform", "ss_session_gain_db", "ss_session_duration_ms", "ss_session_tick_file",
+    "ss_session_tick_capture", "ss_session_restart", "ss_session_lufs_history",
 ]
 
 SS_OK = 0
@@ -56,6 +59,13 @@ class WavInfo(C.Structure):
     _fields_ = [("format", C.c_uint32), ("channels", C.c_uint32), ("sample_rate", C.c_uint32),
                 ("bits_per_sample", C.c_uint32), ("data_offset", C.c_uint64), ("data_bytes", C.c_uint64),
                 ("frames", C.c_uint64)]
+
+
+class TickResult(C.Structure):
+    _fields_ = [("playhead", C.c_uint64), ("fft_ran", C.c_int32), ("mid_status", C.c_int32),
+                ("side_status", C.c_int32), ("n_mid", C.c_uint32), ("n_side", C.c_uint32),
+                ("lufs_ran", C.c_int32), ("fed", C.c_int32), ("add_status", C.c_int32),
+                ("shortterm_status", C.c_int32), ("reserved", C.c_uint32), ("shortterm", C.c_double)]
 
 
 class BatchLayout(C.Structure):
@@ -125,6 +135,18 @@ def _bind(lib):
         "ss_pcm_sample_bytes": (C.c_size_t, [C.c_int]),
         "ss_pcm_decode": (C.c_int, [vp, C.c_size_t, C.c_int, f32p]),
         "ss_batch_upload_pcm": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, C.c_int]),
+        "ss_session_open_file": (C.c_int, [f32p, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(vp)]),
+        "ss_session_open_capture": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(vp)]),
+        "ss_session_close": (None, [vp]),
+        "ss_session_analyzer": (vp, [vp]),
+        "ss_session_waveform": (C.c_int, [vp, f64p, C.c_size_t, szp]),
+        "ss_session_gain_db": (C.c_int, [vp, C.POINTER(C.c_float)]),
+        "ss_session_duration_ms": (C.c_int, [vp, u64p]),
+        "ss_session_tick_file": (C.c_int, [vp, C.c_size_t, f64p, f64p, C.c_size_t, C.POINTER(TickResult)]),
+        "ss_session_tick_capture": (C.c_int, [vp, f32p, C.c_size_t, f64p, f64p, C.c_size_t, f64p, C.c_size_t,
+                                              szp, C.POINTER(TickResult)]),
+        "ss_session_restart": (C.c_int, [vp]),
+        "ss_session_lufs_history": (C.c_int, [vp, f64p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -1,0 +1,141 @@
+"""Tick drivers through the C ABI against the CPU restatement of the reference App
+(oracle/app_driver.py follows tui.rs:1207-1241, :1427-1552).  Same bars as test_gpu_parity.py:
+decimation bit-exact, spectrum / loudness within +-0.01 dB."""
+import numpy as np
+import pytest
+
+import soundscope_amd as ssa
+from soundscope_amd import _lib as L
+from conftest import db_close, make_stereo
+
+pytestmark = pytest.mark.gpu
+
+TOL_DB = 0.01
+
+
+def lufs_close(a, b, tol=TOL_DB):
+    if np.isinf(a) or np.isinf(b):
+        return a == b
+    return abs(a - b) <= tol
+
+
+def check_tick(res, ref, sess, app):
+    for k in ("fft_ran", "mid_status", "side_status", "lufs_ran", "fed", "add_status", "shortterm_status"):
+        assert getattr(res, k) == ref[k], (k, getattr(res, k), ref[k])
+    if ref["fft_ran"]:
+        for got, want in ((sess.mid_fft, app.mid_fft), (sess.side_fft, app.side_fft)):
+            assert got.shape == want.shape
+            if want.shape[0] > 1:
+                assert np.array_equal(got[:, 0], want[:, 0])
+                assert db_close(got[:, 1], want[:, 1], TOL_DB)
+            else:
+                assert np.array_equal(got, want)
+    assert lufs_close(res.shortterm, ref["shortterm"])
+
+
+@pytest.mark.parametrize("rate,seconds", [(48000, 6.0), (44100, 4.3)])
+def test_file_session_matches_reference_driver(oracle, rate, seconds):
+    from oracle.app_driver import FileApp
+    frames = int(rate * seconds)
+    x = make_stereo(7 + rate, frames, rate=rate, level=0.6)
+    sess = ssa.FileSession(x, 2, rate)
+    app = FileApp(x, 2, rate)
+    # receive_audio_file
+    assert sess.duration_ms == app.duration_ms
+    assert sess.audio_file_chart.shape == app.audio_file_chart.shape
+    assert np.array_equal(sess.audio_file_chart, app.audio_file_chart)          # bit-exact decimation
+    assert abs(sess.fft_gain_compensation_db - app.fft_gain_compensation_db) <= TOL_DB
+    # playback: the player reports positions at hop 1024 frames (interleaved samples = 2048 per tick);
+    # include the early ticks the reference skips (left bound 0) and positions past the end
+    positions = list(range(2048, 2 * frames + 3 * 2048, 2048))
+    for pos in positions[:40] + positions[40::7]:
+        res = sess.analyze_audio_file_samples(pos)
+        ref = app.analyze_audio_file_samples(pos)
+        assert res.playhead == ref["playhead"]
+        check_tick(res, ref, sess, app)
+    assert np.allclose(sess.lufs, app.lufs, atol=TOL_DB)
+    # the file_analyzer's running state after the 8x-overlapped feed
+    assert lufs_close(sess.analyzer.get_integrated_lufs(), app.analyzer.meter.integrated())
+    tl, tr = sess.analyzer.get_true_peak()
+    for got, c in ((tl, 0), (tr, 1)):
+        want = max(app.analyzer.meter.true_peak(c), app.analyzer.meter.sample_peak(c))
+        assert abs(got - want) <= 1e-4 * want
+    # seek: lufs history and meter are cleared
+    sess.restart()
+    app.restart()
+    assert np.array_equal(sess.lufs, app.lufs)
+    pos = 2048 * 30
+    check_tick(sess.analyze_audio_file_samples(pos), app.analyze_audio_file_samples(pos), sess, app)
+    assert np.allclose(sess.lufs, app.lufs, atol=TOL_DB)
+
+
+def test_file_session_odd_cases(oracle):
+    """Mono-flagged file (pos / 1), a NaN pair and an infinite pair inside some windows, odd sample count."""
+    from oracle.app_driver import FileApp
+    rate = 48000
+    x = make_stereo(99, rate * 2, rate=rate, level=0.5)[:-1].copy()      # odd length: last sample unpaired
+    x[2 * 30000] = np.nan                                                # mid and side NaN at pair 30000
+    x[2 * 60000 + 1] = np.inf                                            # mid +inf, side -inf at pair 60000
+    for channels in (2, 1):
+        sess = ssa.FileSession(x, channels, rate)
+        app = FileApp(x, channels, rate)
+        assert sess.duration_ms == app.duration_ms
+        assert np.array_equal(sess.audio_file_chart, app.audio_file_chart, equal_nan=True)
+        assert (sess.fft_gain_compensation_db == app.fft_gain_compensation_db
+                or abs(sess.fft_gain_compensation_db - app.fft_gain_compensation_db) <= TOL_DB
+                or (np.isnan(sess.fft_gain_compensation_db) and np.isnan(app.fft_gain_compensation_db)))
+        step = 2048 if channels == 2 else 1024
+        for pos in range(step * 14, x.size + 4 * step, step * 3):
+            res = sess.analyze_audio_file_samples(pos)
+            ref = app.analyze_audio_file_samples(pos)
+            for k in ("fft_ran", "mid_status", "side_status", "lufs_ran", "fed", "add_status"):
+                assert getattr(res, k) == ref[k], (channels, pos, k, getattr(res, k), ref[k])
+            if ref["fft_ran"] and ref["mid_status"] == 0:
+                assert db_close(sess.mid_fft[:, 1], app.mid_fft[:, 1], TOL_DB)
+            if ref["fft_ran"] and ref["mid_status"] != 0:
+                assert np.array_equal(sess.mid_fft, app.mid_fft)
+        sess.close()
+
+
+def test_file_session_short_file(oracle):
+    """A file shorter than one window: every tick is skipped or falls back, like the reference."""
+    from oracle.app_driver import FileApp
+    x = make_stereo(5, 9000, level=0.4)
+    sess = ssa.FileSession(x, 2, 48000)
+    app = FileApp(x, 2, 48000)
+    assert np.array_equal(sess.audio_file_chart, app.audio_file_chart)
+    for pos in (0, 2048, 16384, 18000, 32768, 32770, 40000):
+        res = sess.analyze_audio_file_samples(pos)
+        ref = app.analyze_audio_file_samples(pos)
+        check_tick(res, ref, sess, app)
+    assert np.allclose(sess.lufs, app.lufs, atol=TOL_DB)
+
+
+@pytest.mark.parametrize("rate,channels", [(48000, 2), (44100, 2), (48000, 1)])
+def test_capture_session_matches_reference_driver(oracle, rate, channels):
+    from oracle.app_driver import CaptureApp
+    sess = ssa.CaptureSession(channels, rate)
+    app = CaptureApp(channels, rate)
+    # a 30*rate-sample capture ring advancing by one callback's worth of samples per tick
+    total = make_stereo(3 + rate, 15 * rate + 8 * 4096, rate=rate, level=0.5)
+    n = 30 * rate
+    for k in range(6):
+        off = 2 * 4096 * k
+        ring = total[off:off + n]
+        res = sess.analyze_microphone_input(ring)
+        ref = app.analyze_microphone_input(ring)
+        for key in ("mid_status", "side_status", "add_status", "shortterm_status"):
+            assert getattr(res, key) == ref[key], (key, getattr(res, key), ref[key])
+        assert np.array_equal(sess.microphone_input_chart, app.microphone_input_chart)   # bit-exact
+        assert db_close(sess.mid_fft[:, 1], app.mid_fft[:, 1], TOL_DB)
+        assert db_close(sess.side_fft[:, 1], app.side_fft[:, 1], TOL_DB)
+        assert lufs_close(res.shortterm, ref["shortterm"])
+    assert np.allclose(sess.lufs, app.lufs, atol=TOL_DB)
+
+
+def test_session_argument_errors():
+    with pytest.raises(ssa.AnalyzerError):
+        ssa.CaptureSession(2, 1000)                       # 15*rate < 16384: the reference's subtraction underflows
+    sess = ssa.CaptureSession(2, 48000)
+    with pytest.raises(ssa.AnalyzerError):
+        sess.analyze_microphone_input(np.zeros(1000, np.float32))      # not the 30*rate ring

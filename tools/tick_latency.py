@@ -31,3 +31,27 @@ print("whole tick        :", f(t_all), "(budget: 8 ms TUI loop + 21 ms between t
 t0 = time.perf_counter(); w = ssa.Analyzer.get_waveform(x, 12.0); t1 = time.perf_counter()
 v = an.calculate_integrated_lufs(2, x); t2 = time.perf_counter()
 print(f"file load (12 s stereo): get_waveform {(t1 - t0) * 1e3:.2f} ms, calculate_integrated_lufs {(t2 - t1) * 1e3:.2f} ms")
+
+# the same tick as ONE call on a file session (audio resident in HBM, nothing uploaded per tick)
+t0 = time.perf_counter(); sess = ssa.FileSession(x, 2, rate); t1 = time.perf_counter()
+print(f"FileSession open (upload + waveform + integrated gain): {(t1 - t0) * 1e3:.2f} ms")
+t_sess = []
+for tick, pos in enumerate(range(16384 * 2 + 2048, x.size, 2048)):
+    t0 = time.perf_counter()
+    sess.analyze_audio_file_samples(pos)
+    t1 = time.perf_counter()
+    if tick >= 20:
+        t_sess.append(t1 - t0)
+    if tick > 300:
+        break
+print("session tick      :", f(t_sess))
+cap = ssa.CaptureSession(2, rate)
+ring = np.concatenate([x, x, x])[:30 * rate]
+t_cap = []
+for tick in range(60):
+    t0 = time.perf_counter()
+    cap.analyze_microphone_input(ring)
+    t1 = time.perf_counter()
+    if tick >= 10:
+        t_cap.append(t1 - t0)
+print("capture tick (30 s ring upload + 15 s waveform):", f(t_cap))
