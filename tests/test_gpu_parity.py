@@ -389,3 +389,32 @@ def test_large_single_feed_and_many_small_feeds_agree(oracle):
     assert lufs_close(an.get_integrated_lufs(), m.integrated())
     assert abs(an.get_loudness_range() - m.loudness_range()) <= TOL_DB
     assert lufs_close(an.get_shortterm_lufs(), m.shortterm())
+
+
+def test_ebu3341_dynamic_window_cases_on_device(oracle):
+    """EBU Tech 3341 cases 9 (short-term) and 12 (momentary) streamed through the handle in 100 ms feeds:
+    the device readings sit at -23.0 +-0.1 LU and within 0.01 of the oracle's at every step."""
+    rate = 48000
+
+    def tone(db, sec):
+        t = np.arange(int(rate * sec)) / rate
+        return 10 ** (db / 20) * np.sin(2 * np.pi * 1000 * t)
+
+    def stereo(parts):
+        s = np.concatenate([tone(d, sec) for d, sec in parts]).astype(np.float32)
+        return np.repeat(s, 2)
+
+    for parts, which, settle in (([(-20, 1.34), (-30, 1.66)] * 5, "S", 3.0), ([(-20, 0.18), (-30, 0.22)] * 25, "M", 1.0)):
+        x = stereo(parts)
+        an = ssa.Analyzer()
+        an.create_loudness_meter(2, rate)
+        m = oracle.Meter(2, rate)
+        step = rate // 10 * 2
+        for i in range(0, x.size, step):
+            an.add_samples(x[i:i + step])
+            m.add_frames(x[i:i + step])
+            got = an.get_shortterm_lufs() if which == "S" else an.get_momentary_lufs()
+            ref = m.shortterm() if which == "S" else m.momentary()
+            assert lufs_close(got, ref)
+            if (i + step) / 2 / rate >= settle:
+                assert abs(got + 23.0) <= 0.1

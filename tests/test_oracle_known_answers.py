@@ -105,6 +105,47 @@ def test_six_channel_default_map_ignores_lfe(oracle):
     assert b - a == pytest.approx(10 * np.log10(1.41), abs=1e-6)
 
 
+
+def _readings(oracle, x, rate, step_s=0.1):
+    """Feed in 100 ms slices; after each, read (t, momentary, shortterm)."""
+    m = oracle.Meter(2, rate)
+    step = int(rate * step_s) * 2
+    out = []
+    for i in range(0, x.size, step):
+        m.add_frames(x[i:i + step])
+        out.append(((i + step) / 2 / rate, m.momentary(), m.shortterm()))
+    return out
+
+
+def test_ebu3341_cases_9_and_12_dynamic_windows(oracle):
+    """Case 9: (1.34 s @ -20 dBFS, 1.66 s @ -30 dBFS) x 5 -> S = -23.0 +-0.1, constant after 3 s.
+    Case 12: (0.18 s @ -20, 0.22 s @ -30) x 25 -> M = -23.0 +-0.1, constant after 1 s.
+    (power mean check: (1.34e-2 + 1.66e-3)/3 -> -22.99 dB; (0.18e-2 + 0.22e-3)/0.4 -> -22.97 dB)"""
+    rate = 48000
+    s9 = seq(rate, [(-20, 1.34), (-30, 1.66)] * 5)
+    for t, _, st in _readings(oracle, interleave(s9, s9), rate):
+        if t >= 3.0:
+            assert st == pytest.approx(-23.0, abs=0.1), t
+    s12 = seq(rate, [(-20, 0.18), (-30, 0.22)] * 25)
+    for t, mo, _ in _readings(oracle, interleave(s12, s12), rate):
+        if t >= 1.0:
+            assert mo == pytest.approx(-23.0, abs=0.1), t
+
+
+def test_ebu3341_cases_10_and_13_burst_maxima(oracle):
+    """Case 10 / 13 shape: silence, a 3 s (S) or 0.4 s (M) tone at -23 dBFS, silence ->
+    the maximum reading is -23.0 +-0.1 and no reading exceeds it."""
+    rate = 48000
+    z = lambda sec: np.zeros(int(rate * sec))
+    for k in range(0, 20, 7):
+        x = np.concatenate([z(0.15 * k + 0.1), sine(rate, 3.0, 1000, -23.0), z(1.0)])
+        r = _readings(oracle, interleave(x, x), rate, 0.05)
+        assert max(v[2] for v in r) == pytest.approx(-23.0, abs=0.1)
+        x = np.concatenate([z(0.02 * k + 0.1), sine(rate, 0.4, 1000, -23.0), z(1.0)])
+        r = _readings(oracle, interleave(x, x), rate, 0.01)
+        assert max(v[1] for v in r) == pytest.approx(-23.0, abs=0.1)
+
+
 # ------------------------------------------------------------------ EBU Tech 3342 (LRA)
 @pytest.mark.parametrize("lo,hi,expect", [(-20, -30, 10), (-20, -15, 5), (-40, -20, 20)])
 def test_ebu3342_lra(oracle, lo, hi, expect):
