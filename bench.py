@@ -86,13 +86,21 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (soundscope_amd has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    rc = L.lib().ss_set_device(local_rank)
+    # SS_BENCH_SHARED_GPU=1 + SS_BENCH_BACKEND=gloo: launch-path check on a 1-GPU box (all ranks on device 0,
+    # collectives staged through host memory); the judged runs use one GPU per rank and RCCL
+    backend = os.environ.get("SS_BENCH_BACKEND", "nccl")
+    dev = 0 if os.environ.get("SS_BENCH_SHARED_GPU") == "1" else local_rank
+    torch.cuda.set_device(dev)
+    rc = L.lib().ss_set_device(dev)
     if rc:
         raise SystemExit("ss_set_device failed: " + L.lib().ss_last_device_error().decode())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
+    host_staged = world > 1 and backend != "nccl"
 
     frames = int(round(args.seconds * args.rate))
     total_streams = args.streams * world
@@ -105,7 +113,12 @@ def main():
     def step():
         b.run()
         b.histograms_to_device(hist.data_ptr())      # syncs the batch's stream
-        allreduce_histograms(hist)                     # RCCL over xGMI when world > 1
+        if host_staged:
+            h = hist.cpu()
+            allreduce_histograms(h)
+            hist.copy_(h)
+        else:
+            allreduce_histograms(hist)                 # RCCL over xGMI when world > 1
         if world > 1:
             torch.cuda.current_stream().synchronize()  # the next step refills `hist`: the collective must be done
 
@@ -125,7 +138,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if host_staged else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     b.sync()
