@@ -241,6 +241,30 @@ int ss_batch_histograms_device(ss_batch *b, void *dst_device_2000_u64);
 double ss_corpus_integrated_lufs(const uint64_t *block_hist1000);
 double ss_corpus_loudness_range(const uint64_t *st_hist1000);
 
+/* ------------------------------------------------------------------------- *
+ *  Render-side reductions: the step after the path.
+ *  The reference adds fft_gain_compensation_db to every bin (tui.rs:801-821) and draws inside the chart
+ *  bounds [FFT_LOWER_BOUND, FFT_UPPER_BOUND] = [-100, 0] dB (tui.rs:49-51, :890); the waveform chart shows
+ *  the view [x_min, x_max] of the decimation bins (tui.rs:664-681).  Here both are reduced on the device to
+ *  `cols` chart columns so that only what a terminal can show leaves HBM.  Gain and bounds are the
+ *  reference's; the column rule is this library's (the reference hands every point to ratatui):
+ *    spectrum column c = bins with floor(chart_x / 100 * cols) == c (last column closed), value =
+ *                        max(clamp(dB + gain, -100, 0)); a column without a bin is NaN
+ *    waveform column c = decimation bins i with floor((i - x_min) * cols / (x_max - x_min)) == c,
+ *                        value = (min of mins, max of maxes); a column without a bin is (NaN, NaN)
+ * ------------------------------------------------------------------------- */
+enum { SS_GAIN_FIXED = 0,       /* gain_db as given                                                   */
+       SS_GAIN_REFERENCE = 1 }; /* per stream FFT_TARGET_LUFS(-13) - integrated as f32 (tui.rs:1234) */
+/* after ss_batch_run: [stream][window][fft_channel][cols] f32 into a device buffer of the batch */
+int ss_batch_render_spectrum(ss_batch *b, uint32_t cols, int gain_mode, float gain_db);
+int ss_batch_download_spectrum_columns(ss_batch *b, uint32_t stream, float *out, size_t cap_floats);
+/* [stream][cols][2] f32 (min, max) of the decimation bins x_min <= i < x_max */
+int ss_batch_render_waveform(ss_batch *b, uint32_t cols, uint32_t x_min, uint32_t x_max);
+int ss_batch_download_waveform_columns(ss_batch *b, uint32_t stream, float *out, size_t cap_floats);
+/* the Player-mode view bounds of the waveform chart (tui.rs:664-681); host arithmetic, f64 */
+void ss_waveform_view(double playhead_ms, double waveform_window_s, size_t chart_points,
+                      double *x_min, double *x_max);
+
 /* kernel timing with HIP events on the batch's own stream (for roofline
  * reporting): enable, run N passes, then read accumulated per-kernel time. */
 enum { SS_KERNEL_FFT = 0, SS_KERNEL_TIME_DOMAIN = 1, SS_KERNEL_FINALIZE = 2, SS_KERNEL_WAVEFORM = 3, SS_KERNEL_COUNT = 4 };

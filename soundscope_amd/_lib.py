@@ -30,6 +30,8 @@ SYMBOLS = [
     "ss_session_open_file", "ss_session_open_capture", "ss_session_close", "ss_session_analyzer",
     "ss_session_waveform", "ss_session_gain_db", "ss_session_duration_ms", "ss_session_tick_file",
     "ss_session_tick_capture", "ss_session_restart", "ss_session_lufs_history",
+    "ss_batch_render_spectrum", "ss_batch_download_spectrum_columns", "ss_batch_render_waveform",
+    "ss_batch_download_waveform_columns", "ss_waveform_view",
 ]
 
 SS_OK = 0
@@ -39,6 +41,7 @@ SS_ERR_CAPACITY, SS_ERR_UNSUPPORTED, SS_ERR_INVALID_ARG, SS_ERR_DEVICE = 20, 21,
 
 SS_BATCH_FFT, SS_BATCH_LUFS, SS_BATCH_TRUE_PEAK, SS_BATCH_WAVEFORM, SS_BATCH_ALL = 1, 2, 4, 8, 15
 SS_PCM_U8, SS_PCM_S16, SS_PCM_S24, SS_PCM_S32, SS_PCM_F32, SS_PCM_F64 = 1, 2, 3, 4, 5, 6
+SS_GAIN_FIXED, SS_GAIN_REFERENCE = 0, 1
 SS_KERNEL_FFT, SS_KERNEL_TIME_DOMAIN, SS_KERNEL_FINALIZE, SS_KERNEL_WAVEFORM, SS_KERNEL_COUNT = 0, 1, 2, 3, 4
 
 
@@ -147,6 +150,11 @@ def _bind(lib):
                                               szp, C.POINTER(TickResult)]),
         "ss_session_restart": (C.c_int, [vp]),
         "ss_session_lufs_history": (C.c_int, [vp, f64p]),
+        "ss_batch_render_spectrum": (C.c_int, [vp, C.c_uint32, C.c_int, C.c_float]),
+        "ss_batch_download_spectrum_columns": (C.c_int, [vp, C.c_uint32, f32p, C.c_size_t]),
+        "ss_batch_render_waveform": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32]),
+        "ss_batch_download_waveform_columns": (C.c_int, [vp, C.c_uint32, f32p, C.c_size_t]),
+        "ss_waveform_view": (None, [C.c_double, C.c_double, C.c_size_t, f64p, f64p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -91,6 +91,29 @@ class Batch:
         _check(L.lib().ss_batch_download_waveform(self._h, stream, out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
         return out.reshape(-1, 2)          # [bin] -> (min, max)
 
+    # -- render-side reductions (tui.rs:49-51, :801-821, :664-681)
+    def render_spectrum(self, cols, gain_db=None):
+        """Reduce every spectrum row to `cols` chart columns on the device.  gain_db=None uses the
+        reference's per-file rule -13 - integrated (tui.rs:1234)."""
+        mode = L.SS_GAIN_REFERENCE if gain_db is None else L.SS_GAIN_FIXED
+        _check(L.lib().ss_batch_render_spectrum(self._h, cols, mode, 0.0 if gain_db is None else float(gain_db)))
+        self._render_cols = cols
+
+    def spectrum_columns(self, stream):
+        lay = self.layout
+        out = np.empty((lay.n_windows, lay.fft_channels, self._render_cols), np.float32)
+        _check(L.lib().ss_batch_download_spectrum_columns(self._h, stream, out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
+        return out
+
+    def render_waveform(self, cols, x_min, x_max):
+        _check(L.lib().ss_batch_render_waveform(self._h, cols, int(x_min), int(x_max)))
+        self._render_wave_cols = cols
+
+    def waveform_columns(self, stream):
+        out = np.empty((self._render_wave_cols, 2), np.float32)
+        _check(L.lib().ss_batch_download_waveform_columns(self._h, stream, out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
+        return out
+
     def subblocks(self, stream):
         n = self.layout.n_subblocks
         out = np.empty((n, int(self.cfg.channels)), np.float64)
@@ -122,3 +145,10 @@ def corpus_integrated_lufs(block_hist):
 def corpus_loudness_range(st_hist):
     h = np.ascontiguousarray(st_hist, dtype=np.uint64)
     return L.lib().ss_corpus_loudness_range(h.ctypes.data_as(C.POINTER(C.c_uint64)))
+
+
+def waveform_view(playhead_ms, waveform_window_s, chart_points):
+    """Player-mode x bounds of the waveform chart (tui.rs:664-681) -> (x_min, x_max)."""
+    lo, hi = C.c_double(), C.c_double()
+    L.lib().ss_waveform_view(float(playhead_ms), float(waveform_window_s), int(chart_points), C.byref(lo), C.byref(hi))
+    return lo.value, hi.value

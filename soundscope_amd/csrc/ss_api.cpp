@@ -836,6 +836,10 @@ struct ss_batch {
     DevBuf<double> sub, weights, integrated, lra, out2;
     DevBuf<uint64_t> hist, corpus;
     DevBuf<uint32_t> counts;
+    // render-side reductions (N3)
+    DevBuf<float> render_spec, render_wave;
+    DevBuf<uint32_t> col_start;
+    uint32_t render_cols = 0, render_wave_cols = 0;
     bool timing = false;
     hipEvent_t ev[2 * SS_KERNEL_COUNT];
     bool ev_ready = false;
@@ -1248,6 +1252,86 @@ int ss_batch_histograms_device(ss_batch *b, void *dst)
 
 double ss_corpus_integrated_lufs(const uint64_t *h) { return h ? sst::gated_loudness(h) : NAN; }
 double ss_corpus_loudness_range(const uint64_t *h) { return h ? sst::loudness_range(h) : NAN; }
+
+// ---- render-side reductions ---------------------------------
+int ss_batch_render_spectrum(ss_batch *b, uint32_t cols, int gain_mode, float gain_db)
+{
+    if (!b || cols == 0 || cols > 65536 || (gain_mode != SS_GAIN_FIXED && gain_mode != SS_GAIN_REFERENCE))
+        return SS_ERR_INVALID_ARG;
+    const ss_batch_layout &L = b->lay;
+    if (!(b->cfg.flags & SS_BATCH_FFT) || !L.n_windows || !L.n_bins) return SS_ERR_INVALID_MODE;
+    if (gain_mode == SS_GAIN_REFERENCE && !(b->cfg.flags & SS_BATCH_LUFS)) return SS_ERR_INVALID_MODE;
+    // column of a bin: floor(chart_x / 100 * cols), the last column closed on the right; chart_x ascends
+    std::vector<uint32_t> start(cols + 1, L.n_bins);
+    {
+        uint32_t c = 0;
+        start[0] = 0;
+        for (uint32_t i = 0; i < L.n_bins; i++) {
+            double f = std::floor(b->bt->chart_x[i] / 100.0 * (double)cols);
+            if (f < 0) f = 0;
+            uint32_t ci = f >= (double)cols ? cols - 1 : (uint32_t)f;
+            while (c < ci) start[++c] = i;
+        }
+        while (c < cols) start[++c] = L.n_bins;
+    }
+    const uint64_t rows = (uint64_t)b->cfg.n_streams * L.n_windows * L.fft_channels;
+    HIPCHK(b->col_start.ensure(cols + 1));
+    HIPCHK(hipMemcpyAsync(b->col_start.p, start.data(), (cols + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));           // `start` is a local
+    HIPCHK(b->render_spec.ensure(rows * cols));
+    b->render_cols = cols;
+    HIPCHK(ssk::launch_render_spectrum(b->fft.p, L.fft_bin_stride, L.n_bins, rows, L.n_windows * L.fft_channels,
+                                       b->col_start.p, cols,
+                                       gain_mode == SS_GAIN_REFERENCE ? b->integrated.p : nullptr, gain_db,
+                                       b->render_spec.p, b->stream));
+    return SS_OK;
+}
+
+int ss_batch_download_spectrum_columns(ss_batch *b, uint32_t stream, float *out, size_t cap)
+{
+    if (!b || !out || stream >= b->cfg.n_streams || !b->render_cols) return SS_ERR_INVALID_ARG;
+    const size_t per = (size_t)b->lay.n_windows * b->lay.fft_channels * b->render_cols;
+    if (cap < per) return SS_ERR_CAPACITY;
+    HIPCHK(hipMemcpyAsync(out, b->render_spec.p + (size_t)stream * per, per * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return SS_OK;
+}
+
+int ss_batch_render_waveform(ss_batch *b, uint32_t cols, uint32_t x_min, uint32_t x_max)
+{
+    if (!b || cols == 0 || cols > 65536 || x_max <= x_min) return SS_ERR_INVALID_ARG;
+    if (!(b->cfg.flags & SS_BATCH_WAVEFORM) || !b->wave_window) return SS_ERR_INVALID_MODE;
+    HIPCHK(b->render_wave.ensure((size_t)b->cfg.n_streams * cols * 2));
+    b->render_wave_cols = cols;
+    HIPCHK(ssk::launch_render_waveform(b->wave.p, (uint64_t)2 * b->wave_window, b->lay.n_wave_points / 2,
+                                       b->cfg.n_streams, x_min, x_max, cols, b->render_wave.p, b->stream));
+    return SS_OK;
+}
+
+int ss_batch_download_waveform_columns(ss_batch *b, uint32_t stream, float *out, size_t cap)
+{
+    if (!b || !out || stream >= b->cfg.n_streams || !b->render_wave_cols) return SS_ERR_INVALID_ARG;
+    const size_t per = (size_t)2 * b->render_wave_cols;
+    if (cap < per) return SS_ERR_CAPACITY;
+    HIPCHK(hipMemcpyAsync(out, b->render_wave.p + (size_t)stream * per, per * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return SS_OK;
+}
+
+// the waveform chart's x bounds in Player mode (tui.rs:664-681), f64 like the reference
+void ss_waveform_view(double playhead_ms, double waveform_window_s, size_t chart_points, double *x_min, double *x_max)
+{
+    const double half_window = waveform_window_s * 500.0;
+    const double max_x = (double)chart_points / 2.0;
+    double lo = playhead_ms - half_window;
+    lo = std::fmin(lo, max_x - waveform_window_s * 1000.0);
+    lo = std::fmax(lo, 0.0);
+    double hi = playhead_ms + half_window;
+    hi = std::fmin(hi, max_x);
+    hi = std::fmax(hi, waveform_window_s * 1000.0);
+    if (x_min) *x_min = lo;
+    if (x_max) *x_max = hi;
+}
 
 int ss_batch_timing_enable(ss_batch *b, int enable)
 {

@@ -128,6 +128,12 @@ hipError_t launch_waveform(const WaveParams &p, hipStream_t s);
 // ---- utilities --------------------------------------------------------------
 // raw little-endian PCM -> f32 (format: 1 u8, 2 s16, 3 s24, 4 s32, 5 f32, 6 f64)
 hipError_t launch_pcm_to_f32(const void *src, size_t n_samples, int format, float *dst, hipStream_t s);
+// render-side reductions (N3)
+hipError_t launch_render_spectrum(const float *rows, uint32_t bin_stride, uint32_t n_bins, uint64_t n_rows,
+                                  uint32_t rows_per_stream, const uint32_t *col_start, uint32_t cols,
+                                  const double *integrated, float gain_db, float *out, hipStream_t s);
+hipError_t launch_render_waveform(const float *wave, uint64_t wave_stride, uint32_t n_points, uint32_t n_streams,
+                                  uint32_t x_min, uint32_t x_max, uint32_t cols, float *out, hipStream_t s);
 hipError_t launch_mid_side(const float *interleaved, size_t frames, float *mid, float *side, hipStream_t s);
 hipError_t launch_synth(float *pcm, uint32_t n_streams, uint64_t frames, uint32_t channels,
                         uint32_t rate, uint64_t seed, uint32_t first_id, hipStream_t s);

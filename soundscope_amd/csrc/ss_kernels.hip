@@ -1635,6 +1635,86 @@ hipError_t launch_mid_side(const float *interleaved, size_t frames, float *mid, 
     return hipGetLastError();
 }
 
+// ============================================================================
+//  Render-side reductions (tui.rs:49-51, :801-821, :664-681)
+//  Spectrum: y + gain, clamped to the chart's [-100, 0] dB, reduced to chart columns on the log-x axis
+//  (column c owns the contiguous bin range [col_start[c], col_start[c+1]); value = maximum; no bin -> NaN).
+//  One wave per spectrum row: the row is staged in wave-private LDS with coalesced loads, then lane c
+//  walks its bins.  gain: fixed, or the reference's per-file rule FFT_TARGET_LUFS - integrated (f32).
+// ============================================================================
+__global__ __launch_bounds__(256) void k_render_spectrum(const float *rows, uint32_t bin_stride, uint32_t n_bins,
+                                                         uint64_t n_rows, uint32_t rows_per_stream,
+                                                         const uint32_t *col_start, uint32_t cols,
+                                                         const double *integrated, float gain_db, float *out)
+{
+    extern __shared__ float rs_lds[];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint64_t row = (uint64_t)blockIdx.x * 4 + wv;
+    if (row >= n_rows) return;
+    float *mine = rs_lds + (size_t)wv * bin_stride;
+    const float4 *src = reinterpret_cast<const float4 *>(rows + row * bin_stride);
+    for (uint32_t i = lane; i < bin_stride / 4; i += 64u) reinterpret_cast<float4 *>(mine)[i] = src[i];
+    __builtin_amdgcn_wave_barrier();
+    float gain = gain_db;
+    if (integrated) gain = -13.0f - (float)integrated[row / rows_per_stream];      // tui.rs:1234
+    float *o = out + row * cols;
+    for (uint32_t c = lane; c < cols; c += 64u) {
+        const uint32_t b0 = col_start[c], b1 = col_start[c + 1];
+        float m = __builtin_nanf("");
+        for (uint32_t b = b0; b < b1 && b < n_bins; b++) {
+            float v = mine[b] + gain;
+            v = fminf(fmaxf(v, -100.0f), 0.0f);
+            m = fmaxf(m, v);                 // maxNum: the NaN seed disappears with the first bin
+        }
+        o[c] = m;
+    }
+}
+
+hipError_t launch_render_spectrum(const float *rows, uint32_t bin_stride, uint32_t n_bins, uint64_t n_rows,
+                                  uint32_t rows_per_stream, const uint32_t *col_start, uint32_t cols,
+                                  const double *integrated, float gain_db, float *out, hipStream_t s)
+{
+    if (!n_rows || !cols) return hipSuccess;
+    const size_t lds = (size_t)4 * bin_stride * sizeof(float);
+    hipLaunchKernelGGL(k_render_spectrum, dim3((uint32_t)((n_rows + 3) / 4)), dim3(256), lds, s, rows, bin_stride,
+                       n_bins, n_rows, rows_per_stream, col_start, cols, integrated, gain_db, out);
+    return hipGetLastError();
+}
+
+// Waveform: the (min, max) decimation bins inside the view [x_min, x_max) reduced to `cols` columns:
+// column c owns bins i with floor((i - x_min) * cols / (x_max - x_min)) == c; min of mins, max of maxes
+// (f32::min / f32::max semantics like get_waveform itself).
+__global__ __launch_bounds__(256) void k_render_waveform(const float *wave, uint64_t wave_stride, uint32_t n_points,
+                                                         uint32_t n_streams, uint32_t x_min, uint32_t x_max,
+                                                         uint32_t cols, float *out)
+{
+    const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (uint64_t)n_streams * cols) return;
+    const uint32_t stream = (uint32_t)(idx / cols), c = (uint32_t)(idx % cols);
+    const uint64_t span = (uint64_t)x_max - x_min;
+    // first bin of column c: smallest i with (i - x_min) * cols >= c * span
+    const uint32_t i0 = x_min + (uint32_t)(((uint64_t)c * span + cols - 1) / cols);
+    const uint32_t i1 = x_min + (uint32_t)(((uint64_t)(c + 1) * span + cols - 1) / cols);
+    const float2 *w = reinterpret_cast<const float2 *>(wave + (uint64_t)stream * wave_stride);
+    float lo = __builtin_nanf(""), hi = __builtin_nanf("");
+    for (uint32_t i = i0; i < i1 && i < n_points; i++) {
+        const float2 v = w[i];
+        lo = fminf(lo, v.x);
+        hi = fmaxf(hi, v.y);
+    }
+    reinterpret_cast<float2 *>(out)[idx] = make_float2(lo, hi);
+}
+
+hipError_t launch_render_waveform(const float *wave, uint64_t wave_stride, uint32_t n_points, uint32_t n_streams,
+                                  uint32_t x_min, uint32_t x_max, uint32_t cols, float *out, hipStream_t s)
+{
+    if (!n_streams || !cols || x_max <= x_min) return hipSuccess;
+    const uint64_t n = (uint64_t)n_streams * cols;
+    hipLaunchKernelGGL(k_render_waveform, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, wave, wave_stride,
+                       n_points, n_streams, x_min, x_max, cols, out);
+    return hipGetLastError();
+}
+
 // PCM ingest: symphonia's sample conversions to f32 (audio_player.rs:169-267 decodes through
 // SampleBuffer::<f32>::copy_interleaved_ref).  Every scale is an exact power of two.
 __global__ __launch_bounds__(256) void k_pcm_to_f32(const unsigned char *src, size_t n, int format, float *dst)

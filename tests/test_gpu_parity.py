@@ -418,3 +418,42 @@ def test_ebu3341_dynamic_window_cases_on_device(oracle):
             assert lufs_close(got, ref)
             if (i + step) / 2 / rate >= settle:
                 assert abs(got + 23.0) <= 0.1
+
+
+# ---------------------------------------------------------------- render-side reductions (N3)
+@pytest.mark.parametrize("cols,gain", [(160, None), (77, 4.5), (4000, 0.0)])
+def test_render_reductions_match_restatement(oracle, cols, gain):
+    from oracle import render as R
+    from soundscope_amd.batch import waveform_view
+    rate, frames, ns = 48000, 48000 * 4 + 777, 3
+    xs = [make_stereo(200 + s, frames, rate=rate, level=0.2 + 0.3 * s) for s in range(ns)]
+    b = ssa.Batch(rate, 2, ns, frames, 4096, 1024, flags=L.SS_BATCH_ALL)
+    b.upload(0, np.concatenate(xs))
+    b.run()
+    b.render_spectrum(cols, gain)
+    res = b.results()
+    chart_x, _, _ = b.bin_tables()
+    for s in range(ns):
+        g = R.gain_db(res[s].integrated_lufs) if gain is None else gain
+        rows = b.fft(s)                                   # [window][mid/side][bin] f32 dB (+pink)
+        got = b.spectrum_columns(s)
+        for w in (0, rows.shape[0] // 2, rows.shape[0] - 1):
+            for ch in (0, 1):
+                want = R.spectrum_columns(np.stack([chart_x, rows[w, ch].astype(np.float64)], 1), g, cols)
+                assert np.array_equal(np.isnan(got[w, ch]), np.isnan(want))
+                ok = ~np.isnan(want)
+                assert np.abs(got[w, ch][ok] - want[ok]).max() <= 1e-3
+    # waveform: the Player-mode view around a playhead, reduced to columns; exact (min/max only)
+    wave_pts = b.layout.n_wave_points
+    for playhead_ms, window_s in ((0.0, 2.0), (2000.0, 1.5), (3900.0, 3.0)):
+        lo, hi = waveform_view(playhead_ms, window_s, wave_pts)
+        assert (lo, hi) == R.waveform_view(playhead_ms, window_s, wave_pts)
+        x_min, x_max = int(lo), int(np.ceil(hi))
+        wc = min(cols, 500)
+        b.render_waveform(wc, x_min, x_max)
+        for s in range(ns):
+            mm = b.waveform(s)
+            chart = np.stack([np.repeat(np.arange(mm.shape[0]), 2), mm.reshape(-1).astype(np.float64)], 1)
+            want = R.waveform_columns(chart, x_min, x_max, wc)
+            got = b.waveform_columns(s)
+            assert np.array_equal(got.astype(np.float64), want, equal_nan=True)
