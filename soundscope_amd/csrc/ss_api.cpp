@@ -1094,7 +1094,10 @@ int ss_batch_run(ss_batch *b)
             p.db_offset = (float)(20.0 * std::log10(4.0 / (double)c.fft_n));
             if (c.fft_n == 16384) {
                 p.tw_core = b->ft->core_tw4096; p.tw_256 = b->ft->core_tw256;
-                HIPCHK(ssk::launch_fft16k(p, b->fft_mode, b->stream));
+                if (c.hop_frames == 1024 && L.n_windows >= 8 && !std::getenv("SS_FFT16K_SINGLE"))
+                    HIPCHK(ssk::launch_fft16k_run(p, b->fft_mode, b->stream));
+                else
+                    HIPCHK(ssk::launch_fft16k(p, b->fft_mode, b->stream));
             } else {
                 HIPCHK(ssk::launch_fft_generic(p, b->fft_mode, b->stream));
             }

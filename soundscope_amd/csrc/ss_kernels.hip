@@ -614,6 +614,225 @@ __global__ __launch_bounds__(512, 2) void k_fft16k(FftBatchParams p, int midside
 #undef X2W
 }
 
+// ============================================================================
+//  Spectrum, N = 16384 at hop 1024 for batches: one REAL channel per 512-thread workgroup that walks
+//  `windows_per_block` consecutive windows with sliding sample registers (hop 1024 samples = one slot,
+//  so a sample is fetched once per run instead of 16 times) and window weights rebuilt from two
+//  resident twiddles, w[n0 + 1024 j] = 1/2 - 1/2 cos(a0 + j pi/8).
+//  Decimation in time by four:  X[b] = A0[b] + W^b A1[b] + W^2b A2[b] + W^3b A3[b],  W = W_16384,
+//  A_r = FFT_4096 of the real sequence xw[4i + r].  Half q (both are carried by every thread) transforms the complex
+//  sequence z_q[i] = (xw[4i + 2q], xw[4i + 2q + 1]) on the radix-16 passes of k_fft4096_ms1; A_{2q}, A_{2q+1}
+//  are its even / odd parts (the mid/side split of the N = 4096 kernel), combined per bin by Horner.
+//  The two halves never exchange data before the epilogue.  MODE 0: mono buffer or channel `ch` of an
+//  interleaved buffer, 1: stereo -> mid/side (audio_player.rs:400-419).
+// ============================================================================
+template <bool MIDSIDE>
+__global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_t fft_ch)
+{
+    __shared__ __attribute__((aligned(16))) v2f xbuf2[2][16 * kPlane];       // 2 x 36864 B
+    __shared__ __attribute__((aligned(16))) v2f tw2s[256];                    //  2048 B
+    __shared__ __attribute__((aligned(16))) float stage[4][256];              //  4096 B: 79872 B per workgroup, two per CU
+#define X1W(ka, tb_, ta_) ((ka) * kX1Stride + (tb_) + 16 * (ta_))
+#define X2W(kb, ka_, tb_) ((kb) * kPlane + (ka_) * kRow + (tb_))
+    const int t = threadIdx.x;
+    const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
+    uint32_t bid = blockIdx.x;
+    const uint32_t ch = bid % fft_ch; bid /= fft_ch;            // the channels of one run are neighbours: shared lines hit L2
+    const uint32_t grp = bid % groups;
+    const uint32_t stream = bid / groups;
+    const uint32_t w_begin = grp * p.windows_per_block;
+    uint32_t w_end = w_begin + p.windows_per_block;
+    if (w_end > p.n_windows) w_end = p.n_windows;
+    const uint32_t C = p.channels;
+    const float *base = p.pcm + ((size_t)stream * p.frames_per_stream + p.first_start + (size_t)w_begin * 1024u) * C;
+    const v2f *tw16k = reinterpret_cast<const v2f *>(p.tw_n);       // W_16384^k, k < 8192
+    const v2f *tw4k = reinterpret_cast<const v2f *>(p.tw_core);     // W_4096^k
+    tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[t];
+
+    // samples n .. n + 3 of this workgroup's channel (n relative to the run's first window): the two
+    // halves' complex inputs z_0 = (x[n], x[n+1]), z_1 = (x[n+2], x[n+3])
+    auto ld4 = [&](size_t n, v2f &z0, v2f &z1) {
+        if (MIDSIDE) {
+            const float2 *f = reinterpret_cast<const float2 *>(base) + n;
+            const float2 a = f[0], b = f[1], c = f[2], d = f[3];
+            if (ch == 0) { z0 = v2f{(a.x + a.y) * 0.5f, (b.x + b.y) * 0.5f}; z1 = v2f{(c.x + c.y) * 0.5f, (d.x + d.y) * 0.5f}; }
+            else { z0 = v2f{(a.x - a.y) * 0.5f, (b.x - b.y) * 0.5f}; z1 = v2f{(c.x - c.y) * 0.5f, (d.x - d.y) * 0.5f}; }
+        } else {
+            const float *f = base + n * C + ch;
+            z0 = v2f{f[0], f[C]};
+            z1 = v2f{f[2 * (size_t)C], f[3 * (size_t)C]};
+        }
+    };
+    const uint32_t n0 = 4u * (uint32_t)t;           // slot j holds samples n0 + 1024 j .. +3 of the current window
+    v2f raw0[16], raw1[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) ld4((size_t)n0 + 1024u * j, raw0[j], raw1[j]);
+    // Hann weights of slot j: angle a_e + j pi/8, a_e = 2 pi (n0 + e) / 16384, e = 0..3 (table holds (cos, -sin))
+    const v2f wa = tw16k[n0], wb = tw16k[n0 + 1], wc = tw16k[n0 + 2], wd = tw16k[n0 + 3];
+    const v2f hc0 = {-0.5f * wa.x, -0.5f * wb.x}, hs0 = {-0.5f * wa.y, -0.5f * wb.y};   // -1/2 cos a_e, +1/2 sin a_e
+    const v2f hc1 = {-0.5f * wc.x, -0.5f * wd.x}, hs1 = {-0.5f * wc.y, -0.5f * wd.y};
+    const v2f half = {0.5f, 0.5f};
+    v2f twg[16];
+    twg[1] = tw4k[t]; twg[2] = tw4k[2 * t]; twg[3] = tw4k[3 * t];
+    twg[4] = tw4k[4 * t]; twg[8] = tw4k[8 * t]; twg[12] = tw4k[12 * t];
+    const int tb = t & 15, hi = t >> 4;
+    const int tsw = SPEC_POS(t);
+    const uint32_t ngroups = (p.n_bins + 3) >> 2;
+    constexpr float kDb = 3.01029995663981195f;
+    const float off2 = p.db_offset - 6.02059991327962390f;      // the epilogue carries 2 X
+    __syncthreads();
+
+    for (uint32_t w = w_begin; w < w_end; ++w) {
+        const bool more = (w + 1 < w_end);
+        v2f nx0 = {0.0f, 0.0f}, nx1 = {0.0f, 0.0f};
+        if (more) ld4((size_t)(w + 1 - w_begin) * 1024u + n0 + 1024u * 15u, nx0, nx1);
+        // the two halves are independent problems: every barrier phase carries both (half the barriers
+        // per transform, two instruction streams to cover LDS latency)
+        v2f z0[16], z1[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            // cos(j pi/8), sin(j pi/8)
+            constexpr float cj[16] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.0f,
+                                      -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.0f,
+                                      -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f, 0.0f,
+                                      0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f};
+            constexpr float sj[16] = {0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f, 1.0f,
+                                      0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.0f,
+                                      -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.0f,
+                                      -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f};
+            // w = 1/2 - 1/2 (cos a cj - sin a sj)
+            z0[j] = raw0[j] * (half + hc0 * cj[j] + hs0 * sj[j]);
+            z1[j] = raw1[j] * (half + hc1 * cj[j] + hs1 * sj[j]);
+        }
+        fft16(z0);
+        xbuf2[0][X1W(0, tb, hi)] = z0[R16(0)];
+#pragma unroll
+        for (int ka = 1; ka < 16; ka++) {
+            v2f v = z0[R16(ka)];
+            if (ka & 3) v = pk_cmul(v, twg[ka & 3]);
+            if (ka & 12) v = pk_cmul(v, twg[ka & 12]);
+            xbuf2[0][X1W(ka, tb, hi)] = v;
+        }
+        fft16(z1);
+        xbuf2[1][X1W(0, tb, hi)] = z1[R16(0)];
+#pragma unroll
+        for (int ka = 1; ka < 16; ka++) {
+            v2f v = z1[R16(ka)];
+            if (ka & 3) v = pk_cmul(v, twg[ka & 3]);
+            if (ka & 12) v = pk_cmul(v, twg[ka & 12]);
+            xbuf2[1][X1W(ka, tb, hi)] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ta = 0; ta < 16; ta++) { z0[ta] = xbuf2[0][X1W(hi, tb, ta)]; z1[ta] = xbuf2[1][X1W(hi, tb, ta)]; }
+        __syncthreads();
+        fft16(z0);
+        xbuf2[0][X2W(0, hi, tb)] = z0[R16(0)];
+#pragma unroll
+        for (int kb = 1; kb < 16; kb++) xbuf2[0][X2W(kb, hi, tb)] = pk_cmul(z0[R16(kb)], tw2s[tb * kb]);
+        fft16(z1);
+        xbuf2[1][X2W(0, hi, tb)] = z1[R16(0)];
+#pragma unroll
+        for (int kb = 1; kb < 16; kb++) xbuf2[1][X2W(kb, hi, tb)] = pk_cmul(z1[R16(kb)], tw2s[tb * kb]);
+        __syncthreads();
+#pragma unroll
+        for (int qq = 0; qq < 16; qq++) { z0[qq] = xbuf2[0][X2W(hi, tb, qq)]; z1[qq] = xbuf2[1][X2W(hi, tb, qq)]; }
+        __syncthreads();
+        fft16(z0);
+#pragma unroll
+        for (int kc = 0; kc < 16; kc++) xbuf2[0][kc * 256 + tsw] = z0[R16(kc)];   // Z_q[k] at SPEC_POS(k)
+        fft16(z1);
+#pragma unroll
+        for (int kc = 0; kc < 16; kc++) xbuf2[1][kc * 256 + tsw] = z1[R16(kc)];
+        __syncthreads();
+
+        // ---- epilogue.  Iteration `it` covers 1024 retained bins, wave wv the 256 of them starting at
+        // 1024 it + 256 wv.  Reading: lane l takes bins +l, +64+l, +128+l, +192+l, so every LDS read of the two
+        // published spectra (and of their mirrors, descending) is stride-1 across the wave: conflict-free
+        // whatever first_bin is.  Writing: the four dB values go through a wave-private 1 KB staging row so
+        // that lane l stores bins +4l..+4l+3 with one 16-byte store.  From one iteration to the next the bin
+        // index grows by 1024: positions move by +-1024 (SPEC_POS only looks at bits 1 and 6), twiddles turn by W_16^1.
+        float *o = p.out + (((size_t)stream * p.n_windows + w) * fft_ch + ch) * p.bin_stride;
+        {
+            const uint32_t lane = (uint32_t)t & 63u, wv = (uint32_t)t >> 6;
+            float *stg = stage[wv];
+            uint32_t pb[4], pm[4];
+            v2f wt[4];
+            uint32_t fb = p.first_bin;
+            asm volatile("" : "+s"(fb));        // per-window recomputation: hoisting these 16 registers out of the loop spills
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t b = fb + 256u * wv + 64u * e + lane;
+                const uint32_t bq = b & 4095u, mq = (4096u - bq) & 4095u;
+                pb[e] = SPEC_POS(bq); pm[e] = SPEC_POS(mq);
+                wt[e] = tw16k[b & 8191u];
+            }
+            const v2f rho = {0.92387953251128674f, -0.38268343236508977f};
+            const uint32_t n_iter = (4u * ngroups + 1023u) >> 10;
+            for (uint32_t it = 0; it < n_iter; it++) {
+                float r[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const v2f e0 = xbuf2[0][pb[e]], em = xbuf2[0][pm[e]];
+                    const v2f o0 = xbuf2[1][pb[e]], om = xbuf2[1][pm[e]];
+                    v2f a0, a1, a2, a3;        // 2 A_r[b]
+                    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,0] neg_hi:[0,1]" : "=v"(a0) : "v"(e0), "v"(em));
+                    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[1,0]" : "=v"(a1) : "v"(e0), "v"(em));
+                    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,0] neg_hi:[0,1]" : "=v"(a2) : "v"(o0), "v"(om));
+                    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[1,0]" : "=v"(a3) : "v"(o0), "v"(om));
+                    v2f x = pk_cmul(a3, wt[e]) + a2;
+                    x = pk_cmul(x, wt[e]) + a1;
+                    x = pk_cmul(x, wt[e]) + a0;
+                    const float qv = fmaf(x.x, x.x, x.y * x.y);
+                    const float db = fmaf(__log2f(qv), kDb, off2);
+                    r[e] = qv == 0.0f ? -150.0f : db;
+                    pb[e] = (pb[e] + 1024u) & 4095u;
+                    pm[e] = (pm[e] - 1024u) & 4095u;
+                    wt[e] = pk_cmul(wt[e], rho);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) stg[64 * e + lane] = r[e];
+                __builtin_amdgcn_wave_barrier();                      // LDS is in order per wave: ordering is all that is needed
+                const float4 v = reinterpret_cast<const float4 *>(stg)[lane];
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t g = 256u * it + 64u * wv + lane;        // group of four bins this lane stores
+                if (g < ngroups) {
+                    float4 pk = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p.pink) pk = *reinterpret_cast<const float4 *>(p.pink + 4u * g);
+                    reinterpret_cast<float4 *>(o)[g] = make_float4(v.x + pk.x, v.y + pk.y, v.z + pk.z, v.w + pk.w);
+                }
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 15; j++) { raw0[j] = raw0[j + 1]; raw1[j] = raw1[j + 1]; }
+            raw0[15] = nx0; raw1[15] = nx1;
+        }
+        __syncthreads();                    // epilogue reads are done before the next window's pass-1 writes
+    }
+#undef X1W
+#undef X2W
+}
+
+// runs of windows at hop 1024 (batches); `mode` as launch_fft16k
+hipError_t launch_fft16k_run(FftBatchParams p, int mode, hipStream_t s)
+{
+    if (p.n_windows == 0 || p.n_streams == 0 || p.n_bins == 0) return hipSuccess;
+    const uint32_t fft_ch = (mode == 0) ? 1u : (mode == 1 ? 2u : p.channels);
+    // enough workgroups to fill 256 CUs x 2, runs of at least 16 windows (the run's first window costs a full load)
+    const uint64_t pairs = (uint64_t)p.n_streams * fft_ch;
+    uint32_t groups = (uint32_t)((4096 + pairs - 1) / pairs);
+    const uint32_t max_groups = p.n_windows / 16u ? p.n_windows / 16u : 1u;
+    if (groups > max_groups) groups = max_groups;
+    if (groups < 1) groups = 1;
+    p.windows_per_block = (p.n_windows + groups - 1) / groups;
+    groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
+    const dim3 grid((uint32_t)(pairs * groups)), block(256);
+    if (mode == 1) hipLaunchKernelGGL(k_fft16k_run<true>, grid, block, 0, s, p, fft_ch);
+    else hipLaunchKernelGGL(k_fft16k_run<false>, grid, block, 0, s, p, fft_ch);
+    return hipGetLastError();
+}
+
 hipError_t launch_fft16k(const FftBatchParams &p, int mode, hipStream_t s)
 {
     if (p.n_windows == 0 || p.n_streams == 0 || p.n_bins == 0) return hipSuccess;

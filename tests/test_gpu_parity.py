@@ -366,6 +366,18 @@ def test_batch_mono_and_reference_native_window(oracle):
     m = oracle.Meter(1, rate); m.add_frames(x)
     assert lufs_close(b.results()[0].integrated_lufs, m.integrated())
 
+    # mono at the native window: the run kernel's per-channel mode with C = 1 (40 kHz: the Nyquist bin is retained)
+    for r2 in (48000, 40000):
+        xm = make_multich(29, r2 * 2 + 313, 1, r2)
+        b = ssa.Batch(r2, 1, 1, xm.size, 16384, 1024, flags=L.SS_BATCH_FFT)
+        b.upload(0, xm)
+        b.run(); b.sync()
+        fft = b.fft(0)
+        assert b.layout.n_windows >= 8
+        for w in (0, 1, b.layout.n_windows // 2, b.layout.n_windows - 1):
+            start = (w + 1) * 1024
+            assert db_close(fft[w, 0], oracle.get_fft(r2, xm[start:start + 16384])[:, 1], TOL_DB)
+
     xs = make_stereo(23, 48000 * 10, rate)
     b = ssa.Batch(rate, 2, 1, 48000 * 10, 16384, 1024, flags=L.SS_BATCH_FFT)
     b.upload(0, xs)

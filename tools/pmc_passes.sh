@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes (one rocprofv3 run per counter group; no tracing) over tools/perf_probe.py.
-# usage: tools/pmc_passes.sh <tag> "<probe args>" "<group1 counters>" "<group2 counters>" ...
+# usage: [PROBE=tools/probe_native.py] tools/pmc_passes.sh <tag> "<probe args>" "<group1 counters>" "<group2 counters>" ...
 set -u
 tag=$1; shift
 args=$1; shift
@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "$@"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $grp -d $out/g$i -o p -- python $root/tools/perf_probe.py $args > $out/g$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $grp -d $out/g$i -o p -- python $root/${PROBE:-tools/perf_probe.py} $args > $out/g$i.log 2>&1
   db=$(find $out/g$i -name '*.db' | head -1)
   if [ -n "$db" ]; then echo "## group $i: $grp" >> $out/summary.txt; python $root/tools/rocpd_summary.py "$db" | grep -E "ssk::" | grep -v "^ *[0-9]+ +[0-9.]+ +[0-9.]+ +[0-9.]+ +[0-9.]+ +[0-9.]+ +None" >> $out/summary.txt; fi
   rm -rf $out/g$i
