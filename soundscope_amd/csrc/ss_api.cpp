@@ -257,7 +257,10 @@ int get_hist_tables(const double **energies, const double **bounds)
 bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 
 // run-in of time segments > 0 in the time-domain kernel: 0.3 s, e^-72 of the initial state survives
-constexpr uint32_t kTdWarmSub = 3;
+// run-in of a time segment that starts from a zero filter state: the slowest K-weighting pole (38 Hz
+// high-pass, |p| = 0.99502 at 48 kHz) decays by e^-23.9 per 100 ms sub-block, so after two sub-blocks what is
+// left of the unknown true state is 1.6e-21 of it — below half an ulp of the f64 state it is added to
+constexpr uint32_t kTdWarmSub = 2;
 
 int meter_args_ok(uint32_t channels, uint32_t rate)
 {
@@ -934,19 +937,6 @@ int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
         if (rc) return rc;
         const uint64_t S = b->td->host.s100;
         L.n_subblocks = (uint32_t)(F / S);
-        // time segments per stream: enough waves to fill the chip (16 per CU x 256 CUs), each at
-        // least 8 sub-blocks long so the 3-sub-block filter run-in stays a small overhead
-        {
-            const uint32_t nsub = L.n_subblocks;
-            uint32_t want = (4096u + cfg->n_streams - 1) / cfg->n_streams;
-            if (want > nsub / 8) want = nsub / 8;
-            if (want < 1) want = 1;
-            uint32_t seg_sub = want > 1 ? (nsub + want - 1) / want : 0;
-            if (want > 1 && seg_sub < kTdWarmSub) { want = 1; seg_sub = 0; }
-            b->td_nseg = want > 1 ? (nsub + seg_sub - 1) / seg_sub : 1;
-            b->td_seg_sub = seg_sub;
-            if (b->td_nseg <= 1) { b->td_nseg = 1; b->td_seg_sub = 0; }
-        }
         HIPCHK(b->state.alloc(cfg->n_streams));
         HIPCHK(b->sub.alloc((size_t)cfg->n_streams * (L.n_subblocks ? L.n_subblocks : 1) * C));
         HIPCHK(b->hist.alloc((size_t)cfg->n_streams * 2 * sst::kHistBins));
@@ -983,6 +973,34 @@ int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
             uint32_t halo = need < 24 ? 24 : need;
             halo = (halo + 3u) & ~3u;
             if (halo <= 512) { b->wave_fused = true; b->wave_halo = halo; }
+        }
+    }
+    // time segments per stream.  A segment costs a kTdWarmSub-sub-block filter run-in and the chip holds W0
+    // waves at once (LDS per wave grows with channels and halo).  Pick the segment length that maximises
+    //   useful fraction  seg / (seg + warm)  x  fill of the last round  waves / (ceil(waves / W0) W0)
+    // (ranks the measured config-5 sweep seg = 2..13 in the right order; measured within noise for config 3)
+    if (b->td) {
+        const uint32_t nsub = L.n_subblocks;
+        const double W0 = 256.0 * ssk::td_resident_waves_per_cu(C, b->td->host.s100, b->wave_fused ? b->wave_halo : 0);
+        auto score_of = [&](uint32_t seg, uint32_t nseg) {
+            const double waves = (double)cfg->n_streams * nseg;
+            const double useful = nseg > 1 ? (double)seg / (double)(seg + kTdWarmSub) : 1.0;
+            return useful * waves / (std::ceil(waves / W0) * W0);
+        };
+        uint32_t best_seg = 0;
+        double best = nsub ? score_of(nsub, 1) : 0.0;                         // one segment: no run-in
+        for (uint32_t want = 2; want <= nsub; want++) {                     // balanced segments: seg = ceil(nsub / want)
+            const uint32_t seg = (nsub + want - 1) / want;
+            if (seg < kTdWarmSub) break;
+            const double sc = score_of(seg, (nsub + seg - 1) / seg);
+            if (sc > best * 1.0000001) { best = sc; best_seg = seg; }
+        }
+        if (const char *e = std::getenv("SS_TD_SEG_SUB")) best_seg = (uint32_t)std::atoi(e);   // tuning knob
+        if (best_seg >= kTdWarmSub && best_seg < nsub) {
+            b->td_seg_sub = best_seg;
+            b->td_nseg = (nsub + best_seg - 1) / best_seg;
+        } else {
+            b->td_nseg = 1; b->td_seg_sub = 0;
         }
     }
     for (auto &e : b->ev) HIPCHK(hipEventCreate(&e));

@@ -93,6 +93,7 @@ struct TdParams {
 hipError_t launch_time_domain(const TdParams &p, hipStream_t s);
 // frames per sequential chunk for a channel count (the constant block's m_pow must match)
 uint32_t td_chunk_frames(uint32_t channels, uint32_t s100);
+uint32_t td_resident_waves_per_cu(uint32_t channels, uint32_t s100, uint32_t halo_frames);
 
 struct FinalizeParams {
     const TdConst *k;

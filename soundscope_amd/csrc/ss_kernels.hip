@@ -1516,6 +1516,25 @@ uint32_t td_chunk_frames(uint32_t C, uint32_t s100)
     return best;
 }
 
+// waves of k_time_domain one CU holds at once (LDS per wave grows with the channel count and the decimation halo)
+uint32_t td_resident_waves_per_cu(uint32_t C, uint32_t s100, uint32_t halo_frames)
+{
+    const uint32_t L = td_chunk_frames(C, s100);
+    const uint32_t cap = (64u / C) * L;
+    const uint32_t pieces = (s100 + cap - 1) / cap;
+    uint32_t tile_len = (s100 + pieces - 1) / pieces;
+    if (tile_len > cap) tile_len = cap;
+    const uint32_t halo = halo_frames ? halo_frames : (uint32_t)kTdHaloFrames;
+    uint32_t wave_floats = (halo + tile_len + kTdTailFrames) * C + kMaxChannels;
+    wave_floats = (wave_floats + 3u) & ~3u;
+    const size_t lds = (size_t)wave_floats * 4 * kTdWavesPerBlock;
+    uint32_t blocks = lds ? (uint32_t)((160u * 1024u) / lds) : 4u;
+    const uint32_t max_blocks = (4u * SS_TD_WAVES) / kTdWavesPerBlock;      // launch bound: SS_TD_WAVES waves per SIMD
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (blocks < 1) blocks = 1;
+    return blocks * kTdWavesPerBlock;
+}
+
 template <int FACTOR, bool RING, int CT, bool WAVE>
 static hipError_t td_launch(const TdParams &p, hipStream_t s)
 {
