@@ -171,7 +171,7 @@ def main():
         kernels = {}
         for k in range(L.SS_KERNEL_COUNT):
             ms, n = b.timing_read(k)
-            kernels[L.lib().ss_kernel_name(k).decode()] = round(ms / max(n, 1), 4)
+            kernels[L.lib().ss_batch_kernel_name(b._h, k).decode()] = round(ms / max(n, 1), 4)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "fft_hbm_traffic.json")
         if os.path.exists(tpath):
@@ -191,7 +191,7 @@ def main():
                        "streams_total": total_streams, "windows_per_stream": lay.n_windows, "bins": lay.n_bins,
                        "sharding": f"streams, {world} rank(s)", "corpus_integrated_lufs": corpus_i,
                        "corpus_lra": corpus_lra, "kernel_ms": kernels},
-            "roofline": {"bound": "hbm", "kernel": L.lib().ss_kernel_name(L.SS_KERNEL_FFT).decode(),
+            "roofline": {"bound": "hbm", "kernel": L.lib().ss_batch_kernel_name(b._h, L.SS_KERNEL_FFT).decode(),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes},

@@ -270,7 +270,8 @@ void ss_waveform_view(double playhead_ms, double waveform_window_s, size_t chart
 enum { SS_KERNEL_FFT = 0, SS_KERNEL_TIME_DOMAIN = 1, SS_KERNEL_FINALIZE = 2, SS_KERNEL_WAVEFORM = 3, SS_KERNEL_COUNT = 4 };
 int ss_batch_timing_enable(ss_batch *b, int enable);
 int ss_batch_timing_read(ss_batch *b, int kernel, double *total_ms, uint64_t *launches);
-const char *ss_kernel_name(int kernel);
+const char *ss_kernel_name(int kernel);            /* the bench configuration's kernels */
+const char *ss_batch_kernel_name(const ss_batch *b, int kernel);   /* the kernel this batch's shape selects */
 
 /* ------------------------------------------------------------------------- *
  *  Tick drivers: the per-file / per-device state of the

@@ -31,7 +31,7 @@ SYMBOLS = [
     "ss_session_waveform", "ss_session_gain_db", "ss_session_duration_ms", "ss_session_tick_file",
     "ss_session_tick_capture", "ss_session_restart", "ss_session_lufs_history",
     "ss_batch_render_spectrum", "ss_batch_download_spectrum_columns", "ss_batch_render_waveform",
-    "ss_batch_download_waveform_columns", "ss_waveform_view",
+    "ss_batch_download_waveform_columns", "ss_waveform_view", "ss_batch_kernel_name",
 ]
 
 SS_OK = 0
@@ -155,6 +155,7 @@ def _bind(lib):
         "ss_batch_render_waveform": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32]),
         "ss_batch_download_waveform_columns": (C.c_int, [vp, C.c_uint32, f32p, C.c_size_t]),
         "ss_waveform_view": (None, [C.c_double, C.c_double, C.c_size_t, f64p, f64p]),
+        "ss_batch_kernel_name": (C.c_char_p, [vp, C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -1374,6 +1374,19 @@ int ss_batch_timing_read(ss_batch *b, int kernel, double *total_ms, uint64_t *la
     return SS_OK;
 }
 
+// the spectrum kernel a batch of this shape launches (names as rocprofv3 prints them, without template arguments)
+const char *ss_batch_kernel_name(const ss_batch *b, int kernel)
+{
+    if (!b || kernel != SS_KERNEL_FFT) return ss_kernel_name(kernel);
+    if (b->fft_fast) {
+        const uint32_t hop = b->cfg.hop_frames;
+        return hop == 1024 ? "k_fft4096_ms1" : ((hop == 512 || hop == 2048) ? "k_fft4096_ms" : "k_fft4096_ms_anyhop");
+    }
+    if (b->cfg.fft_n == 16384)
+        return (b->cfg.hop_frames == 1024 && b->lay.n_windows >= 8) ? "k_fft16k_run" : "k_fft16k";
+    return "k_fft_generic";
+}
+
 const char *ss_kernel_name(int kernel)
 {
     switch (kernel) {

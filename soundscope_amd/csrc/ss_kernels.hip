@@ -1569,8 +1569,10 @@ static hipError_t td_launch(const TdParams &p, hipStream_t s)
 template <int FACTOR, bool RING>
 static hipError_t td_launch_c(const TdParams &p, hipStream_t s)
 {
-    if (!RING && p.wave_out)      // fused decimation is a batch feature (never together with the ring)
+    if (!RING && p.wave_out) {    // fused decimation is a batch feature (never together with the ring)
+        if (p.channels == 8) return td_launch<FACTOR, false, 8, true>(p, s);      // BASELINE config 5
         return p.channels == 2 ? td_launch<FACTOR, false, 2, true>(p, s) : td_launch<FACTOR, false, 0, true>(p, s);
+    }
     return p.channels == 2 ? td_launch<FACTOR, RING, 2, false>(p, s) : td_launch<FACTOR, RING, 0, false>(p, s);
 }
 

@@ -26,7 +26,7 @@ tot = 0.0
 for k in range(L.SS_KERNEL_COUNT):
     ms, n = b.timing_read(k)
     tot += ms / max(n, 1)
-    print(f"{L.lib().ss_kernel_name(k).decode():16s} {ms / max(n, 1):9.4f} ms")
+    print(f"{L.lib().ss_batch_kernel_name(b._h, k).decode():16s} {ms / max(n, 1):9.4f} ms")
 lay = b.layout
 alg = streams * (480000 * 2 * 4 + lay.n_windows * 2 * lay.n_bins * 4)
 fft_ms = b.timing_read(0)[0] / steps

@@ -16,7 +16,7 @@ for tp in (4, 0):
     tot = 0
     for k in range(L.SS_KERNEL_COUNT):
         ms, n = b.timing_read(k); tot += ms / max(n, 1)
-        print(f"tp={tp or 2}x {L.lib().ss_kernel_name(k).decode():16s} {ms / max(n, 1):9.3f} ms")
+        print(f"tp={tp or 2}x {L.lib().ss_batch_kernel_name(b._h, k).decode():16s} {ms / max(n, 1):9.3f} ms")
     lay = b.layout
     print(f"tp={tp or 2}x total {tot:.3f} ms -> {streams * 960000 * 8 / tot / 1e6:.2f} Gsamples/s; windows {lay.n_windows} bins {lay.n_bins}")
     b.close()
