@@ -1064,7 +1064,9 @@ constexpr int kTdBatch = 11;          // LDS reads issued together in the sequen
     u4 = b4 * v0_;
 
 // CT: compile-time channel count (0 = runtime)
-template <int FACTOR, bool RING, int CT, bool WAVE>
+// WAVE: 0 no decimation, 1 fused get_waveform (any bin geometry), 2 the same for an exact-integer samples-per-bin that is
+// a multiple of four with 16-byte aligned tiles (the host checks)
+template <int FACTOR, bool RING, int CT, int WAVE>
 __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_domain(TdParams p, uint32_t L, uint32_t tile_len,
                                                                                       uint32_t wave_lds_floats, uint32_t halo_frames)
 {
@@ -1126,6 +1128,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
     // the wave whose tile holds the bin's LAST sample; its first samples may sit in the halo.
     const uint64_t wv_len = p.n_frames * C;
     const double wv_spp = WAVE ? (double)wv_len / (double)p.wave_window : 0.0;
+    const uint32_t wv_spp_i = WAVE ? (uint32_t)wv_spp : 0u;
     uint32_t wv_cur = 0;
     if (WAVE && sg != 0) {
         const uint64_t b0 = seg_begin * C;               // first interleaved index this wave owns
@@ -1241,6 +1244,42 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
             const uint32_t t0 = (uint32_t)(pos * C), t1 = (uint32_t)((pos + seg) * C);   // tile's interleaved index range
             const uint32_t wlen = (uint32_t)wv_len;
             const uint32_t lane16 = lane & 15u;
+            // Exact-integer samples-per-bin that is a multiple of four (96 at 48 kHz stereo, W = duration in ms):
+            // floor(i spp) and ceil((i+1) spp) are the integer products themselves, bins are 16-byte aligned in the
+            // tile, so eight lanes cover a bin with 16-byte LDS reads: eight bins per iteration.
+            if (WAVE == 2) {
+                const uint32_t lane8 = lane & 7u, n4 = wv_spp_i >> 2;
+                for (;;) {
+                    const uint32_t i = wv_cur + (lane >> 3);
+                    const uint32_t bs = i * wv_spp_i, be = bs + wv_spp_i;           // be <= len: W spp == len exactly
+                    const bool valid = i < p.wave_window && be <= t1;
+                    float mn = __builtin_nanf(""), mx = __builtin_nanf("");
+                    if (valid) {
+                        const float4 *bp4 = reinterpret_cast<const float4 *>(tile + ((int)bs - (int)t0));   // may reach into the halo
+#pragma unroll
+                        for (int it = 0; it < 4; it++) {                              // spp <= 128: four clamped reads cover a bin
+                            uint32_t j = lane8 + 8u * it;
+                            j = j < n4 ? j : n4 - 1;
+                            const float4 v = bp4[j];
+                            mn = fminf(fminf(mn, v.x), fminf(fminf(v.y, v.z), v.w));
+                            mx = fmaxf(fmaxf(mx, v.x), fmaxf(fmaxf(v.y, v.z), v.w));
+                        }
+                    }
+                    // 8-lane all-reduce: xor 1, xor 2 (quad_perm), then the mirror inside each half row
+#define SS_DPP(x, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), (ctrl), 0xF, 0xF, false))
+                    mn = fminf(mn, SS_DPP(mn, 0xB1)); mx = fmaxf(mx, SS_DPP(mx, 0xB1));
+                    mn = fminf(mn, SS_DPP(mn, 0x4E)); mx = fmaxf(mx, SS_DPP(mx, 0x4E));
+                    mn = fminf(mn, SS_DPP(mn, 0x141)); mx = fmaxf(mx, SS_DPP(mx, 0x141));
+#undef SS_DPP
+                    if (valid && lane8 == 0) {
+                        float2 *o = reinterpret_cast<float2 *>(p.wave_out + (size_t)stream * p.wave_stride) + i;
+                        *o = make_float2(mn, mx);
+                    }
+                    const uint32_t nvalid = (uint32_t)__popcll(__ballot(valid && lane8 == 0));
+                    wv_cur += nvalid;
+                    if (nvalid < 8u) break;                   // the next bin ends beyond this tile
+                }
+            } else
             for (;;) {
                 const uint32_t i = wv_cur + (lane >> 4);
                 const uint32_t bs = (uint32_t)((double)i * wv_spp);
@@ -1535,7 +1574,7 @@ uint32_t td_resident_waves_per_cu(uint32_t C, uint32_t s100, uint32_t halo_frame
     return blocks * kTdWavesPerBlock;
 }
 
-template <int FACTOR, bool RING, int CT, bool WAVE>
+template <int FACTOR, bool RING, int CT, int WAVE>
 static hipError_t td_launch(const TdParams &p, hipStream_t s)
 {
     const uint32_t C = p.channels;
@@ -1566,14 +1605,32 @@ static hipError_t td_launch(const TdParams &p, hipStream_t s)
     return hipGetLastError();
 }
 
+// Decimation fast path (WAVE = 2): samples per bin spp = len / W is an exact integer multiple of four (<= 128), so
+// floor(i spp) / ceil((i+1) spp) are the integer products, and every tile starts on a multiple of four floats.
+static bool td_wave_int4(const TdParams &p)
+{
+    const uint64_t len = p.n_frames * p.channels;
+    if (!p.wave_window || len % p.wave_window) return false;
+    const uint64_t spp = len / p.wave_window;
+    if (spp < 4 || spp > 128 || (spp & 3u)) return false;
+    const uint32_t C = p.channels, S = p.s100;
+    const uint32_t L = td_chunk_frames(C, S);
+    const uint32_t cap = (64u / C) * L;
+    const uint32_t pieces = (S + cap - 1) / cap;
+    uint32_t tile_len = (S + pieces - 1) / pieces;
+    if (tile_len > cap) tile_len = cap;
+    return ((uint64_t)S * C) % 4u == 0 && ((uint64_t)tile_len * C) % 4u == 0 && (p.halo_frames * C) % 4u == 0;
+}
+
 template <int FACTOR, bool RING>
 static hipError_t td_launch_c(const TdParams &p, hipStream_t s)
 {
     if (!RING && p.wave_out) {    // fused decimation is a batch feature (never together with the ring)
-        if (p.channels == 8) return td_launch<FACTOR, false, 8, true>(p, s);      // BASELINE config 5
-        return p.channels == 2 ? td_launch<FACTOR, false, 2, true>(p, s) : td_launch<FACTOR, false, 0, true>(p, s);
+        if (p.channels == 8) return td_launch<FACTOR, false, 8, 1>(p, s);      // BASELINE config 5
+        if (p.channels == 2) return td_wave_int4(p) ? td_launch<FACTOR, false, 2, 2>(p, s) : td_launch<FACTOR, false, 2, 1>(p, s);
+        return td_launch<FACTOR, false, 0, 1>(p, s);
     }
-    return p.channels == 2 ? td_launch<FACTOR, RING, 2, false>(p, s) : td_launch<FACTOR, RING, 0, false>(p, s);
+    return p.channels == 2 ? td_launch<FACTOR, RING, 2, 0>(p, s) : td_launch<FACTOR, RING, 0, 0>(p, s);
 }
 
 hipError_t launch_time_domain(const TdParams &p, hipStream_t s)
