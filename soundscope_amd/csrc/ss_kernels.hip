@@ -1019,7 +1019,10 @@ __device__ __forceinline__ void mat4_apply_add(const double *__restrict__ M, con
 constexpr int kTdHaloFrames = 24;     // minimum halo: >= HIST-1 of the longest branch (multiple of 4: the tile stays 16-B aligned)
 constexpr int kTdTailFrames = 16;     // slack past the tile end for the last MFMA window
 constexpr int kTdWavesPerBlock = 4;
-constexpr int kTdPrefetch = 8;        // float4 per lane held in flight for the next tile
+#ifndef SS_TD_PREFETCH
+#define SS_TD_PREFETCH 8
+#endif
+constexpr int kTdPrefetch = SS_TD_PREFETCH;        // float4 per lane held in flight for the next tile
 constexpr int kTdBatch = 11;          // LDS reads issued together in the sequential passes
 
 // one K-weighting state step (DF-II, zero-based state v1..v4); the critical path is one FMA
