@@ -70,3 +70,27 @@ def test_corpus_gate_host_helpers_match_oracle(oracle):
     z = np.zeros(1000, np.uint64)
     assert ssa.corpus_integrated_lufs(z) == -np.inf
     assert ssa.corpus_loudness_range(z) == 0.0
+
+
+def build_c_client(tmp_path):
+    """gcc -std=c99 on tests/cabi/cabi_client.c against the header and the in-tree library."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "cabi_client")
+    L.lib()                                              # builds the library on demand
+    libdir = os.path.dirname(L.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cabi", "cabi_client.c"), "-o", exe,
+                           "-L", libdir, "-lsoundscope_hip", "-lm", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    return dict(kv.split("=", 1) for kv in re.findall(r'(\w+=(?:"[^"]*"|\S+))', out.stdout))
+
+
+def test_c99_client_links_and_fails_loudly_without_device(tmp_path):
+    """The header is valid C99, every symbol the client uses resolves, and without a GPU the first compute
+    entry point returns SS_ERR_DEVICE (no CPU fallback)."""
+    kv = build_c_client(tmp_path)
+    assert kv["abi"] == "1" and kv["sizeof_tick"] == "56"
+    if int(kv["devices"]) == 0:
+        assert int(kv["open"]) == L.SS_ERR_DEVICE

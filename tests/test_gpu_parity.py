@@ -469,3 +469,24 @@ def test_render_reductions_match_restatement(oracle, cols, gain):
             want = R.waveform_columns(chart, x_min, x_max, wc)
             got = b.waveform_columns(s)
             assert np.array_equal(got.astype(np.float64), want, equal_nan=True)
+
+
+def test_c99_client_runs_a_tick(oracle, tmp_path):
+    """tests/cabi/cabi_client.c (plain C, no Python in the loop): one file tick of a 997 Hz left-only sine."""
+    from test_abi import build_c_client
+    from oracle.app_driver import FileApp
+    kv = build_c_client(tmp_path)
+    assert int(kv["open"]) == 0 and int(kv["tick"]) == 0 and int(kv["fft_ran"]) == 1 and int(kv["fed"]) == 1
+    rate, frames = 48000, 96000
+    x = np.zeros(2 * frames, np.float32)
+    x[0::2] = (0.5 * np.sin(2.0 * np.pi * 997.0 * np.arange(frames) / rate)).astype(np.float32)
+    app = FileApp(x, 2, rate)
+    ref = app.analyze_audio_file_samples(2 * 60000)
+    assert int(kv["n_mid"]) == app.mid_fft.shape[0]
+    k = int(np.argmax(app.mid_fft[:, 1]))
+    assert abs(float(kv["mid_peak_db"]) - app.mid_fft[k, 1]) <= TOL_DB
+    assert abs(float(kv["mid_peak_x"]) - app.mid_fft[k, 0]) <= 1e-3
+    assert lufs_close(float(kv["shortterm"]), ref["shortterm"])
+    assert abs(float(kv["gain_db"]) - app.fft_gain_compensation_db) <= TOL_DB
+    assert rel_close(float(kv["true_peak_l"]), max(app.analyzer.meter.true_peak(0), app.analyzer.meter.sample_peak(0)), 2e-4)
+    assert float(kv["true_peak_r"]) == 0.0
