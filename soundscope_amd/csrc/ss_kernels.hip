@@ -352,6 +352,23 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
 #ifndef SS_FFT1_WAVES
 #define SS_FFT1_WAVES 3
 #endif
+// Wave priority by phase: a wave that is exchanging through LDS (writes, barrier, reads) runs at raised priority so
+// its few LDS instructions issue ahead of the other workgroups' butterflies; measured 3.15 -> 3.05 ms (A/B in one process)
+#ifndef SS_FFT_PRIO
+#define SS_FFT_PRIO 3
+#endif
+#if SS_FFT_PRIO > 0
+#define SS_PRIO_HI() __builtin_amdgcn_s_setprio(SS_FFT_PRIO)
+#define SS_PRIO_LO() __builtin_amdgcn_s_setprio(0)
+#else
+#define SS_PRIO_HI()
+#define SS_PRIO_LO()
+#endif
+#if defined(SS_FFT_PRIO_EPI)
+#define SS_PRIO_EPI() 
+#else
+#define SS_PRIO_EPI() SS_PRIO_LO()
+#endif
 template <int HS, bool TW6>
 __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchParams p)
 {
@@ -404,7 +421,9 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
         v2f z[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) z[j] = v2f{sm[j] * hw[j], df[j] * hw[j]};
+        SS_PRIO_LO();
         fft16(z);
+        SS_PRIO_HI();
         xbuf[X1W(0, tb, hi)] = z[R16(0)];
 #pragma unroll
         for (int ka = 1; ka < 16; ka++) {
@@ -421,7 +440,9 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
 #pragma unroll
         for (int ta = 0; ta < 16; ta++) z[ta] = xbuf[X1W(hi, tb, ta)];
         __syncthreads();
+        SS_PRIO_LO();
         fft16(z);
+        SS_PRIO_HI();
         xbuf[X2W(0, hi, tb)] = z[R16(0)];
 #pragma unroll
         for (int kb = 1; kb < 16; kb++) xbuf[X2W(kb, hi, tb)] = pk_cmul(z[R16(kb)], tw2s[tb * kb]);
@@ -429,11 +450,14 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
 #pragma unroll
         for (int q = 0; q < 16; q++) z[q] = xbuf[X2W(hi, tb, q)];
         __syncthreads();
+        SS_PRIO_LO();
         fft16(z);
+        SS_PRIO_HI();
 #pragma unroll
         for (int kc = 0; kc < 16; kc++)
             if ((p.publish_mask >> kc) & 1u) xbuf[kc * 256 + tsw] = z[R16(kc)];   // blocks with no retained bin or mirror are skipped
         __syncthreads();
+        SS_PRIO_EPI();
         float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
         fft4096_epilogue(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride);
         if (more) {
