@@ -490,3 +490,62 @@ def test_c99_client_runs_a_tick(oracle, tmp_path):
     assert abs(float(kv["gain_db"]) - app.fft_gain_compensation_db) <= TOL_DB
     assert rel_close(float(kv["true_peak_l"]), max(app.analyzer.meter.true_peak(0), app.analyzer.meter.sample_peak(0)), 2e-4)
     assert float(kv["true_peak_r"]) == 0.0
+
+
+def test_two_handles_and_threads_do_not_interfere(oracle):
+    """tui.rs:459-460 keeps two Analyzers side by side; INTEGRATION.md says a handle is `Send` and the library has
+    no global mutable state beyond mutex-protected constant tables.  Interleave two handles on one thread, then
+    drive four handles from four host threads at once (ctypes drops the GIL); every result must equal the oracle's."""
+    import threading
+    rates = (48000, 44100)
+    xs = [make_stereo(300 + i, r * 3, rate=r, level=0.3 + 0.2 * i) for i, r in enumerate(rates)]
+    ans = [ssa.Analyzer() for _ in rates]
+    refs = [oracle.Meter(2, r) for r in rates]
+    for an, r in zip(ans, rates):
+        an.create_loudness_meter(2, r)
+    for off in range(0, rates[1] * 3 * 2, 16384):
+        for an, m, x in zip(ans, refs, xs):
+            sl = x[off:off + 16384]
+            if sl.size:
+                an.add_samples(sl)
+                m.add_frames(sl)
+                assert lufs_close(an.get_shortterm_lufs(), m.shortterm())
+    for an, m, x, r in zip(ans, refs, xs, rates):
+        assert lufs_close(an.get_integrated_lufs(), m.integrated())
+        n = 16384
+        assert db_close(an.get_fft(x[:n])[:, 1], oracle.get_fft(r, x[:n])[:, 1], TOL_DB)
+
+    out, errs = {}, []
+
+    def worker(k):
+        try:
+            r = (48000, 44100, 96000, 32000)[k]
+            x = make_stereo(400 + k, r * 2, rate=r, level=0.5)
+            an = ssa.Analyzer()
+            an.create_loudness_meter(2, r)
+            st = []
+            for off in range(0, x.size, 9600):
+                an.add_samples(x[off:off + 9600])
+                st.append(an.get_shortterm_lufs())
+            wave = ssa.Analyzer.get_waveform(x, 2.0)
+            out[k] = (r, x, st, an.get_integrated_lufs(), an.get_true_peak(), wave)
+        except Exception as e:                      # surfaced below: exceptions in threads do not fail a test by themselves
+            errs.append((k, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for k in range(4):
+        r, x, st, integ, tp, wave = out[k]
+        m = oracle.Meter(2, r)
+        ref_st = []
+        for off in range(0, x.size, 9600):
+            m.add_frames(x[off:off + 9600])
+            ref_st.append(m.shortterm())
+        assert all(lufs_close(a, b) for a, b in zip(st, ref_st))
+        assert lufs_close(integ, m.integrated())
+        assert rel_close(tp[0], max(m.true_peak(0), m.sample_peak(0))) and rel_close(tp[1], max(m.true_peak(1), m.sample_peak(1)))
+        assert np.array_equal(wave, oracle.get_waveform(x, 2.0))
