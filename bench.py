@@ -78,7 +78,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=1024, help="streams per GPU")
+    ap.add_argument("--streams", type=int, default=1024, help="streams per GPU (weak scaling, the default)")
+    ap.add_argument("--total-streams", type=int, default=0,
+                    help="strong scaling instead: this many streams in total, sharded over the ranks "
+                         "(BASELINE config 4: 8192; fits one GPU's 288 GB)")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--rate", type=int, default=48000)
     ap.add_argument("--fft-n", type=int, default=4096)
@@ -118,7 +121,8 @@ def main():
     host_staged = world > 1 and backend != "nccl"
 
     frames = int(round(args.seconds * args.rate))
-    total_streams = args.streams * world
+    strong = args.total_streams > 0
+    total_streams = args.total_streams if strong else args.streams * world
     first, count = shard_streams(total_streams, rank, world)
     b = ssa.Batch(args.rate, 2, count, frames, args.fft_n, args.hop, flags=L.SS_BATCH_ALL)
     b.synthesize(0x5EED0000, first)
@@ -182,9 +186,9 @@ def main():
         out = {
             "metric": "audio samples/s analyzed (48 kHz stereo)", "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.streams} streams/GPU x {args.seconds:g} s, {args.rate} Hz stereo f32 "
+            "config": {"workload": f"{str(total_streams) + ' streams in total' if strong else str(args.streams) + ' streams/GPU'} x {args.seconds:g} s, {args.rate} Hz stereo f32 "
                                    f"(BASELINE config 3 per GPU; config 4 at 8 GPUs): mid/side {args.fft_n}-pt Hann FFT "
                                    f"hop {args.hop} + K-weighted gated LUFS/LRA + 4x true peak + min-max decimation "
                                    "+ corpus gate (1 all-reduce of 2x1000 u64)",
