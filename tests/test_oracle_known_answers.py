@@ -351,3 +351,48 @@ def test_streaming_equals_one_shot(oracle):
     assert a.integrated() == b.integrated() and a.shortterm() == b.shortterm()
     assert np.array_equal(a.block_hist(), b.block_hist())
     assert a.true_peak(0) == b.true_peak(0)
+
+
+# ------------------------------------------------------------------ independent BS.1770 / EBU 3342 in numpy
+def _bs1770_exact(x, rate, b, a):
+    """BS.1770-4 integrated loudness and EBU 3342 LRA written from the standards' text in numpy/scipy, exact
+    gating (no histogram): 400 ms blocks every 100 ms, -70 LUFS absolute gate, -10 LU relative gate; LRA from 3 s
+    blocks every 1 s, -70 absolute, -20 LU relative, 10th..95th percentile."""
+    s100 = (rate + 5) // 10
+    y = [signal.lfilter(b, a, x[c::2].astype(np.float64)) for c in range(2)]
+    p = y[0] ** 2 + y[1] ** 2
+    cs = np.concatenate([[0.0], np.cumsum(p)])
+    nsub = p.size // s100
+
+    def blocks(len_sub, step_sub):
+        ends = np.arange(len_sub, nsub + 1, step_sub) * s100
+        return (cs[ends] - cs[ends - len_sub * s100]) / (len_sub * s100)
+
+    lk = lambda e: -0.691 + 10 * np.log10(e)
+    e4 = blocks(4, 1)
+    e4 = e4[lk(np.maximum(e4, 1e-300)) >= -70.0]
+    rel = lk(e4.mean()) - 10.0
+    integrated = lk(e4[lk(e4) >= rel].mean())
+    e30 = blocks(30, 10)
+    e30 = e30[lk(np.maximum(e30, 1e-300)) >= -70.0]
+    e30 = np.sort(e30[lk(e30) >= lk(e30.mean()) - 20.0])
+    n = e30.size
+    lra = lk(e30[int((n - 1) * 0.95 + 0.5)]) - lk(e30[int((n - 1) * 0.10 + 0.5)])
+    return integrated, lra
+
+
+@pytest.mark.parametrize("seed,rate", [(1, 48000), (2, 44100), (3, 48000)])
+def test_integrated_and_lra_match_exact_numpy_bs1770(oracle, seed, rate):
+    """Programme-like material (level steps, a near-silent gap, two tones + noise): the oracle's histogram-mode
+    integrated loudness and LRA sit within the 0.1 LU bin width of an exact-gating numpy implementation."""
+    rng = np.random.default_rng(seed)
+    parts = []
+    for lvl in rng.uniform(0.02, 0.7, 8):
+        parts.append(make_stereo(int(rng.integers(1 << 30)), int(rate * rng.uniform(2.0, 5.0)), rate, level=float(lvl)))
+    parts.insert(4, make_stereo(9, rate * 3, rate, level=1e-4))            # below the absolute gate
+    x = np.concatenate(parts)
+    m = measure(oracle, x, 2, rate)
+    b, a = m.coeffs()
+    integ, lra = _bs1770_exact(x, rate, b, a)
+    assert m.integrated() == pytest.approx(integ, abs=0.1)
+    assert m.loudness_range() == pytest.approx(lra, abs=0.2)
