@@ -1676,14 +1676,16 @@ hipError_t launch_time_domain(const TdParams &p, hipStream_t s)
 //  Gating blocks, histograms, integrated loudness and LRA
 //  (ebur128 calc_gating_block / loudness_global / loudness_range, histogram mode)
 // ============================================================================
+// largest i with bounds[i] <= energy (the caller has checked energy >= bounds[0]) — what ebur128's binary search
+// over the bin boundaries returns.  bounds[i] is the energy of -70 + i/10 LUFS, so the index is guessed in closed
+// form and then corrected against the table itself (at most a step or two): two dependent loads instead of ten.
 __device__ __forceinline__ uint32_t hist_index(const double *__restrict__ bounds, double energy)
 {
-    uint32_t lo = 0, hi = kHistBins;
-    do {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (energy >= bounds[mid]) lo = mid; else hi = mid;
-    } while (hi - lo != 1);
-    return lo;
+    const double g = (10.0 * log10(energy) - 0.691 + 70.0) * 10.0;
+    int i = g > 0.0 ? (g < (double)(kHistBins - 1) ? (int)g : kHistBins - 1) : 0;
+    while (i > 0 && energy < bounds[i]) i--;
+    while (i < kHistBins - 1 && energy >= bounds[i + 1]) i++;
+    return (uint32_t)i;
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -1811,10 +1813,56 @@ __global__ __launch_bounds__(64) void k_finalize(FinalizeParams p)
               p.out_lra ? &p.out_lra[stream] : nullptr);
 }
 
+// Streaming form (one handle, a few new sub-blocks per call, no per-call read-out): the same gating rules
+// with the histogram updated in place by global atomics instead of a 16 KB round trip through LDS.
+__global__ __launch_bounds__(64) void k_finalize_stream(FinalizeParams p)
+{
+    const int lane = threadIdx.x;
+    unsigned long long *gh = reinterpret_cast<unsigned long long *>(p.hist);
+    const uint32_t C = p.channels;
+    const double S = (double)p.k->s100;
+    const double *P = p.subblocks;
+    uint32_t nb = 0, ns = 0;
+    for (uint64_t j = p.sub_begin + lane; j < p.sub_end; j += 64) {
+        if (j >= 3) {
+            double sum = 0.0;
+            for (uint32_t c = 0; c < C; c++) {
+                const double w = p.weights[c];
+                if (w == 0.0) continue;
+                double cs = 0.0;
+                for (int q = 3; q >= 0; q--) cs += P[(size_t)((j - q) % p.sub_cap) * C + c];
+                sum += w * cs;
+            }
+            sum /= 4.0 * S;
+            nb++;
+            if (sum >= p.hist_bounds[0]) atomicAdd(&gh[hist_index(p.hist_bounds, sum)], 1ull);
+        }
+        if (j >= 29 && (j - 29) % 10 == 0) {
+            double sum = 0.0;
+            for (uint32_t c = 0; c < C; c++) {
+                const double w = p.weights[c];
+                if (w == 0.0) continue;
+                double cs = 0.0;
+                for (int q = 29; q >= 0; q--) cs += P[(size_t)((j - q) % p.sub_cap) * C + c];
+                sum += w * cs;
+            }
+            sum /= 30.0 * S;
+            ns++;
+            if (sum >= p.hist_bounds[0]) atomicAdd(&gh[kHistBins + hist_index(p.hist_bounds, sum)], 1ull);
+        }
+    }
+    if (p.out_counts) {
+        if (nb) atomicAdd(&p.out_counts[0], nb);
+        if (ns) atomicAdd(&p.out_counts[1], ns);
+    }
+}
+
 hipError_t launch_finalize(const FinalizeParams &p, hipStream_t s)
 {
     if (p.n_streams == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_finalize, dim3(p.n_streams), dim3(64), 0, s, p);
+    const bool streaming = p.n_streams == 1 && !p.corpus_hist && !p.out_integrated && !p.out_lra && p.sub_stride == 0;
+    if (streaming) hipLaunchKernelGGL(k_finalize_stream, dim3(1), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(k_finalize, dim3(p.n_streams), dim3(64), 0, s, p);
     return hipGetLastError();
 }
 
