@@ -1455,6 +1455,7 @@ struct ss_session {
     DevBuf<float> ms;                   // capture: mid | side (n/2 each)
     DevBuf<float> spec;                 // [2][bin_stride] dB rows of a tick
     DevBuf<float> wave;                 // capture: [bins][2]
+    hipStream_t fft_stream = nullptr;   // the spectrum of a tick runs beside the loudness chain
     float *stage = nullptr;             // pinned: 2 * bin_stride floats | wave floats
     double *stage_d = nullptr;          // pinned: short-term loudness (2 doubles)
     size_t stage_floats = 0;
@@ -1511,6 +1512,7 @@ int session_common_init(ss_session *s, uint32_t meter_channels, uint32_t rate)
     s->bin_stride = (uint32_t)((s->bt->count + 3) & ~(size_t)3);
     if (s->bin_stride == 0) s->bin_stride = 4;
     HIPCHK(s->spec.alloc((size_t)2 * s->bin_stride));
+    HIPCHK(hipStreamCreateWithFlags(&s->fft_stream, hipStreamNonBlocking));
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->stage_d), 2 * sizeof(double), hipHostMallocDefault));
     return SS_OK;
 }
@@ -1526,9 +1528,8 @@ int session_stage(ss_session *s, size_t floats)
 }
 
 // enqueue the mid/side spectrum of pairs [lb, lb + 16384) of an interleaved pair buffer
-int session_enqueue_fft(ss_session *s, const float *pairs, size_t lb)
+int session_enqueue_fft(ss_session *s, const float *pairs, size_t lb, hipStream_t stream)
 {
-    ss_analyzer *h = s->an;
     ssk::FftBatchParams p{};
     p.pcm = pairs; p.out = s->spec.p;
     p.window = s->ft->window.p; p.half_window = s->ft->half_window.p;
@@ -1538,7 +1539,7 @@ int session_enqueue_fft(ss_session *s, const float *pairs, size_t lb)
     p.first_bin = (uint32_t)s->bt->first; p.n_bins = (uint32_t)s->bt->count; p.bin_stride = s->bin_stride;
     p.windows_per_block = 1;
     p.db_offset = (float)(20.0 * std::log10(4.0 / (double)SS_TICK_WINDOW));
-    HIPCHK(ssk::launch_fft16k(p, 1, h->stream));
+    HIPCHK(ssk::launch_fft16k(p, 1, stream));
     return SS_OK;
 }
 
@@ -1571,6 +1572,7 @@ extern "C" {
 void ss_session_close(ss_session *s)
 {
     if (!s) return;
+    if (s->fft_stream) { (void)hipStreamSynchronize(s->fft_stream); (void)hipStreamDestroy(s->fft_stream); }
     if (s->an) ss_analyzer_destroy(s->an);
     if (s->stage) (void)hipHostFree(s->stage);
     if (s->stage_d) (void)hipHostFree(s->stage_d);
@@ -1723,10 +1725,11 @@ int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side
             if (!mid_st) mid_st = lim;
             if (!side_st) side_st = lim;
             if ((!mid_st || !side_st) && s->bt->count) {
-                int rc = session_enqueue_fft(s, s->pcm.p, fft_lb);
+                // the file is resident and read-only: the spectrum runs on its own stream beside the loudness chain
+                int rc = session_enqueue_fft(s, s->pcm.p, fft_lb, s->fft_stream);
                 if (rc) return rc;
                 HIPCHK(hipMemcpyAsync(s->stage, s->spec.p, (size_t)2 * s->bin_stride * sizeof(float),
-                                      hipMemcpyDeviceToHost, h->stream));
+                                      hipMemcpyDeviceToHost, s->fft_stream));
                 fft_launched = true;
             }
         } else {
@@ -1754,7 +1757,8 @@ int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side
             }
         }
     }
-    if (fft_launched || st_launched || res->fed) HIPCHK(hipStreamSynchronize(h->stream));
+    if (st_launched || res->fed) HIPCHK(hipStreamSynchronize(h->stream));
+    if (fft_launched) HIPCHK(hipStreamSynchronize(s->fft_stream));
 
     if (res->fft_ran) {
         session_emit_spectrum(s, s->stage, fft_launched ? mid_st : (mid_st ? mid_st : SS_OK), mid_xy,
@@ -1797,7 +1801,7 @@ int ss_session_tick_capture(ss_session *s, const float *latest, size_t n, double
     if (!side_st) side_st = lim;
     bool fft_launched = false;
     if ((!mid_st || !side_st) && s->bt->count) {
-        int rc = session_enqueue_fft(s, s->pcm.p, lb);
+        int rc = session_enqueue_fft(s, s->pcm.p, lb, h->stream);
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(s->stage, s->spec.p, (size_t)2 * s->bin_stride * sizeof(float),
                               hipMemcpyDeviceToHost, h->stream));
