@@ -549,3 +549,38 @@ def test_two_handles_and_threads_do_not_interfere(oracle):
         assert lufs_close(integ, m.integrated())
         assert rel_close(tp[0], max(m.true_peak(0), m.sample_peak(0))) and rel_close(tp[1], max(m.true_peak(1), m.sample_peak(1)))
         assert np.array_equal(wave, oracle.get_waveform(x, 2.0))
+
+
+def test_config2_600s_single_stream(oracle):
+    """BASELINE config 2's steady-state variant: ONE 600 s 48 kHz stereo stream (57.6 M samples) as a
+    batch of one — 6000 sub-blocks cut into time segments, 28 121 windows.  Loudness, LRA, peaks against one oracle
+    meter pass; the decimation bit-exact; a sample of windows bin by bin."""
+    rate, secs = 48000, 600
+    frames = rate * secs
+    rng = np.random.default_rng(2024)
+    # level steps every 20 s so the gates and the LRA percentiles have something to do
+    x = np.concatenate([make_stereo(1000 + i, rate * 20, rate, level=float(l))
+                        for i, l in enumerate(rng.uniform(0.05, 0.8, secs // 20))])
+    assert x.size == 2 * frames
+    b = ssa.Batch(rate, 2, 1, frames, 4096, 1024)
+    b.upload(0, x)
+    b.run(); b.sync()
+    lay = b.layout
+    assert lay.n_windows == frames // 1024 - 4 and lay.n_bins == 1705
+    m = oracle.Meter(2, rate)
+    m.add_frames(x)
+    r = b.results()[0]
+    assert lufs_close(r.integrated_lufs, m.integrated())
+    assert abs(r.loudness_range - m.loudness_range()) <= TOL_DB
+    for c in range(2):
+        assert rel_close(r.true_peak[c], m.true_peak(c))
+        assert r.sample_peak[c] == m.sample_peak(c)
+    assert r.n_gating_blocks == 6000 - 3 and r.n_st_blocks == (6000 - 30) // 10 + 1
+    wave = b.waveform(0)
+    assert np.array_equal(wave.reshape(-1), oracle.get_waveform(x, float(secs))[:, 1].astype(np.float32))
+    mid, side = oracle.mid_side(x)
+    fft = b.fft(0)
+    for w in (0, 1, 17777, lay.n_windows // 2, lay.n_windows - 1):
+        start = (w + 1) * 1024
+        assert db_close(fft[w, 0], oracle.get_fft(rate, mid[start:start + 4096])[:, 1], TOL_DB)
+        assert db_close(fft[w, 1], oracle.get_fft(rate, side[start:start + 4096])[:, 1], TOL_DB)
