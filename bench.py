@@ -19,6 +19,9 @@ import time
 
 import numpy as np
 
+# the host driver only supports dmabuf IPC: RCCL across processes needs this (inherited on the GPU boxes; set if missing)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -116,6 +119,17 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            try:        # prove the communicator before the timed region; a broken RCCL setup must not cost the whole line
+                probe = torch.ones(1, dtype=torch.int64, device="cuda")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                ok = int(probe.item()) == world
+            except Exception as e:
+                print(f"[bench] rank {rank}: RCCL all-reduce failed ({e!r})", file=sys.stderr, flush=True)
+                ok = False
+            if not ok:
+                raise SystemExit("RCCL all-reduce over the node's GPUs failed; set SS_BENCH_BACKEND=gloo to stage the "
+                                 "16 kB histogram exchange through host memory instead")
         else:
             dist.init_process_group(backend)
     host_staged = world > 1 and backend != "nccl"
@@ -193,7 +207,7 @@ def main():
                                    f"hop {args.hop} + K-weighted gated LUFS/LRA + 4x true peak + min-max decimation "
                                    "+ corpus gate (1 all-reduce of 2x1000 u64)",
                        "streams_total": total_streams, "windows_per_stream": lay.n_windows, "bins": lay.n_bins,
-                       "sharding": f"streams, {world} rank(s)", "corpus_integrated_lufs": corpus_i,
+                       "sharding": f"streams, {world} rank(s)", "collective": ("none" if world == 1 else ("rccl" if not host_staged else backend + " (host staged)")), "corpus_integrated_lufs": corpus_i,
                        "corpus_lra": corpus_lra, "kernel_ms": kernels},
             "roofline": {"bound": "hbm", "kernel": L.lib().ss_batch_kernel_name(b._h, L.SS_KERNEL_FFT).decode(),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
