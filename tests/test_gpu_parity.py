@@ -584,3 +584,28 @@ def test_config2_600s_single_stream(oracle):
         start = (w + 1) * 1024
         assert db_close(fft[w, 0], oracle.get_fft(rate, mid[start:start + 4096])[:, 1], TOL_DB)
         assert db_close(fft[w, 1], oracle.get_fft(rate, side[start:start + 4096])[:, 1], TOL_DB)
+
+
+@pytest.mark.parametrize("flags", [L.SS_BATCH_FFT, L.SS_BATCH_LUFS, L.SS_BATCH_TRUE_PEAK, L.SS_BATCH_WAVEFORM,
+                                   L.SS_BATCH_FFT | L.SS_BATCH_WAVEFORM, L.SS_BATCH_LUFS | L.SS_BATCH_WAVEFORM,
+                                   L.SS_BATCH_TRUE_PEAK | L.SS_BATCH_WAVEFORM, L.SS_BATCH_LUFS | L.SS_BATCH_TRUE_PEAK])
+def test_batch_flag_subsets_agree_with_full_run(flags):
+    """Every subset of the batch's passes produces exactly what the full run produces for the parts it covers
+    (the decimation is fused into the time-domain pass only when that pass runs; alone it takes the standalone kernel)."""
+    rate, frames, ns = 48000, 48000 * 3 + 500, 3
+    xs = np.concatenate([make_stereo(60 + s, frames, rate, level=0.3 + 0.2 * s) for s in range(ns)])
+    full = ssa.Batch(rate, 2, ns, frames, 4096, 1024, flags=L.SS_BATCH_ALL)
+    full.upload(0, xs); full.run(); full.sync()
+    part = ssa.Batch(rate, 2, ns, frames, 4096, 1024, flags=flags)
+    part.upload(0, xs); part.run(); part.sync()
+    rf, rp = full.results(), part.results()
+    for s in range(ns):
+        if flags & L.SS_BATCH_FFT:
+            assert np.array_equal(part.fft(s), full.fft(s))
+        if flags & L.SS_BATCH_WAVEFORM:
+            assert np.array_equal(part.waveform(s), full.waveform(s))
+        if flags & L.SS_BATCH_LUFS:
+            assert rp[s].integrated_lufs == rf[s].integrated_lufs and rp[s].loudness_range == rf[s].loudness_range
+            assert np.array_equal(part.subblocks(s), full.subblocks(s))
+        if flags & L.SS_BATCH_TRUE_PEAK:
+            assert list(rp[s].true_peak) == list(rf[s].true_peak) and list(rp[s].sample_peak) == list(rf[s].sample_peak)
