@@ -197,6 +197,19 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # second kernel of the pass: streaming + MFMA true peak.  HBM fraction live; pipe utilisation from the committed PMC run
+        td_ms, td_n = b.timing_read(L.SS_KERNEL_TIME_DOMAIN)
+        td = {"kernel": L.lib().ss_batch_kernel_name(b._h, L.SS_KERNEL_TIME_DOMAIN).decode(),
+              "algorithmic_bytes_per_launch": count * frames * 2 * 4}
+        if td_ms > 0:
+            td["achieved_GBps"] = td["algorithmic_bytes_per_launch"] / (td_ms / max(td_n, 1) * 1e-3) / 1e9
+            td["hbm_frac"] = td["achieved_GBps"] / HBM_PEAK_GBS
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", "td_pmc.json")))["derived"]
+            td.update({"mfma_busy_frac": d["mfma_busy_frac"], "valu_busy_frac": d["valu_busy_frac"],
+                       "lds_busy_frac": d["lds_busy_frac"], "pmc_source": "profiles/td_pmc.json"})
+        except Exception:
+            pass
         out = {
             "metric": "audio samples/s analyzed (48 kHz stereo)", "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -208,7 +221,7 @@ def main():
                                    "+ corpus gate (1 all-reduce of 2x1000 u64)",
                        "streams_total": total_streams, "windows_per_stream": lay.n_windows, "bins": lay.n_bins,
                        "sharding": f"streams, {world} rank(s)", "collective": ("none" if world == 1 else ("rccl" if not host_staged else backend + " (host staged)")), "corpus_integrated_lufs": corpus_i,
-                       "corpus_lra": corpus_lra, "kernel_ms": kernels},
+                       "corpus_lra": corpus_lra, "kernel_ms": kernels, "time_domain_kernel": td},
             "roofline": {"bound": "hbm", "kernel": L.lib().ss_batch_kernel_name(b._h, L.SS_KERNEL_FFT).decode(),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
