@@ -660,8 +660,13 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
 #define X2W(kb, ka_, tb_) ((kb) * kPlane + (ka_) * kRow + (tb_))
     const int t = threadIdx.x;
     const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
-    uint32_t bid = blockIdx.x;
-    const uint32_t ch = bid % fft_ch; bid /= fft_ch;            // the channels of one run are neighbours: shared lines hit L2
+    // Workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.  The channels of one run read the
+    // same interleaved lines, so they must sit on ONE XCD: logical id = (id mod 8) * ceil(total / 8) + id / 8 makes
+    // the ids of an XCD consecutive (the launcher pads the grid to a multiple of 8; surplus ids leave).
+    const uint32_t per_xcd = gridDim.x >> 3;
+    uint32_t bid = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (bid >= p.n_streams * groups * fft_ch) return;
+    const uint32_t ch = bid % fft_ch; bid /= fft_ch;            // the channels of one run are neighbours in the logical order
     const uint32_t grp = bid % groups;
     const uint32_t stream = bid / groups;
     const uint32_t w_begin = grp * p.windows_per_block;
@@ -851,7 +856,7 @@ hipError_t launch_fft16k_run(FftBatchParams p, int mode, hipStream_t s)
     if (groups < 1) groups = 1;
     p.windows_per_block = (p.n_windows + groups - 1) / groups;
     groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
-    const dim3 grid((uint32_t)(pairs * groups)), block(256);
+    const dim3 grid((uint32_t)((pairs * groups + 7) & ~(uint64_t)7)), block(256);      // multiple of 8: see the XCD mapping in the kernel
     if (mode == 1) hipLaunchKernelGGL(k_fft16k_run<true>, grid, block, 0, s, p, fft_ch);
     else hipLaunchKernelGGL(k_fft16k_run<false>, grid, block, 0, s, p, fft_ch);
     return hipGetLastError();
