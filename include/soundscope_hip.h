@@ -283,9 +283,9 @@ const char *ss_batch_kernel_name(const ss_batch *b, int kernel);   /* the kernel
  *    ss_session_open_capture  device selection              tui.rs:1780-1808
  *    ss_session_tick_capture  analyze_microphone_input      tui.rs:1427-1480
  *    ss_session_restart       play / seek handlers          tui.rs:1586-1614
- *  A tick is ONE call, one stream, one synchronisation: nothing is uploaded for
- *  a file tick (the file was uploaded at open), the capture tick uploads the
- *  30*rate-sample capture ring.  The session owns its analyzer (file_analyzer /
+ *  A tick is ONE call: nothing is uploaded for a file tick (the file was
+ *  uploaded at open; its spectrum runs on a side stream beside the loudness
+ *  chain), the capture tick uploads the 30*rate-sample capture ring.  The session owns its analyzer (file_analyzer /
  *  device_analyzer) and the 300-entry short-term history (tui.rs:420,463).
  * ------------------------------------------------------------------------- */
 typedef struct ss_session ss_session;
