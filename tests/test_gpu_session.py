@@ -5,7 +5,6 @@ import numpy as np
 import pytest
 
 import soundscope_amd as ssa
-from soundscope_amd import _lib as L
 from conftest import db_close, make_stereo
 
 pytestmark = pytest.mark.gpu

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE config 5 probe: 96 kHz, 8 ch, N=16384 per channel, true peak 4x (forced) and 2x (ebur128 rule)."""
-import os, sys, time
-import numpy as np
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import soundscope_amd as ssa
 from soundscope_amd import _lib as L
