@@ -1028,6 +1028,8 @@ hipError_t launch_fft_generic(const FftBatchParams &p, int mode, hipStream_t s)
 //    which true_peak() maxes in anyway (analyzer.rs:159-164 -> ebur128 true_peak).
 // ============================================================================
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
+
 
 template <int FACTOR>
 struct TpCfg {
@@ -1045,6 +1047,9 @@ __device__ __forceinline__ void mat4_apply_add(const double *__restrict__ M, con
         z[r] = fma(M[r * 4 + 0], x[0], fma(M[r * 4 + 1], x[1], fma(M[r * 4 + 2], x[2], fma(M[r * 4 + 3], x[3], z[r]))));
 }
 
+#ifndef SS_TP_F16
+#define SS_TP_F16 1
+#endif
 constexpr int kTdHaloFrames = 24;     // minimum halo: >= HIST-1 of the longest branch (multiple of 4: the tile stays 16-B aligned)
 constexpr int kTdTailFrames = 16;     // slack past the tile end for the last MFMA window
 constexpr int kTdWavesPerBlock = 4;
@@ -1193,6 +1198,29 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
         }
         tp_lane_off = ((int)((uint32_t)mrow / C) * Cfg::BLK - (Cfg::HIST - 1) + kq) * (int)C + (int)tp_c;
     }
+    // f16 form of the same product (factor 4, K = 16 in ONE v_mfma_f32_16x16x16_f16): taps and samples are split
+    // into f16 pairs, c = c_hi + c_lo, 256 x = x_hi + x_lo, and hi*hi + hi*lo + lo*hi accumulate in f32 (the dropped
+    // lo*lo and the split remainders are < 1e-6 relative).  18 cycles per MFMA instead of 32 and four times the
+    // depth, and unlike the f32 MFMA it runs beside other waves' f64 VALU work (tools/ubench4.hip).
+    // Lane (mrow, kq) holds A[mrow][4 kq + j] and B[4 kq + j][mrow], j = 0..3.
+    constexpr bool kTpF16 = (FACTOR == 4) && (SS_TP_F16 != 0);
+    halfx4 a16_hi = {0, 0, 0, 0}, a16_lo = {0, 0, 0, 0};
+    int tp_lane_off16 = 0;
+    if (kTpF16) {
+        const int fph = mrow / Cfg::BLK, r = mrow - fph * Cfg::BLK;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = 4 * kq + j;
+            const int t = Cfg::HIST - 1 + r - k;
+            const float c = (mrow < Cfg::ROWS && t >= 0 && t < Cfg::HIST) ? K.tp[fph][t] : 0.0f;
+            const _Float16 ch_ = (_Float16)c;
+            a16_hi[j] = ch_;
+            a16_lo[j] = (_Float16)(c - (float)ch_);
+        }
+        tp_lane_off16 = ((int)((uint32_t)mrow / C) * Cfg::BLK - (Cfg::HIST - 1) + 4 * kq) * (int)C + (int)tp_c;
+    }
+    float tp_run16 = 0.0f;                              // running max of the f16 path, in units of 256
+    uint32_t tp_clean = carry_in ? 0u : 0x40000000u;    // frames before the current tile known to be within +-128 (a carried halo may hold anything)
     const double a1 = K.a[1], a2 = K.a[2], a3 = K.a[3], a4 = K.a[4];
     const double b0 = K.b[0], b1 = K.b[1], b2 = K.b[2], b3 = K.b[3], b4 = K.b[4];
 
@@ -1355,6 +1383,96 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
             }
         }
 
+        const bool active = lane_ok && chunk < nchunks;
+        const uint32_t len = active ? ((seg - chunk * L) < L ? (seg - chunk * L) : L) : 0u;
+        const float *xs = tile + (size_t)chunk * L * C + ch;
+        const uint32_t nb_full = L / kTdBatch;          // whole batches in a full chunk
+
+        // ---- pass 1: zero-state response of the state recurrence
+        double z[4] = {0.0, 0.0, 0.0, 0.0};
+        {
+            double v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0;
+            uint32_t i = 0;
+            if (len == L) {                             // full chunk: batched, predicate-free, look-ahead form
+                const float *xp = xs + 3 * C;           // the batch loop consumes x[i + 3]
+                SS_KW_LA_INIT((double)xs[0], (double)xs[C], (double)xs[2 * C])
+                for (uint32_t bq = 0; bq < nb_full; bq++, xp += kTdBatch * C) {
+                    float xb[kTdBatch];
+#pragma unroll
+                    for (int u = 0; u < kTdBatch; u++) xb[u] = xp[u * (int)C];   // reaches <= 3 frames past the chunk (slack)
+#pragma unroll
+                    for (int u = 0; u < kTdBatch; u++) { SS_KW_LA_STEP((double)xb[u]) SS_KW_SHIFT() }
+                }
+                i = nb_full * kTdBatch;
+                for (; i < len; i++) { SS_KW_LA_STEP((double)xs[(i + 3) * C]) SS_KW_SHIFT() }
+            }
+            for (; i < len; i++) { SS_KW_STATE((double)xs[i * C]) SS_KW_SHIFT() }
+            z[0] = v1; z[1] = v2; z[2] = v3; z[3] = v4;
+            if (active && chunk == 0) mat4_apply_add(mpow, cv, z);
+        }
+        // ---- in-wave scan over chunks: z_i += (A^L)^(2^k) z_{i - 2^k}
+        for (int kstep = 0; (1u << kstep) < nchunks; kstep++) {
+            const uint32_t d = (1u << kstep) * C;
+            const double xin[4] = {__shfl_up(z[0], d, 64), __shfl_up(z[1], d, 64), __shfl_up(z[2], d, 64), __shfl_up(z[3], d, 64)};
+            if (active && lane >= d) mat4_apply_add(mpow + 16 * kstep, xin, z);
+        }
+        // z = state after this lane's chunk (valid for full chunks); initial state = previous chunk's
+        double v1, v2, v3, v4;
+        {
+            const double p0 = __shfl_up(z[0], C, 64), p1 = __shfl_up(z[1], C, 64), p2 = __shfl_up(z[2], C, 64), p3 = __shfl_up(z[3], C, 64);
+            const bool first = chunk == 0;
+            v1 = first ? cv[0] : p0; v2 = first ? cv[1] : p1; v3 = first ? cv[2] : p2; v4 = first ? cv[3] : p3;
+        }
+
+        // ---- pass 2: true-state rerun + energy + sample peak
+        float sp = 0.0f;                                // this lane's max |x| over its chunk (also steers the true-peak path)
+        {
+            double e = 0.0;
+            uint32_t i = 0;
+            const uint64_t ring_base = fed0 + pos + (uint64_t)chunk * L;
+            if (len == L) {
+                // sample peak over x[0 .. L+2]: the three look-ahead samples are the next chunk's (or the
+                // zeroed slack behind the tile), so including them cannot change the channel's maximum
+                const float *xp = xs + 3 * C;
+                const float xa = xs[0], xb1 = xs[C], xc = xs[2 * C];
+                sp = fmaxf(fmaxf(fabsf(xa), fabsf(xb1)), fabsf(xc));
+                SS_KW_LA_INIT((double)xa, (double)xb1, (double)xc)
+                SS_KW_LA_OUT_INIT()
+                for (uint32_t bq = 0; bq < nb_full; bq++, xp += kTdBatch * C) {
+                    float xb[kTdBatch];
+#pragma unroll
+                    for (int u = 0; u < kTdBatch; u++) xb[u] = xp[u * (int)C];
+#pragma unroll
+                    for (int u = 0; u < kTdBatch; u++) {
+                        sp = fmaxf(sp, fabsf(xb[u]));
+                        SS_KW_LA_STEP((double)xb[u]) SS_KW_LA_OUT() SS_KW_SHIFT()
+                        e = fma(y_, y_, e);
+                        if (RING) p.ring[((ring_base + bq * kTdBatch + u) % p.ring_frames) * C + ch] = y_;
+                    }
+                }
+                i = nb_full * kTdBatch;
+                for (; i < len; i++) {
+                    const float xn = xs[(i + 3) * C];
+                    sp = fmaxf(sp, fabsf(xn));
+                    SS_KW_LA_STEP((double)xn) SS_KW_LA_OUT() SS_KW_SHIFT()
+                    e = fma(y_, y_, e);
+                    if (RING) p.ring[((ring_base + i) % p.ring_frames) * C + ch] = y_;
+                }
+            }
+            for (; i < len; i++) {
+                const float xf = xs[i * C];
+                sp = fmaxf(sp, fabsf(xf));
+                SS_KW_STATE((double)xf) SS_KW_OUT() SS_KW_SHIFT()
+                e = fma(y_, y_, e);
+                if (RING) p.ring[((ring_base + i) % p.ring_frames) * C + ch] = y_;
+            }
+            if (!warm) { e_run += e; sp_run = fmaxf(sp_run, sp); }
+        }
+        // the f16 true-peak product needs 256 |x| inside the f16 range: a wave-uniform test on the sample peaks of this
+        // tile and of the frames before it that the FIR window can reach
+        const bool tp_big_now = kTpF16 && (__ballot(sp > 128.0f) != 0ull);
+        const bool tp_big = tp_big_now || tp_clean < (uint32_t)(Cfg::HIST - 1);
+        tp_clean = tp_big_now ? 0u : (tp_clean + seg < 0x40000000u ? tp_clean + seg : 0x40000000u);
         // ---- true peak on the matrix pipe (not during the run-in)
         if (FACTOR != 0 && !warm) {
             const uint32_t nblk = (seg + Cfg::BLK - 1) / Cfg::BLK;     // blocks per channel
@@ -1363,8 +1481,30 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
             if (tp_fixed) {
                 constexpr int GS = 16 * Cfg::BLK;                      // floats per group (16 columns x BLK outputs)
                 const uint32_t nfull = seg / (tp_bpg * Cfg::BLK);      // groups whose every output lies inside the tile
-                const float *bp = tile + tp_lane_off;
                 uint32_t gi = 0;
+                if (kTpF16 && !tp_big) {                                // anything beyond +-128 full scale takes the f32 product below
+                    const float *bq = tile + tp_lane_off16;
+                    for (; gi + 2 <= nfull; gi += 2, bq += 2 * GS) {
+                        halfx4 h0, l0, h1, l1;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const float x0 = bq[j * (int)C] * 256.0f, x1 = bq[GS + j * (int)C] * 256.0f;
+                            const _Float16 xh0 = (_Float16)x0, xh1 = (_Float16)x1;
+                            h0[j] = xh0; l0[j] = (_Float16)(x0 - (float)xh0);      // exact remainder, then rounded to f16
+                            h1[j] = xh1; l1[j] = (_Float16)(x1 - (float)xh1);
+                        }
+                        floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_hi, h0, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_hi, h1, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_hi, l0, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_hi, l1, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_lo, h0, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_lo, h1, acc1, 0, 0, 0);
+                        tp_run16 = fmaxf(fmaxf(tp_run16, fmaxf(fabsf(acc0[0]), fabsf(acc0[1]))), fmaxf(fabsf(acc0[2]), fabsf(acc0[3])));
+                        tp_run16 = fmaxf(fmaxf(tp_run16, fmaxf(fabsf(acc1[0]), fabsf(acc1[1]))), fmaxf(fabsf(acc1[2]), fabsf(acc1[3])));
+                    }
+                }
+                const float *bp = tile + tp_lane_off + (size_t)gi * GS;
                 for (; gi + 2 <= nfull; gi += 2, bp += 2 * GS) {
                     floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                     float bv0[Cfg::KSTEPS], bv1[Cfg::KSTEPS];
@@ -1414,91 +1554,6 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
             }
         }
 
-        const bool active = lane_ok && chunk < nchunks;
-        const uint32_t len = active ? ((seg - chunk * L) < L ? (seg - chunk * L) : L) : 0u;
-        const float *xs = tile + (size_t)chunk * L * C + ch;
-        const uint32_t nb_full = L / kTdBatch;          // whole batches in a full chunk
-
-        // ---- pass 1: zero-state response of the state recurrence
-        double z[4] = {0.0, 0.0, 0.0, 0.0};
-        {
-            double v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0;
-            uint32_t i = 0;
-            if (len == L) {                             // full chunk: batched, predicate-free, look-ahead form
-                const float *xp = xs + 3 * C;           // the batch loop consumes x[i + 3]
-                SS_KW_LA_INIT((double)xs[0], (double)xs[C], (double)xs[2 * C])
-                for (uint32_t bq = 0; bq < nb_full; bq++, xp += kTdBatch * C) {
-                    float xb[kTdBatch];
-#pragma unroll
-                    for (int u = 0; u < kTdBatch; u++) xb[u] = xp[u * (int)C];   // reaches <= 3 frames past the chunk (slack)
-#pragma unroll
-                    for (int u = 0; u < kTdBatch; u++) { SS_KW_LA_STEP((double)xb[u]) SS_KW_SHIFT() }
-                }
-                i = nb_full * kTdBatch;
-                for (; i < len; i++) { SS_KW_LA_STEP((double)xs[(i + 3) * C]) SS_KW_SHIFT() }
-            }
-            for (; i < len; i++) { SS_KW_STATE((double)xs[i * C]) SS_KW_SHIFT() }
-            z[0] = v1; z[1] = v2; z[2] = v3; z[3] = v4;
-            if (active && chunk == 0) mat4_apply_add(mpow, cv, z);
-        }
-        // ---- in-wave scan over chunks: z_i += (A^L)^(2^k) z_{i - 2^k}
-        for (int kstep = 0; (1u << kstep) < nchunks; kstep++) {
-            const uint32_t d = (1u << kstep) * C;
-            const double xin[4] = {__shfl_up(z[0], d, 64), __shfl_up(z[1], d, 64), __shfl_up(z[2], d, 64), __shfl_up(z[3], d, 64)};
-            if (active && lane >= d) mat4_apply_add(mpow + 16 * kstep, xin, z);
-        }
-        // z = state after this lane's chunk (valid for full chunks); initial state = previous chunk's
-        double v1, v2, v3, v4;
-        {
-            const double p0 = __shfl_up(z[0], C, 64), p1 = __shfl_up(z[1], C, 64), p2 = __shfl_up(z[2], C, 64), p3 = __shfl_up(z[3], C, 64);
-            const bool first = chunk == 0;
-            v1 = first ? cv[0] : p0; v2 = first ? cv[1] : p1; v3 = first ? cv[2] : p2; v4 = first ? cv[3] : p3;
-        }
-
-        // ---- pass 2: true-state rerun + energy + sample peak
-        {
-            double e = 0.0;
-            float sp = 0.0f;
-            uint32_t i = 0;
-            const uint64_t ring_base = fed0 + pos + (uint64_t)chunk * L;
-            if (len == L) {
-                // sample peak over x[0 .. L+2]: the three look-ahead samples are the next chunk's (or the
-                // zeroed slack behind the tile), so including them cannot change the channel's maximum
-                const float *xp = xs + 3 * C;
-                const float xa = xs[0], xb1 = xs[C], xc = xs[2 * C];
-                sp = fmaxf(fmaxf(fabsf(xa), fabsf(xb1)), fabsf(xc));
-                SS_KW_LA_INIT((double)xa, (double)xb1, (double)xc)
-                SS_KW_LA_OUT_INIT()
-                for (uint32_t bq = 0; bq < nb_full; bq++, xp += kTdBatch * C) {
-                    float xb[kTdBatch];
-#pragma unroll
-                    for (int u = 0; u < kTdBatch; u++) xb[u] = xp[u * (int)C];
-#pragma unroll
-                    for (int u = 0; u < kTdBatch; u++) {
-                        sp = fmaxf(sp, fabsf(xb[u]));
-                        SS_KW_LA_STEP((double)xb[u]) SS_KW_LA_OUT() SS_KW_SHIFT()
-                        e = fma(y_, y_, e);
-                        if (RING) p.ring[((ring_base + bq * kTdBatch + u) % p.ring_frames) * C + ch] = y_;
-                    }
-                }
-                i = nb_full * kTdBatch;
-                for (; i < len; i++) {
-                    const float xn = xs[(i + 3) * C];
-                    sp = fmaxf(sp, fabsf(xn));
-                    SS_KW_LA_STEP((double)xn) SS_KW_LA_OUT() SS_KW_SHIFT()
-                    e = fma(y_, y_, e);
-                    if (RING) p.ring[((ring_base + i) % p.ring_frames) * C + ch] = y_;
-                }
-            }
-            for (; i < len; i++) {
-                const float xf = xs[i * C];
-                sp = fmaxf(sp, fabsf(xf));
-                SS_KW_STATE((double)xf) SS_KW_OUT() SS_KW_SHIFT()
-                e = fma(y_, y_, e);
-                if (RING) p.ring[((ring_base + i) % p.ring_frames) * C + ch] = y_;
-            }
-            if (!warm) { e_run += e; sp_run = fmaxf(sp_run, sp); }
-        }
         // carry-out: exact state after the last valid sample, broadcast to every lane of the channel
         {
             const uint32_t src_lane = (nchunks - 1) * C + ch;
@@ -1550,6 +1605,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
         const float o = __shfl_down(sp_run, d * C, 64);
         if (lane + d * C < 64u) sp_run = fmaxf(sp_run, o);
     }
+    if (kTpF16) tp_run = fmaxf(tp_run, tp_run16 * (1.0f / 256.0f));
     if (FACTOR != 0 && tp_fixed) atomicMax(&tpk[tp_c], __float_as_uint(tp_run));
     if (lane < C) {
         if (FACTOR != 0) atomicMax(reinterpret_cast<unsigned *>(&st.true_peak[lane]), tpk[lane]);

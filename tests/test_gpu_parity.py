@@ -609,3 +609,33 @@ def test_batch_flag_subsets_agree_with_full_run(flags):
             assert np.array_equal(part.subblocks(s), full.subblocks(s))
         if flags & L.SS_BATCH_TRUE_PEAK:
             assert list(rp[s].true_peak) == list(rf[s].true_peak) and list(rp[s].sample_peak) == list(rf[s].sample_peak)
+
+
+def test_true_peak_f16_path_guards(oracle):
+    """The 4x true peak runs as an f16-split matrix product (256 x = hi + lo) where that is safe and falls back to the
+    f32 product around anything beyond +-128 full scale.  Quiet streams, huge isolated samples next to tile
+    boundaries (tiles are 960 frames at 48 kHz) and uniformly huge streams all stay within 1e-4 of the oracle."""
+    rate, frames = 48000, 48000 * 3
+    base = make_stereo(77, frames, rate, level=0.5)
+    quiet = (base * np.float32(2e-4)).astype(np.float32)
+    spikes = base.copy()
+    for f, v in ((959, 5000.0), (960, -3000.0), (4800 * 3 + 1, 777.0), (96000 + 11, -129.0), (frames - 1, 4000.0)):
+        spikes[2 * f] = np.float32(v)
+    huge = (base * np.float32(400.0)).astype(np.float32)
+    xs = [quiet, spikes, huge, base]
+    b = ssa.Batch(rate, 2, len(xs), frames, 4096, 1024, flags=L.SS_BATCH_LUFS | L.SS_BATCH_TRUE_PEAK)
+    b.upload(0, np.concatenate(xs)); b.run(); b.sync()
+    res = b.results()
+    for i, x in enumerate(xs):
+        m = oracle.Meter(2, rate); m.add_frames(x)
+        for c in range(2):
+            assert rel_close(res[i].true_peak[c], m.true_peak(c)), (i, c, res[i].true_peak[c], m.true_peak(c))
+            assert res[i].sample_peak[c] == m.sample_peak(c)
+    # the streaming handle: slices of every size, the spike stream
+    an = ssa.Analyzer(); an.create_loudness_meter(2, rate)
+    m = oracle.Meter(2, rate)
+    off = 0
+    for n in (2 * 959, 2, 2 * 7, 16384, 2 * 4800, 2 * 33, 16384, 16384, 2 * 20000):
+        an.add_samples(spikes[off:off + n]); m.add_frames(spikes[off:off + n]); off += n
+        l, r = an.get_true_peak()
+        assert rel_close(l, max(m.true_peak(0), m.sample_peak(0))) and rel_close(r, max(m.true_peak(1), m.sample_peak(1)))
