@@ -6,7 +6,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define N_ITERS 4096
-// role: 0 idle, 1 mfma f32 16x16x4, 2 f64 fma x8, 3 f32 fma x8, 4 mfma f16 16x16x16, 5 mfma f16 16x16x32
+// role: 0 idle, 1 mfma f32 16x16x4, 2 f64 fma x8, 3 f32 fma x8, 4 mfma f16 16x16x16, 5 mfma f16 16x16x32, 6 mfma f64 16x16x4
 __global__ __launch_bounds__(512) void k(float *out, int roleA, int roleB, int n)
 {
     const int wave = threadIdx.x >> 6;
@@ -40,6 +40,17 @@ __global__ __launch_bounds__(512) void k(float *out, int roleA, int roleB, int n
             a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(y, x, a1, 0, 0, 0);
         }
         r = a0[0] + a1[1];
+    } else if (role == 6) {
+        typedef double doublex4 __attribute__((ext_vector_type(4)));
+        doublex4 d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
+        double x = threadIdx.x * 1e-3, y = 1.0 + x;
+        for (int i = 0; i < n; i++) {
+            d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, d1, 0, 0, 0);
+        }
+        r = (float)(d0[0] + d1[1]);
     } else if (role == 2) {
         double b0 = threadIdx.x, b1 = b0 + 1, b2 = b0 + 2, b3 = b0 + 3, b4 = b0 + 4, b5 = b0 + 5, b6 = b0 + 6, b7 = b0 + 7;
         const double c = 0.999999, d = 1e-9;
@@ -71,8 +82,8 @@ static float run(int a, int b)
 }
 int main()
 {
-    const char *nm[] = {"idle", "mfma_f32x4", "fma_f64", "fma_f32", "mfma_f16x16", "mfma_f16x32"};
-    int pairs[][2] = {{1, 0}, {4, 0}, {5, 0}, {2, 0}, {3, 0}, {4, 2}, {4, 3}, {5, 2}, {4, 4}, {1, 1}};
+    const char *nm[] = {"idle", "mfma_f32x4", "fma_f64", "fma_f32", "mfma_f16x16", "mfma_f16x32", "mfma_f64x4"};
+    int pairs[][2] = {{1, 0}, {4, 0}, {5, 0}, {6, 0}, {2, 0}, {3, 0}, {4, 2}, {4, 3}, {5, 2}, {6, 2}, {6, 3}, {6, 4}, {2, 3}, {4, 4}, {6, 6}, {1, 1}};
     for (auto &p : pairs) printf("%-11s + %-11s : %.3f ms  (%.1f ns per inner iteration)\n", nm[p[0]], nm[p[1]], run(p[0], p[1]),
                                  run(p[0], p[1]) * 1e6 / N_ITERS);
     return 0;
