@@ -843,6 +843,10 @@ struct ss_batch {
     DevBuf<float> render_spec, render_wave;
     DevBuf<uint32_t> col_start;
     uint32_t render_cols = 0, render_wave_cols = 0;
+    // opt-in (SS_BATCH_OVERLAP=1): the spectrum kernel on a second stream beside the time-domain chain
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap = false;
     bool timing = false;
     hipEvent_t ev[2 * SS_KERNEL_COUNT];
     bool ev_ready = false;
@@ -1005,6 +1009,12 @@ int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
     }
     for (auto &e : b->ev) HIPCHK(hipEventCreate(&e));
     b->ev_ready = true;
+    if (const char *e = std::getenv("SS_BATCH_OVERLAP")) b->overlap = std::atoi(e) != 0;
+    if (b->overlap) {
+        HIPCHK(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+    }
     *out = b.release();
     return SS_OK;
 }
@@ -1013,6 +1023,9 @@ void ss_batch_destroy(ss_batch *b)
 {
     if (!b) return;
     if (b->stream) { (void)hipStreamSynchronize(b->stream); }
+    if (b->stream2) { (void)hipStreamSynchronize(b->stream2); (void)hipStreamDestroy(b->stream2); }
+    if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+    if (b->ev_join) (void)hipEventDestroy(b->ev_join);
     if (b->ev_ready) for (auto &e : b->ev) (void)hipEventDestroy(e);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -1083,6 +1096,15 @@ int ss_batch_run(ss_batch *b)
     const bool tm = b->timing;
     auto rec = [&](int idx) -> hipError_t { return tm ? hipEventRecord(b->ev[idx], b->stream) : hipSuccess; };
 
+    // overlap mode: fork — the spectrum kernel goes to stream2 after everything already queued on the main stream
+    // (uploads, the previous pass), the time-domain chain stays on the main stream, join at the end.  Per-kernel
+    // event timing is meaningless while two kernels share the chip, so timing passes stay sequential.
+    const bool ov = b->overlap && !tm;
+    hipStream_t fft_stream = ov ? b->stream2 : b->stream;
+    if (ov) {
+        HIPCHK(hipEventRecord(b->ev_fork, b->stream));
+        HIPCHK(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
+    }
     HIPCHK(rec(2 * SS_KERNEL_FFT));
     if ((c.flags & SS_BATCH_FFT) && L.n_windows) {
         ssk::FftBatchParams p{};
@@ -1107,17 +1129,17 @@ int ss_batch_run(ss_batch *b)
                 }
                 p.publish_mask = mask;
             }
-            HIPCHK(ssk::launch_fft4096_ms(p, b->stream));
+            HIPCHK(ssk::launch_fft4096_ms(p, fft_stream));
         } else {
             p.db_offset = (float)(20.0 * std::log10(4.0 / (double)c.fft_n));
             if (c.fft_n == 16384) {
                 p.tw_core = b->ft->core_tw4096; p.tw_256 = b->ft->core_tw256;
                 if (c.hop_frames == 1024 && L.n_windows >= 8 && !std::getenv("SS_FFT16K_SINGLE"))
-                    HIPCHK(ssk::launch_fft16k_run(p, b->fft_mode, b->stream));
+                    HIPCHK(ssk::launch_fft16k_run(p, b->fft_mode, fft_stream));
                 else
-                    HIPCHK(ssk::launch_fft16k(p, b->fft_mode, b->stream));
+                    HIPCHK(ssk::launch_fft16k(p, b->fft_mode, fft_stream));
             } else {
-                HIPCHK(ssk::launch_fft_generic(p, b->fft_mode, b->stream));
+                HIPCHK(ssk::launch_fft_generic(p, b->fft_mode, fft_stream));
             }
         }
     }
@@ -1166,6 +1188,10 @@ int ss_batch_run(ss_batch *b)
         HIPCHK(ssk::launch_waveform(p, b->stream));
     }
     HIPCHK(rec(2 * SS_KERNEL_WAVEFORM + 1));
+    if (ov) {                                  // join: later work on the main stream (downloads, the next pass) sees the spectrum
+        HIPCHK(hipEventRecord(b->ev_join, b->stream2));
+        HIPCHK(hipStreamWaitEvent(b->stream, b->ev_join, 0));
+    }
     b->pending_events = tm;
     return SS_OK;
 }
