@@ -1102,7 +1102,7 @@ constexpr int kTdBatch = 11;          // LDS reads issued together in the sequen
 
 // CT: compile-time channel count (0 = runtime)
 // WAVE: 0 no decimation, 1 fused get_waveform (any bin geometry), 2 the same for an exact-integer samples-per-bin that is
-// a multiple of four with 16-byte aligned tiles (the host checks)
+// a multiple of four (<= 128) with 16-byte aligned tiles (the host checks), 3 the same for 128 < spp <= 1000
 template <int FACTOR, bool RING, int CT, int WAVE>
 __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_domain(TdParams p, uint32_t L, uint32_t tile_len,
                                                                                       uint32_t wave_lds_floats, uint32_t halo_frames)
@@ -1307,7 +1307,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
             // Exact-integer samples-per-bin that is a multiple of four (96 at 48 kHz stereo, W = duration in ms):
             // floor(i spp) and ceil((i+1) spp) are the integer products themselves, bins are 16-byte aligned in the
             // tile, so eight lanes cover a bin with 16-byte LDS reads: eight bins per iteration.
-            if (WAVE == 2) {
+            if (WAVE >= 2) {
                 const uint32_t lane8 = lane & 7u, n4 = wv_spp_i >> 2;
                 for (;;) {
                     const uint32_t i = wv_cur + (lane >> 3);
@@ -1324,6 +1324,12 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
                             mn = fminf(fminf(mn, v.x), fminf(fminf(v.y, v.z), v.w));
                             mx = fmaxf(fmaxf(mx, v.x), fmaxf(fmaxf(v.y, v.z), v.w));
                         }
+                        if (WAVE == 3)                                                 // longer bins (192 at 96 kHz stereo)
+                            for (uint32_t j = lane8 + 32u; j < n4; j += 8u) {
+                                const float4 v = bp4[j];
+                                mn = fminf(fminf(mn, v.x), fminf(fminf(v.y, v.z), v.w));
+                                mx = fmaxf(fmaxf(mx, v.x), fmaxf(fmaxf(v.y, v.z), v.w));
+                            }
                     }
                     // 8-lane all-reduce: xor 1, xor 2 (quad_perm), then the mirror inside each half row
 #define SS_DPP(x, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), (ctrl), 0xF, 0xF, false))
@@ -1695,19 +1701,20 @@ static hipError_t td_launch(const TdParams &p, hipStream_t s)
 
 // Decimation fast path (WAVE = 2): samples per bin spp = len / W is an exact integer multiple of four (<= 128), so
 // floor(i spp) / ceil((i+1) spp) are the integer products, and every tile starts on a multiple of four floats.
-static bool td_wave_int4(const TdParams &p)
+static int td_wave_int4(const TdParams &p)
 {
     const uint64_t len = p.n_frames * p.channels;
-    if (!p.wave_window || len % p.wave_window) return false;
+    if (!p.wave_window || len % p.wave_window) return 0;
     const uint64_t spp = len / p.wave_window;
-    if (spp < 4 || spp > 128 || (spp & 3u)) return false;
+    if (spp < 4 || spp > 1000 || (spp & 3u)) return 0;         // the fused path itself stops at 1000 samples per bin
     const uint32_t C = p.channels, S = p.s100;
     const uint32_t L = td_chunk_frames(C, S);
     const uint32_t cap = (64u / C) * L;
     const uint32_t pieces = (S + cap - 1) / cap;
     uint32_t tile_len = (S + pieces - 1) / pieces;
     if (tile_len > cap) tile_len = cap;
-    return ((uint64_t)S * C) % 4u == 0 && ((uint64_t)tile_len * C) % 4u == 0 && (p.halo_frames * C) % 4u == 0;
+    if (!(((uint64_t)S * C) % 4u == 0 && ((uint64_t)tile_len * C) % 4u == 0 && (p.halo_frames * C) % 4u == 0)) return 0;
+    return spp <= 128 ? 2 : 3;
 }
 
 template <int FACTOR, bool RING>
@@ -1715,7 +1722,12 @@ static hipError_t td_launch_c(const TdParams &p, hipStream_t s)
 {
     if (!RING && p.wave_out) {    // fused decimation is a batch feature (never together with the ring)
         if (p.channels == 8) return td_launch<FACTOR, false, 8, 1>(p, s);      // BASELINE config 5
-        if (p.channels == 2) return td_wave_int4(p) ? td_launch<FACTOR, false, 2, 2>(p, s) : td_launch<FACTOR, false, 2, 1>(p, s);
+        if (p.channels == 2) {
+            const int fast = td_wave_int4(p);
+            if (fast == 2) return td_launch<FACTOR, false, 2, 2>(p, s);
+            if (fast == 3) return td_launch<FACTOR, false, 2, 3>(p, s);
+            return td_launch<FACTOR, false, 2, 1>(p, s);
+        }
         return td_launch<FACTOR, false, 0, 1>(p, s);
     }
     return p.channels == 2 ? td_launch<FACTOR, RING, 2, 0>(p, s) : td_launch<FACTOR, RING, 0, 0>(p, s);

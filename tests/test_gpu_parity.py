@@ -639,3 +639,14 @@ def test_true_peak_f16_path_guards(oracle):
         an.add_samples(spikes[off:off + n]); m.add_frames(spikes[off:off + n]); off += n
         l, r = an.get_true_peak()
         assert rel_close(l, max(m.true_peak(0), m.sample_peak(0))) and rel_close(r, max(m.true_peak(1), m.sample_peak(1)))
+
+
+def test_batch_96k_stereo_long_integer_bins(oracle):
+    """96 kHz stereo, whole seconds: 192 interleaved samples per decimation bin — the integer-bin fast path beyond
+    128 samples (WAVE = 3), with the reference rule's 2x true peak."""
+    rate, frames = 96000, 96000 * 2
+    xs = [make_stereo(500 + i, frames, rate, level=0.4) for i in range(2)]
+    b = ssa.Batch(rate, 2, 2, frames, 4096, 1024)
+    b.upload(0, np.concatenate(xs))
+    b.run(); b.sync()
+    _check_batch_against_oracle(oracle, b, xs, rate, 4096, 1024)
