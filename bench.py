@@ -213,7 +213,7 @@ def main():
         out = {
             "metric": "audio samples/s analyzed (48 kHz stereo)", "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32+f64",
             "data": "synthetic",
             "config": {"workload": f"{str(total_streams) + ' streams in total' if strong else str(args.streams) + ' streams/GPU'} x {args.seconds:g} s, {args.rate} Hz stereo f32 "
                                    f"(BASELINE config 3 per GPU; config 4 at 8 GPUs): mid/side {args.fft_n}-pt Hann FFT "
