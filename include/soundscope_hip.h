@@ -210,6 +210,13 @@ int ss_batch_download_input(ss_batch *b, uint32_t stream, float *pcm, size_t cap
 /* same as ss_batch_upload for raw PCM of `format`: the bytes are copied to the GPU and converted
  * there straight into the resident f32 corpus (no host-side f32 copy) */
 int ss_batch_upload_pcm(ss_batch *b, uint32_t first, uint32_t count, const void *pcm, int format);
+/* Pipelined ingest.  A batch owns its HIP stream, so two batches are a double buffer: while one runs, the other's
+ * upload is in flight — provided the host memory is page-locked (ss_host_register pins caller memory in place) and
+ * the upload does not wait: ss_batch_upload_pcm_async only queues the copy and the conversion; `pcm` must stay
+ * valid until the next ss_batch_sync / ss_batch_results on that batch.  soundscope_amd/pipeline.py is the loop. */
+int ss_host_register(void *ptr, size_t bytes);
+int ss_host_unregister(void *ptr);
+int ss_batch_upload_pcm_async(ss_batch *b, uint32_t first, uint32_t count, const void *pcm, int format);
 /* device pointer of the resident corpus ([stream][frame][channel] f32) for
  * producers that already hold data on the GPU */
 void *ss_batch_input_device_ptr(ss_batch *b);

@@ -32,6 +32,7 @@ SYMBOLS = [
     "ss_session_tick_capture", "ss_session_restart", "ss_session_lufs_history",
     "ss_batch_render_spectrum", "ss_batch_download_spectrum_columns", "ss_batch_render_waveform",
     "ss_batch_download_waveform_columns", "ss_waveform_view", "ss_batch_kernel_name",
+    "ss_host_register", "ss_host_unregister", "ss_batch_upload_pcm_async",
 ]
 
 SS_OK = 0
@@ -156,6 +157,9 @@ def _bind(lib):
         "ss_batch_download_waveform_columns": (C.c_int, [vp, C.c_uint32, f32p, C.c_size_t]),
         "ss_waveform_view": (None, [C.c_double, C.c_double, C.c_size_t, f64p, f64p]),
         "ss_batch_kernel_name": (C.c_char_p, [vp, C.c_int]),
+        "ss_host_register": (C.c_int, [vp, C.c_size_t]),
+        "ss_host_unregister": (C.c_int, [vp]),
+        "ss_batch_upload_pcm_async": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

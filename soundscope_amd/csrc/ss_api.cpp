@@ -839,6 +839,7 @@ struct ss_batch {
     DevBuf<double> sub, weights, integrated, lra, out2;
     DevBuf<uint64_t> hist, corpus;
     DevBuf<uint32_t> counts;
+    DevBuf<unsigned char> raw;      // device staging of raw PCM for the asynchronous ingest
     // render-side reductions (N3)
     DevBuf<float> render_spec, render_wave;
     DevBuf<uint32_t> col_start;
@@ -1061,6 +1062,49 @@ int ss_batch_upload_pcm(ss_batch *b, uint32_t first, uint32_t count, const void 
     HIPCHK(hipMemcpyAsync(raw.p, pcm, n * sb, hipMemcpyHostToDevice, b->stream));
     HIPCHK(ssk::launch_pcm_to_f32(raw.p, n, format, b->pcm.p + (size_t)first * per, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
+    return SS_OK;
+}
+
+// ---- pipelined ingest: page-locked host memory + uploads that do not wait -------------------------------------
+// A batch owns its stream, so two batches are a double buffer: while one runs, the other's upload is in flight
+// on the copy engine.  That only holds for page-locked host memory (pageable copies are staged synchronously).
+int ss_host_register(void *ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return SS_ERR_INVALID_ARG;
+    if (require_device()) return SS_ERR_DEVICE;
+    HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return SS_OK;
+}
+
+int ss_host_unregister(void *ptr)
+{
+    if (!ptr) return SS_ERR_INVALID_ARG;
+    HIPCHK(hipHostUnregister(ptr));
+    return SS_OK;
+}
+
+// like ss_batch_upload_pcm, but returns as soon as the copy and the conversion are queued on the batch's stream:
+// `pcm` must stay valid (and should be page-locked) until the next ss_batch_sync / ss_batch_results on this batch
+int ss_batch_upload_pcm_async(ss_batch *b, uint32_t first, uint32_t count, const void *pcm, int format)
+{
+    const size_t sb = ss_pcm_sample_bytes(format);
+    if (!b || !pcm || !sb) return SS_ERR_INVALID_ARG;
+    if ((uint64_t)first + count > b->cfg.n_streams) return SS_ERR_INVALID_ARG;
+    const size_t per = (size_t)b->cfg.frames_per_stream * b->cfg.channels;
+    const size_t n = per * count;
+    if (format == SS_PCM_F32) {
+        HIPCHK(hipMemcpyAsync(b->pcm.p + (size_t)first * per, pcm, n * sizeof(float), hipMemcpyHostToDevice, b->stream));
+        return SS_OK;
+    }
+    // one raw staging area per batch, sized for the whole batch; ranges of different `first` do not overlap
+    const size_t total = per * b->cfg.n_streams;
+    if (b->raw.n < total * sb + 8) {
+        HIPCHK(hipStreamSynchronize(b->stream));
+        HIPCHK(b->raw.alloc(total * sb + 8));
+    }
+    unsigned char *dst = b->raw.p + (size_t)first * per * sb;
+    HIPCHK(hipMemcpyAsync(dst, pcm, n * sb, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(ssk::launch_pcm_to_f32(dst, n, format, b->pcm.p + (size_t)first * per, b->stream));
     return SS_OK;
 }
 

@@ -1,0 +1,83 @@
+"""Pipelined corpus analysis: host-resident PCM in, per-stream loudness results out (the callers' side of the path).
+
+Two `Batch` objects are a double buffer — each owns its HIP stream, so chunk k+1's upload (copy engine) runs while
+chunk k is analysed.  The host corpus is page-locked in place (`ss_host_register`) and uploaded with
+`ss_batch_upload_pcm_async` as raw PCM (s16 input halves the PCIe bytes; the conversion to f32 is a kernel, N2).
+Results that stay small (loudness, peaks, histograms) come back per chunk; spectra stay on the device unless asked for.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .analyzer import _check
+from .batch import Batch
+
+_NP_FORMAT = {np.dtype(np.uint8): L.SS_PCM_U8, np.dtype(np.int16): L.SS_PCM_S16, np.dtype(np.int32): L.SS_PCM_S32,
+              np.dtype(np.float32): L.SS_PCM_F32, np.dtype(np.float64): L.SS_PCM_F64}
+
+
+def analyze_corpus(pcm, sample_rate, channels, frames_per_stream, chunk_streams=256,
+                   flags=L.SS_BATCH_LUFS | L.SS_BATCH_TRUE_PEAK, fft_n=4096, hop_frames=1024, on_chunk=None):
+    """pcm: one contiguous numpy array holding n_streams equal-length interleaved streams (u8/s16/s32/f32/f64).
+    Returns (results, corpus_hist): `results` is a list of StreamResult-like tuples
+    (integrated, lra, true_peak[2], sample_peak[2]) per stream, `corpus_hist` the summed 2 x 1000 histograms.
+    `on_chunk(batch, first_stream, count)` is called after each chunk's pass while its outputs are still resident."""
+    a = np.ascontiguousarray(pcm)
+    fmt = _NP_FORMAT[a.dtype]
+    per = frames_per_stream * channels
+    n_streams = a.size // per
+    assert n_streams * per == a.size
+    chunk_streams = max(1, min(chunk_streams, n_streams))
+    lib = L.lib()
+    pinned = lib.ss_host_register(a.ctypes.data_as(C.c_void_p), a.nbytes) == L.SS_OK
+    bufs = [Batch(sample_rate, channels, chunk_streams, frames_per_stream, fft_n, hop_frames, flags=flags) for _ in range(2)]
+    pending = [None, None]                                  # (first, count) in flight on each buffer
+    results = [None] * n_streams
+    hist = np.zeros(2000, np.uint64)
+
+    def collect(slot):
+        if pending[slot] is None:
+            return
+        first, count = pending[slot]
+        b = bufs[slot]
+        b.sync()
+        if on_chunk is not None:
+            on_chunk(b, first, count)
+        r = b.results()
+        for i in range(count):
+            results[first + i] = (r[i].integrated_lufs, r[i].loudness_range, tuple(r[i].true_peak), tuple(r[i].sample_peak))
+        hb, hs = b.histograms()
+        hist[:1000] += hb
+        hist[1000:] += hs
+        pending[slot] = None
+
+    try:
+        k = 0
+        full = n_streams - n_streams % chunk_streams
+        for first in range(0, full, chunk_streams):
+            slot = k & 1
+            collect(slot)                                    # the buffer's previous chunk must be done before its input is overwritten
+            src = a.reshape(-1)[first * per:(first + chunk_streams) * per]
+            _check(lib.ss_batch_upload_pcm_async(bufs[slot]._h, 0, chunk_streams, src.ctypes.data_as(C.c_void_p), fmt))
+            bufs[slot].run()
+            pending[slot] = (first, chunk_streams)
+            k += 1
+        collect(k & 1)
+        collect((k + 1) & 1)
+        if full < n_streams:                                 # the short last chunk gets a batch of its own size
+            count = n_streams - full
+            tail = Batch(sample_rate, channels, count, frames_per_stream, fft_n, hop_frames, flags=flags)
+            bufs.append(tail)
+            pending.append((full, count))
+            src = a.reshape(-1)[full * per:]
+            _check(lib.ss_batch_upload_pcm_async(tail._h, 0, count, src.ctypes.data_as(C.c_void_p), fmt))
+            tail.run()
+            collect(2)
+    finally:
+        for b in bufs:
+            b.sync()
+            b.close()
+        if pinned:
+            lib.ss_host_unregister(a.ctypes.data_as(C.c_void_p))
+    return results, hist

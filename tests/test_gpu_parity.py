@@ -650,3 +650,27 @@ def test_batch_96k_stereo_long_integer_bins(oracle):
     b.upload(0, np.concatenate(xs))
     b.run(); b.sync()
     _check_batch_against_oracle(oracle, b, xs, rate, 4096, 1024)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int16])
+def test_pipelined_corpus_equals_one_batch(oracle, dtype):
+    """soundscope_amd.pipeline.analyze_corpus (double-buffered chunks, page-locked host corpus, asynchronous raw-PCM
+    upload) returns exactly what one resident batch over the same streams returns, incl. the corpus histograms."""
+    rate, frames, ns = 48000, 48000 * 2, 11                       # 11 streams in chunks of 4: two full rounds + a tail of 3
+    xs = np.concatenate([make_stereo(900 + s, frames, rate, level=0.1 + 0.08 * s) for s in range(ns)])
+    if dtype == np.int16:
+        pcm = np.round(xs * 32767.0).astype(np.int16)
+        ref_in = (pcm.astype(np.float32) / np.float32(32768.0))        # symphonia's s16 -> f32 (tests/test_ingest.py)
+    else:
+        pcm, ref_in = xs, xs
+    res, hist = ssa.analyze_corpus(pcm, rate, 2, frames, chunk_streams=4)
+    full = ssa.Batch(rate, 2, ns, frames, 4096, 1024, flags=L.SS_BATCH_LUFS | L.SS_BATCH_TRUE_PEAK)
+    full.upload(0, ref_in); full.run(); full.sync()
+    r = full.results()
+    for s in range(ns):
+        assert res[s][0] == r[s].integrated_lufs and res[s][1] == r[s].loudness_range
+        assert res[s][2] == tuple(r[s].true_peak) and res[s][3] == tuple(r[s].sample_peak)
+    hb, hs = full.histograms()
+    assert np.array_equal(hist[:1000], hb) and np.array_equal(hist[1000:], hs)
+    m = oracle.Meter(2, rate); m.add_frames(ref_in[:2 * frames])
+    assert lufs_close(res[0][0], m.integrated())
