@@ -674,3 +674,39 @@ def test_pipelined_corpus_equals_one_batch(oracle, dtype):
     assert np.array_equal(hist[:1000], hb) and np.array_equal(hist[1000:], hs)
     m = oracle.Meter(2, rate); m.add_frames(ref_in[:2 * frames])
     assert lufs_close(res[0][0], m.integrated())
+
+
+@pytest.mark.parametrize("frames", [1, 100, 4095, 4096, 4799, 4800, 5119, 5120, 19199, 19200])
+def test_batch_degenerate_lengths(oracle, frames):
+    """Streams shorter than a window, a sub-block, a gating block: no windows / no blocks is a valid result
+    (integrated -inf, LRA 0), peaks and decimation still exact."""
+    rate = 48000
+    xs = [make_stereo(1234 + i, frames, rate, level=0.5) for i in range(2)]
+    b = ssa.Batch(rate, 2, 2, frames, 4096, 1024)
+    b.upload(0, np.concatenate(xs))
+    b.run(); b.sync()
+    lay = b.layout
+    res = b.results()
+    for i, x in enumerate(xs):
+        ref = oracle.analyze_stream(rate, x, 4096, 1024)
+        assert lay.n_windows == ref["n_windows"]
+        if lay.n_windows:
+            fft = b.fft(i)
+            for w in range(lay.n_windows):
+                for c in range(2):
+                    assert db_close(fft[w, c], ref["fft"][w, c], TOL_DB)
+        assert lufs_close(res[i].integrated_lufs, ref["integrated"])
+        assert abs(res[i].loudness_range - ref["lra"]) <= TOL_DB
+        for c in range(2):
+            assert rel_close(res[i].true_peak[c], ref["true_peak"][c])
+            assert res[i].sample_peak[c] == ref["sample_peak"][c]
+        assert np.array_equal(b.waveform(i).reshape(-1), ref["wave"][:, 1].astype(np.float32))
+
+
+def test_batch_create_rejects_nonsense():
+    for kw in (dict(n_streams=0), dict(frames_per_stream=0), dict(channels=0), dict(channels=65), dict(sample_rate=15),
+               dict(fft_n=1000), dict(hop_frames=0)):
+        args = dict(sample_rate=48000, channels=2, n_streams=1, frames_per_stream=48000, fft_n=4096, hop_frames=1024)
+        args.update(kw)
+        with pytest.raises(ssa.AnalyzerError):
+            ssa.Batch(**args)
