@@ -210,6 +210,19 @@ int ss_batch_download_input(ss_batch *b, uint32_t stream, float *pcm, size_t cap
 /* same as ss_batch_upload for raw PCM of `format`: the bytes are copied to the GPU and converted
  * there straight into the resident f32 corpus (no host-side f32 copy) */
 int ss_batch_upload_pcm(ss_batch *b, uint32_t first, uint32_t count, const void *pcm, int format);
+/* Ragged batches: streams of different lengths in one batch.  Create the batch for the longest stream
+ * (frames_per_stream is the slot size), then give every stream its own length; each gets its own window count,
+ * sub-block count and decimation geometry by the rules ss_batch_create applies to a uniform batch.  Rows beyond a
+ * stream's own counts in the downloads are unspecified; ss_batch_stream_shape says how many are valid. */
+typedef struct ss_stream_shape {
+    uint64_t frames;
+    uint32_t n_windows, n_subblocks, n_wave_points, reserved;
+} ss_stream_shape;              /* 24 bytes */
+int ss_batch_set_lengths(ss_batch *b, const uint64_t *frames, uint32_t n_streams);
+int ss_batch_stream_shape(const ss_batch *b, uint32_t stream, ss_stream_shape *out);
+/* the first n_samples interleaved samples of one stream's slot (raw PCM of any ss_pcm_format), queued on the batch's
+ * stream; `pcm` must stay valid until the next ss_batch_sync */
+int ss_batch_upload_samples(ss_batch *b, uint32_t stream, const void *pcm, size_t n_samples, int format);
 /* Pipelined ingest.  A batch owns its HIP stream, so two batches are a double buffer: while one runs, the other's
  * upload is in flight — provided the host memory is page-locked (ss_host_register pins caller memory in place) and
  * the upload does not wait: ss_batch_upload_pcm_async only queues the copy and the conversion; `pcm` must stay

@@ -33,6 +33,7 @@ SYMBOLS = [
     "ss_batch_render_spectrum", "ss_batch_download_spectrum_columns", "ss_batch_render_waveform",
     "ss_batch_download_waveform_columns", "ss_waveform_view", "ss_batch_kernel_name",
     "ss_host_register", "ss_host_unregister", "ss_batch_upload_pcm_async",
+    "ss_batch_set_lengths", "ss_batch_stream_shape", "ss_batch_upload_samples",
 ]
 
 SS_OK = 0
@@ -70,6 +71,11 @@ class TickResult(C.Structure):
                 ("side_status", C.c_int32), ("n_mid", C.c_uint32), ("n_side", C.c_uint32),
                 ("lufs_ran", C.c_int32), ("fed", C.c_int32), ("add_status", C.c_int32),
                 ("shortterm_status", C.c_int32), ("reserved", C.c_uint32), ("shortterm", C.c_double)]
+
+
+class StreamShape(C.Structure):
+    _fields_ = [("frames", C.c_uint64), ("n_windows", C.c_uint32), ("n_subblocks", C.c_uint32),
+                ("n_wave_points", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class BatchLayout(C.Structure):
@@ -160,6 +166,9 @@ def _bind(lib):
         "ss_host_register": (C.c_int, [vp, C.c_size_t]),
         "ss_host_unregister": (C.c_int, [vp]),
         "ss_batch_upload_pcm_async": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, C.c_int]),
+        "ss_batch_set_lengths": (C.c_int, [vp, u64p, C.c_uint32]),
+        "ss_batch_upload_samples": (C.c_int, [vp, C.c_uint32, vp, C.c_size_t, C.c_int]),
+        "ss_batch_stream_shape": (C.c_int, [vp, C.c_uint32, C.POINTER(StreamShape)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

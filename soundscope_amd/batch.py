@@ -66,6 +66,17 @@ class Batch:
     def sync(self):
         _check(L.lib().ss_batch_sync(self._h))
 
+    # -- ragged batches: every stream its own length inside its frames_per_stream slot
+    def set_lengths(self, frames):
+        a = np.ascontiguousarray(frames, dtype=np.uint64)
+        _check(L.lib().ss_batch_set_lengths(self._h, a.ctypes.data_as(C.POINTER(C.c_uint64)), a.size))
+        self._ragged = True
+
+    def stream_shape(self, stream):
+        sh = L.StreamShape()
+        _check(L.lib().ss_batch_stream_shape(self._h, stream, C.byref(sh)))
+        return sh
+
     def results(self):
         n = int(self.cfg.n_streams)
         arr = (L.StreamResult * n)()
@@ -76,7 +87,7 @@ class Batch:
         lay = self.layout
         out = np.empty((lay.n_windows, lay.fft_channels, lay.n_bins), np.float32)
         _check(L.lib().ss_batch_download_fft(self._h, stream, out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
-        return out
+        return out[:self.stream_shape(stream).n_windows] if getattr(self, "_ragged", False) else out
 
     def bin_tables(self):
         n = self.layout.n_bins
@@ -89,6 +100,8 @@ class Batch:
         pts = self.layout.n_wave_points
         out = np.empty(pts, np.float32)
         _check(L.lib().ss_batch_download_waveform(self._h, stream, out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
+        if getattr(self, "_ragged", False):
+            out = out[:self.stream_shape(stream).n_wave_points]
         return out.reshape(-1, 2)          # [bin] -> (min, max)
 
     # -- render-side reductions (tui.rs:49-51, :801-821, :664-681)

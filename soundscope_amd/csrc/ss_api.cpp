@@ -840,6 +840,12 @@ struct ss_batch {
     DevBuf<uint64_t> hist, corpus;
     DevBuf<uint32_t> counts;
     DevBuf<unsigned char> raw;      // device staging of raw PCM for the asynchronous ingest
+    // ragged batches (ss_batch_set_lengths): per-stream frames / windows / sub-blocks / decimation bins
+    bool ragged = false;
+    std::vector<uint64_t> frames_h, wave_samples_h;
+    std::vector<uint32_t> windows_h, sub_h, wave_window_h, wave_bins_h;
+    DevBuf<uint64_t> frames_d, wave_samples_d;
+    DevBuf<uint32_t> windows_d, sub_d, wave_window_d;
     // render-side reductions (N3)
     DevBuf<float> render_spec, render_wave;
     DevBuf<uint32_t> col_start;
@@ -1065,6 +1071,58 @@ int ss_batch_upload_pcm(ss_batch *b, uint32_t first, uint32_t count, const void 
     return SS_OK;
 }
 
+// ---- ragged batches: streams of different lengths in one batch ------------------------------------------------
+// The batch is created for the longest stream (frames_per_stream = the slot size); every stream then gets its own
+// window count, sub-block count and decimation geometry by the very rules ss_batch_create applies to the whole
+// batch.  Slots are uploaded as before (the tail of a short stream's slot is never read).
+int ss_batch_set_lengths(ss_batch *b, const uint64_t *frames, uint32_t count)
+{
+    if (!b || !frames || count != b->cfg.n_streams) return SS_ERR_INVALID_ARG;
+    const ss_batch_config &c = b->cfg;
+    const uint32_t C = c.channels;
+    for (uint32_t i = 0; i < count; i++) if (frames[i] > c.frames_per_stream) return SS_ERR_INVALID_ARG;
+    b->frames_h.assign(frames, frames + count);
+    b->windows_h.assign(count, 0); b->sub_h.assign(count, 0);
+    b->wave_window_h.assign(count, 0); b->wave_bins_h.assign(count, 0); b->wave_samples_h.assign(count, 0);
+    for (uint32_t i = 0; i < count; i++) {
+        const uint64_t F = frames[i];
+        if (c.flags & SS_BATCH_FFT) {
+            const uint64_t hop = c.hop_frames, k_min = c.fft_n / hop + 1, k_max = F / hop;
+            b->windows_h[i] = k_max >= k_min ? (uint32_t)(k_max - k_min + 1) : 0;
+        }
+        if (b->td) b->sub_h[i] = (uint32_t)(F / b->td->host.s100);
+        if (c.flags & SS_BATCH_WAVEFORM) {
+            const double win = c.waveform_window > 0.0 ? c.waveform_window : (double)F / (double)c.sample_rate;
+            size_t window, bins;
+            waveform_shape((size_t)(F * C), win, &window, &bins);
+            if (window > b->wave_window) return SS_ERR_INVALID_ARG;      // cannot happen for F <= frames_per_stream
+            b->wave_window_h[i] = (uint32_t)window; b->wave_bins_h[i] = (uint32_t)bins; b->wave_samples_h[i] = F * C;
+        }
+    }
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(b->frames_d.upload(b->frames_h));
+    HIPCHK(b->windows_d.upload(b->windows_h));
+    HIPCHK(b->sub_d.upload(b->sub_h));
+    HIPCHK(b->wave_window_d.upload(b->wave_window_h));
+    HIPCHK(b->wave_samples_d.upload(b->wave_samples_h));
+    b->ragged = true;
+    return SS_OK;
+}
+
+int ss_batch_stream_shape(const ss_batch *b, uint32_t stream, ss_stream_shape *out)
+{
+    if (!b || !out || stream >= b->cfg.n_streams) return SS_ERR_INVALID_ARG;
+    if (b->ragged) {
+        out->frames = b->frames_h[stream]; out->n_windows = b->windows_h[stream];
+        out->n_subblocks = b->sub_h[stream]; out->n_wave_points = 2 * b->wave_bins_h[stream];
+    } else {
+        out->frames = b->cfg.frames_per_stream; out->n_windows = b->lay.n_windows;
+        out->n_subblocks = b->lay.n_subblocks; out->n_wave_points = b->lay.n_wave_points;
+    }
+    out->reserved = 0;
+    return SS_OK;
+}
+
 // ---- pipelined ingest: page-locked host memory + uploads that do not wait -------------------------------------
 // A batch owns its stream, so two batches are a double buffer: while one runs, the other's upload is in flight
 // on the copy engine.  That only holds for page-locked host memory (pageable copies are staged synchronously).
@@ -1105,6 +1163,31 @@ int ss_batch_upload_pcm_async(ss_batch *b, uint32_t first, uint32_t count, const
     unsigned char *dst = b->raw.p + (size_t)first * per * sb;
     HIPCHK(hipMemcpyAsync(dst, pcm, n * sb, hipMemcpyHostToDevice, b->stream));
     HIPCHK(ssk::launch_pcm_to_f32(dst, n, format, b->pcm.p + (size_t)first * per, b->stream));
+    return SS_OK;
+}
+
+// the first n_samples interleaved samples of one stream's slot, raw PCM of any supported format (ragged batches:
+// a stream shorter than the slot).  Queued on the batch's stream like ss_batch_upload_pcm_async.
+int ss_batch_upload_samples(ss_batch *b, uint32_t stream, const void *pcm, size_t n_samples, int format)
+{
+    const size_t sb = ss_pcm_sample_bytes(format);
+    if (!b || (!pcm && n_samples) || !sb || stream >= b->cfg.n_streams) return SS_ERR_INVALID_ARG;
+    const size_t per = (size_t)b->cfg.frames_per_stream * b->cfg.channels;
+    if (n_samples > per) return SS_ERR_INVALID_ARG;
+    if (!n_samples) return SS_OK;
+    float *dst = b->pcm.p + (size_t)stream * per;
+    if (format == SS_PCM_F32) {
+        HIPCHK(hipMemcpyAsync(dst, pcm, n_samples * sizeof(float), hipMemcpyHostToDevice, b->stream));
+        return SS_OK;
+    }
+    const size_t total = per * b->cfg.n_streams;
+    if (b->raw.n < total * sb + 8) {
+        HIPCHK(hipStreamSynchronize(b->stream));
+        HIPCHK(b->raw.alloc(total * sb + 8));
+    }
+    unsigned char *raw = b->raw.p + (size_t)stream * per * sb;
+    HIPCHK(hipMemcpyAsync(raw, pcm, n_samples * sb, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(ssk::launch_pcm_to_f32(raw, n_samples, format, dst, b->stream));
     return SS_OK;
 }
 
@@ -1159,6 +1242,7 @@ int ss_batch_run(ss_batch *b)
         p.n_streams = c.n_streams; p.channels = C; p.n_windows = L.n_windows; p.hop = c.hop_frames;
         p.n = c.fft_n; p.first_bin = L.first_bin; p.n_bins = L.n_bins; p.bin_stride = L.fft_bin_stride;
         p.windows_per_block = b->windows_per_block;
+        p.windows_of = b->ragged ? b->windows_d.p : nullptr;
         if (b->fft_fast) {
             p.db_offset = (float)(10.0 * std::log10(4.0 / ((double)c.fft_n * (double)c.fft_n)));
             p.offpink = b->bt->offpink4096_dev.p;
@@ -1203,7 +1287,8 @@ int ss_batch_run(ss_batch *b)
         p.subblocks = b->sub.p; p.sub_cap = L.n_subblocks ? L.n_subblocks : 1;
         p.sub_stride = (uint64_t)p.sub_cap * C; p.ring = nullptr; p.ring_frames = 0; p.tp_factor = b->tp_factor;
         p.s100 = b->td->host.s100; p.nseg = b->td_nseg; p.seg_sub = b->td_seg_sub; p.warm_sub = kTdWarmSub;
-        if (b->wave_fused) { p.wave_out = b->wave.p; p.wave_stride = (uint64_t)2 * b->wave_window; p.wave_window = b->wave_window; p.halo_frames = b->wave_halo; }
+        p.frames_of = b->ragged ? b->frames_d.p : nullptr;
+        if (b->wave_fused && !b->ragged) { p.wave_out = b->wave.p; p.wave_stride = (uint64_t)2 * b->wave_window; p.wave_window = b->wave_window; p.halo_frames = b->wave_halo; }
         HIPCHK(ssk::launch_time_domain(p, b->stream));
     }
     HIPCHK(rec(2 * SS_KERNEL_TIME_DOMAIN + 1));
@@ -1219,16 +1304,18 @@ int ss_batch_run(ss_batch *b)
         f.hist_energies = he; f.hist_bounds = hb; f.weights = b->weights.p; f.hist = b->hist.p;
         f.corpus_hist = b->corpus.p; f.n_streams = c.n_streams; f.channels = C;
         f.sub_begin = 0; f.sub_end = L.n_subblocks;
+        f.sub_end_of = b->ragged ? b->sub_d.p : nullptr;
         f.out_integrated = b->integrated.p; f.out_lra = b->lra.p; f.out_counts = b->counts.p;
         HIPCHK(ssk::launch_finalize(f, b->stream));
     }
     HIPCHK(rec(2 * SS_KERNEL_FINALIZE + 1));
 
     HIPCHK(rec(2 * SS_KERNEL_WAVEFORM));
-    if ((c.flags & SS_BATCH_WAVEFORM) && b->wave_window && !b->wave_fused) {
+    if ((c.flags & SS_BATCH_WAVEFORM) && b->wave_window && (!b->wave_fused || b->ragged)) {
         ssk::WaveParams p{};
         p.pcm = b->pcm.p; p.stream_stride = c.frames_per_stream * C; p.n_samples = c.frames_per_stream * C;
         p.n_streams = c.n_streams; p.window = b->wave_window; p.out = b->wave.p; p.out_stride = (uint64_t)2 * b->wave_window;
+        if (b->ragged) { p.samples_of = b->wave_samples_d.p; p.window_of = b->wave_window_d.p; }
         HIPCHK(ssk::launch_waveform(p, b->stream));
     }
     HIPCHK(rec(2 * SS_KERNEL_WAVEFORM + 1));

@@ -35,6 +35,7 @@ struct FftBatchParams {
     uint32_t windows_per_block;  // 4096 kernel
     float db_offset;             // 10*log10(4/N^2) (4096) or 20*log10(4/N) (generic)
     uint32_t publish_mask;       // 4096 kernels: bit kc set when bins [256kc, 256kc+255] hold a retained bin or a mirror
+    const uint32_t *windows_of;   // ragged batches: windows of each stream (nullable = n_windows for all)
 };
 
 // mid/side packed N=4096 kernel (stereo only).  hop must be a multiple of 256.
@@ -89,6 +90,7 @@ struct TdParams {
     uint64_t wave_stride;        // floats between streams
     uint32_t wave_window;        // number of decimation bins W
     uint32_t halo_frames;        // frames kept in front of each tile: >= longest bin, multiple of 4
+    const uint64_t *frames_of;    // ragged batches: frames of each stream (nullable = n_frames for all)
 };
 hipError_t launch_time_domain(const TdParams &p, hipStream_t s);
 // frames per sequential chunk for a channel count (the constant block's m_pow must match)
@@ -108,6 +110,7 @@ struct FinalizeParams {
     double *out_integrated;          // [stream] (nullable)
     double *out_lra;                 // [stream] (nullable)
     uint32_t *out_counts;            // [stream][2] gating / short-term blocks evaluated (nullable)
+    const uint32_t *sub_end_of;   // ragged batches: sub-blocks of each stream (nullable = sub_end for all)
 };
 hipError_t launch_finalize(const FinalizeParams &p, hipStream_t s);
 // gate + LRA on explicit histograms (corpus gate after the all-reduce; handle getters)
@@ -124,6 +127,8 @@ struct WaveParams {
     const float *pcm; uint64_t stream_stride; uint64_t n_samples; // interleaved samples per stream
     uint32_t n_streams; uint32_t window;   // number of decimation bins W
     float *out; uint64_t out_stride;       // [stream][W][2] f32 (min, max)
+    const uint64_t *samples_of;   // ragged batches: interleaved samples / bins of each stream (nullable)
+    const uint32_t *window_of;
 };
 hipError_t launch_waveform(const WaveParams &p, hipStream_t s);
 

@@ -235,7 +235,9 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
     const uint32_t grp = blockIdx.x - stream * groups;
     const uint32_t w_begin = grp * p.windows_per_block;
     uint32_t w_end = w_begin + p.windows_per_block;
-    if (w_end > p.n_windows) w_end = p.n_windows;
+    const uint32_t n_win = p.windows_of ? p.windows_of[stream] : p.n_windows;     // ragged batches: this stream's own count
+    if (w_begin >= n_win) return;
+    if (w_end > n_win) w_end = n_win;
 
     const float2 *src = reinterpret_cast<const float2 *>(p.pcm) + (size_t)stream * p.frames_per_stream +
                         p.first_start + (size_t)w_begin * p.hop;
@@ -382,7 +384,9 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
     const uint32_t grp = blockIdx.x - stream * groups;
     const uint32_t w_begin = grp * p.windows_per_block;
     uint32_t w_end = w_begin + p.windows_per_block;
-    if (w_end > p.n_windows) w_end = p.n_windows;
+    const uint32_t n_win = p.windows_of ? p.windows_of[stream] : p.n_windows;     // ragged batches: this stream's own count
+    if (w_begin >= n_win) return;
+    if (w_end > n_win) w_end = n_win;
     const float2 *src = reinterpret_cast<const float2 *>(p.pcm) + (size_t)stream * p.frames_per_stream +
                         p.first_start + (size_t)w_begin * p.hop;
     const v2f *twn = reinterpret_cast<const v2f *>(p.tw_n);
@@ -483,7 +487,9 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms_anyhop(FftBatc
     const uint32_t grp = blockIdx.x - stream * groups;
     const uint32_t w_begin = grp * p.windows_per_block;
     uint32_t w_end = w_begin + p.windows_per_block;
-    if (w_end > p.n_windows) w_end = p.n_windows;
+    const uint32_t n_win = p.windows_of ? p.windows_of[stream] : p.n_windows;     // ragged batches: this stream's own count
+    if (w_begin >= n_win) return;
+    if (w_end > n_win) w_end = n_win;
     const float2 *src = reinterpret_cast<const float2 *>(p.pcm) + (size_t)stream * p.frames_per_stream +
                         p.first_start + (size_t)w_begin * p.hop;
     tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[t];
@@ -547,6 +553,7 @@ __global__ __launch_bounds__(512, 2) void k_fft16k(FftBatchParams p, int midside
     const uint32_t ch = bid % fft_ch; bid /= fft_ch;
     const uint32_t w = bid % p.n_windows;
     const uint32_t stream = bid / p.n_windows;
+    if (p.windows_of && w >= p.windows_of[stream]) return;                          // ragged batches
     const size_t start = p.first_start + (size_t)w * p.hop;
     const float *base = p.pcm + ((size_t)stream * p.frames_per_stream + start) * p.channels;
     const v2f *tw16k = reinterpret_cast<const v2f *>(p.tw_n);       // W_16384^k, k < 8192
@@ -671,7 +678,9 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
     const uint32_t stream = bid / groups;
     const uint32_t w_begin = grp * p.windows_per_block;
     uint32_t w_end = w_begin + p.windows_per_block;
-    if (w_end > p.n_windows) w_end = p.n_windows;
+    const uint32_t n_win = p.windows_of ? p.windows_of[stream] : p.n_windows;     // ragged batches: this stream's own count
+    if (w_begin >= n_win) return;
+    if (w_end > n_win) w_end = n_win;
     const uint32_t C = p.channels;
     const float *base = p.pcm + ((size_t)stream * p.frames_per_stream + p.first_start + (size_t)w_begin * 1024u) * C;
     const v2f *tw16k = reinterpret_cast<const v2f *>(p.tw_n);       // W_16384^k, k < 8192
@@ -914,6 +923,7 @@ __global__ __launch_bounds__(256) void k_fft_generic(FftBatchParams p, int mode,
     const uint32_t ch = bid % fft_ch; bid /= fft_ch;
     const uint32_t w = bid % p.n_windows;
     const uint32_t stream = bid / p.n_windows;
+    if (p.windows_of && w >= p.windows_of[stream]) return;                          // ragged batches
     const size_t start = p.first_start + (size_t)w * p.hop;
     const float *base = p.pcm + ((size_t)stream * p.frames_per_stream + start) * p.channels;
 
@@ -1134,12 +1144,13 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
     const bool carry_in = (p.nseg == 1);
     const uint64_t fed0 = carry_in ? st.frames_fed : 0;
     uint64_t seg_begin, seg_end;                        // frames of this call, [begin, end)
-    if (p.nseg == 1) { seg_begin = 0; seg_end = p.n_frames; }
+    const uint64_t n_frames = p.frames_of ? p.frames_of[stream] : p.n_frames;         // ragged batches: this stream's own length
+    if (p.nseg == 1) { seg_begin = 0; seg_end = n_frames; }
     else {
         seg_begin = (uint64_t)sg * p.seg_sub * S;
-        seg_end = (sg + 1 == p.nseg) ? p.n_frames : (uint64_t)(sg + 1) * p.seg_sub * S;
-        if (seg_begin > p.n_frames) seg_begin = p.n_frames;
-        if (seg_end > p.n_frames) seg_end = p.n_frames;
+        seg_end = (sg + 1 == p.nseg) ? n_frames : (uint64_t)(sg + 1) * p.seg_sub * S;
+        if (seg_begin > n_frames) seg_begin = n_frames;
+        if (seg_end > n_frames) seg_end = n_frames;
     }
     const uint64_t warm_frames = (sg == 0) ? 0 : (uint64_t)p.warm_sub * S;   // sg > 0 implies seg_begin >= warm
     uint64_t pos = seg_begin - warm_frames;             // first frame this wave reads
@@ -1163,7 +1174,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
 
     // ---- min-max decimation cursor (Analyzer::get_waveform fused into this pass): a bin is produced by
     // the wave whose tile holds the bin's LAST sample; its first samples may sit in the halo.
-    const uint64_t wv_len = p.n_frames * C;
+    const uint64_t wv_len = n_frames * C;
     const double wv_spp = WAVE ? (double)wv_len / (double)p.wave_window : 0.0;
     const uint32_t wv_spp_i = WAVE ? (uint32_t)wv_spp : 0u;
     uint32_t wv_cur = 0;
@@ -1626,7 +1637,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
             st.acc[lane] = e_run;
             for (int q = 1; q <= kTpHistMax; q++) st.tp_hist[lane][q - 1] = tile[-(int)(q * C) + (int)lane];
         }
-        if (lane == 0) st.frames_fed = fed0 + p.n_frames;
+        if (lane == 0) st.frames_fed = fed0 + n_frames;
     }
 #undef SS_TILE_FRAMES
 #undef SS_PREFETCH
@@ -1841,7 +1852,8 @@ __global__ __launch_bounds__(64) void k_finalize(FinalizeParams p)
     const double S = (double)p.k->s100;
     const double *P = p.subblocks + (size_t)stream * p.sub_stride;
     // gating block ending with sub-block j: j-3..j ; short-term block: j-29..j when (j-29) % 10 == 0
-    for (uint64_t j = p.sub_begin + lane; j < p.sub_end; j += 64) {
+    const uint64_t sub_end = p.sub_end_of ? p.sub_end_of[stream] : p.sub_end;          // ragged batches
+    for (uint64_t j = p.sub_begin + lane; j < sub_end; j += 64) {
         if (j >= 3) {
             double sum = 0.0;
             for (uint32_t c = 0; c < C; c++) {
@@ -2026,6 +2038,11 @@ __global__ __launch_bounds__(256) void k_waveform(WaveParams p)
     if (gbin >= total_bins) return;
     const uint32_t stream = (uint32_t)(gbin / p.window);
     const uint32_t i = (uint32_t)(gbin - (uint64_t)stream * p.window);
+    if (p.window_of) {                          // ragged batches: this stream's own length and bin count
+        if (i >= p.window_of[stream]) return;
+        p.n_samples = p.samples_of[stream];
+        p.window = p.window_of[stream];
+    }
     const double spp = (double)p.n_samples / (double)p.window;
     const double sd = (double)i * spp;
     const double ed = ceil((double)(i + 1) * spp);

@@ -81,3 +81,49 @@ def analyze_corpus(pcm, sample_rate, channels, frames_per_stream, chunk_streams=
         if pinned:
             lib.ss_host_unregister(a.ctypes.data_as(C.c_void_p))
     return results, hist
+
+
+def analyze_streams(streams, sample_rate, channels, chunk_streams=256,
+                    flags=L.SS_BATCH_LUFS | L.SS_BATCH_TRUE_PEAK, fft_n=4096, hop_frames=1024, on_chunk=None):
+    """Streams of DIFFERENT lengths (a list of interleaved numpy arrays of one dtype, e.g. decoded files): sorted
+    by length, cut into chunks, each chunk one ragged batch (`ss_batch_set_lengths`) whose slot is its longest
+    stream, every stream uploaded straight from its own array.  Returns (results, corpus_hist) in input order;
+    `on_chunk(batch, indices)` sees each chunk's batch while its spectra / waveforms are still resident."""
+    n = len(streams)
+    arrs = [np.ascontiguousarray(x) for x in streams]
+    if n == 0:
+        return [], np.zeros(2000, np.uint64)
+    fmt = _NP_FORMAT[arrs[0].dtype]
+    order = sorted(range(n), key=lambda i: arrs[i].size)
+    results = [None] * n
+    hist = np.zeros(2000, np.uint64)
+    lib = L.lib()
+    for c0 in range(0, n, chunk_streams):
+        idx = order[c0:c0 + chunk_streams]
+        frames = [arrs[i].size // channels for i in idx]
+        slot = max(max(frames), 1)
+        b = Batch(sample_rate, channels, len(idx), slot, fft_n, hop_frames, flags=flags)
+        try:
+            b.set_lengths(frames)
+            for k, i in enumerate(idx):
+                if frames[k]:
+                    # one slot at a time: a slot-sized "count" would read past the end of a shorter array
+                    _check(_upload_stream(lib, b, k, arrs[i], frames[k] * channels, fmt))
+            b.run()
+            b.sync()
+            if on_chunk is not None:
+                on_chunk(b, idx)
+            r = b.results()
+            for k, i in enumerate(idx):
+                results[i] = (r[k].integrated_lufs, r[k].loudness_range, tuple(r[k].true_peak), tuple(r[k].sample_peak))
+            hb, hs = b.histograms()
+            hist[:1000] += hb
+            hist[1000:] += hs
+        finally:
+            b.close()
+    return results, hist
+
+
+def _upload_stream(lib, batch, slot_index, arr, n_samples, fmt):
+    """Upload n_samples of `arr` into the head of slot `slot_index` (the rest of the slot is never read)."""
+    return lib.ss_batch_upload_samples(batch._h, slot_index, arr.ctypes.data_as(C.c_void_p), n_samples, fmt)

@@ -710,3 +710,65 @@ def test_batch_create_rejects_nonsense():
         args.update(kw)
         with pytest.raises(ssa.AnalyzerError):
             ssa.Batch(**args)
+
+
+@pytest.mark.parametrize("rate,fft_n", [(48000, 4096), (44100, 16384)])
+def test_ragged_batch_matches_oracle_per_stream(oracle, rate, fft_n):
+    """Streams of different lengths in one batch (ss_batch_set_lengths): every stream equals its own oracle pass —
+    window count, spectra, loudness, LRA, peaks, decimation — including one shorter than a window and an empty one."""
+    lens = [rate * 5 + 333, rate * 2, fft_n + 1024, fft_n - 1, rate * 3 + 4799, 0, 1]
+    slot = max(lens)
+    xs = [make_stereo(700 + i, n, rate, level=0.25 + 0.1 * i) for i, n in enumerate(lens)]
+    buf = np.zeros((len(lens), 2 * slot), np.float32)
+    buf[:] = 7.0                                             # slot tails hold garbage that must never be read
+    for i, x in enumerate(xs):
+        buf[i, :x.size] = x
+    b = ssa.Batch(rate, 2, len(lens), slot, fft_n, 1024)
+    b.set_lengths(lens)
+    b.upload(0, buf.reshape(-1))
+    b.run(); b.sync()
+    res = b.results()
+    for i, x in enumerate(xs):
+        sh = b.stream_shape(i)
+        assert sh.frames == lens[i]
+        if lens[i] == 0:
+            assert sh.n_windows == 0 and sh.n_wave_points == 0
+            assert res[i].integrated_lufs == -np.inf and res[i].loudness_range == 0.0
+            assert list(res[i].true_peak) == [0.0, 0.0]
+            continue
+        ref = oracle.analyze_stream(rate, x, fft_n, 1024)
+        assert sh.n_windows == ref["n_windows"]
+        fft = b.fft(i)
+        assert fft.shape[0] == ref["n_windows"]
+        for w in sorted(set([0, ref["n_windows"] // 2, ref["n_windows"] - 1]) & set(range(ref["n_windows"]))):
+            for c in range(2):
+                assert db_close(fft[w, c], ref["fft"][w, c], TOL_DB), (i, w, c)
+        assert lufs_close(res[i].integrated_lufs, ref["integrated"])
+        assert abs(res[i].loudness_range - ref["lra"]) <= TOL_DB
+        for c in range(2):
+            assert rel_close(res[i].true_peak[c], ref["true_peak"][c])
+            assert res[i].sample_peak[c] == ref["sample_peak"][c]
+        assert np.array_equal(b.waveform(i).reshape(-1), ref["wave"][:, 1].astype(np.float32))
+
+
+def test_analyze_streams_of_different_lengths(oracle):
+    """soundscope_amd.pipeline.analyze_streams: a list of decoded files of different lengths (here s16), chunked into
+    ragged batches; results come back in input order and equal one oracle meter pass per file."""
+    rate = 44100
+    lens = [rate * 3, 1000, rate * 7 + 13, rate, 0, rate * 2 + 1, rate * 5]
+    files = [np.round(make_stereo(40 + i, n, rate, level=0.3) * 32767.0).astype(np.int16) for i, n in enumerate(lens)]
+    seen = []
+    res, hist = ssa.analyze_streams(files, rate, 2, chunk_streams=3, on_chunk=lambda b, idx: seen.append(list(idx)))
+    assert sorted(sum(seen, [])) == list(range(len(lens))) and all(len(c) <= 3 for c in seen)
+    total = np.zeros(1000, np.uint64)
+    for i, f in enumerate(files):
+        x = f.astype(np.float32) / np.float32(32768.0)
+        m = oracle.Meter(2, rate)
+        if x.size:
+            m.add_frames(x)
+        assert lufs_close(res[i][0], m.integrated()), i
+        assert abs(res[i][1] - m.loudness_range()) <= TOL_DB
+        for c in range(2):
+            assert rel_close(res[i][2][c], m.true_peak(c)) or (res[i][2][c] == 0.0 and m.true_peak(c) == 0.0)
+        total += m.block_hist()
+    assert np.array_equal(hist[:1000], total)
