@@ -10,7 +10,7 @@ from ._lib import build
 from .analyzer import Analyzer, AnalyzerError, DeviceError, get_mid_and_side_samples
 from .batch import Batch, corpus_integrated_lufs, corpus_loudness_range
 from .session import CaptureSession, FileSession
-from .pipeline import analyze_corpus, analyze_streams
+from .pipeline import analyze_corpus, analyze_streams, analyze_wav_files
 
 __all__ = ["Analyzer", "AnalyzerError", "DeviceError", "Batch", "build", "get_mid_and_side_samples",
-           "corpus_integrated_lufs", "corpus_loudness_range", "FileSession", "CaptureSession", "analyze_corpus", "analyze_streams", "_lib"]
+           "corpus_integrated_lufs", "corpus_loudness_range", "FileSession", "CaptureSession", "analyze_corpus", "analyze_streams", "analyze_wav_files", "_lib"]

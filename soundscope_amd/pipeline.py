@@ -127,3 +127,52 @@ def analyze_streams(streams, sample_rate, channels, chunk_streams=256,
 def _upload_stream(lib, batch, slot_index, arr, n_samples, fmt):
     """Upload n_samples of `arr` into the head of slot `slot_index` (the rest of the slot is never read)."""
     return lib.ss_batch_upload_samples(batch._h, slot_index, arr.ctypes.data_as(C.c_void_p), n_samples, fmt)
+
+
+def analyze_wav_files(paths, chunk_streams=256, flags=L.SS_BATCH_LUFS | L.SS_BATCH_TRUE_PEAK, fft_n=4096,
+                      hop_frames=1024, on_chunk=None):
+    """RIFF/WAVE files -> per-file loudness results, nothing decoded on the host: the header is walked by
+    `ss_wav_parse`, the data chunk goes up as raw PCM (`ss_batch_upload_samples`: u8 / s16 / s24 / s32 / f32 / f64)
+    and is converted by the ingest kernel.  Files are grouped by (rate, channels, format) and each group runs as
+    ragged batches.  Returns {path: (integrated, lra, true_peak[2], sample_peak[2])}; unreadable or unsupported
+    files map to the AnalyzerError they raised."""
+    from .analyzer import AnalyzerError
+    groups, out = {}, {}
+    for p in paths:
+        try:
+            data = np.fromfile(p, dtype=np.uint8)
+            info = L.WavInfo()                                   # the header walk reads the mapped bytes in place
+            rc = L.lib().ss_wav_parse(data.ctypes.data_as(C.c_void_p), data.size, C.byref(info))
+            if rc:
+                raise AnalyzerError(rc)
+            sb = L.lib().ss_pcm_sample_bytes(info.format)
+            n = int(info.frames) * int(info.channels)
+            raw = data[int(info.data_offset):int(info.data_offset) + n * sb]
+            if raw.size != n * sb:
+                raise AnalyzerError(L.SS_ERR_INVALID_ARG)
+            groups.setdefault((int(info.sample_rate), int(info.channels), int(info.format)), []).append((p, raw, n))
+        except (AnalyzerError, OSError) as e:
+            out[p] = e
+    lib = L.lib()
+    for (rate, ch, fmt), items in groups.items():
+        order = sorted(range(len(items)), key=lambda i: items[i][2])
+        for c0 in range(0, len(items), chunk_streams):
+            idx = order[c0:c0 + chunk_streams]
+            frames = [items[i][2] // ch for i in idx]
+            b = Batch(rate, ch, len(idx), max(max(frames), 1), fft_n, hop_frames, flags=flags)
+            try:
+                b.set_lengths(frames)
+                for k, i in enumerate(idx):
+                    if frames[k]:
+                        raw = np.ascontiguousarray(items[i][1])
+                        _check(lib.ss_batch_upload_samples(b._h, k, raw.ctypes.data_as(C.c_void_p), frames[k] * ch, fmt))
+                b.run()
+                b.sync()
+                if on_chunk is not None:
+                    on_chunk(b, [items[i][0] for i in idx])
+                r = b.results()
+                for k, i in enumerate(idx):
+                    out[items[i][0]] = (r[k].integrated_lufs, r[k].loudness_range, tuple(r[k].true_peak), tuple(r[k].sample_peak))
+            finally:
+                b.close()
+    return out

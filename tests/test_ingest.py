@@ -128,3 +128,42 @@ def test_wav_file_end_to_end(oracle):
     r = oracle.analyze_stream(rate, ref, 4096, 1024)
     assert abs(b.results()[0].integrated_lufs - r["integrated"]) <= 0.01
     assert np.array_equal(b.waveform(0).reshape(-1), r["wave"][:, 1].astype(np.float32))
+
+
+@pytest.mark.gpu
+def test_analyze_wav_files_end_to_end(oracle, tmp_path):
+    """Files of four sample formats, two rates and different lengths, a mono one and a broken one: raw PCM goes up
+    as is, results equal the oracle meter on the samples symphonia would have decoded."""
+    from conftest import make_stereo
+    specs = [("a16.wav", 48000, 2, 2, 3.0), ("b24.wav", 48000, 2, 3, 1.5), ("c16.wav", 48000, 2, 2, 0.7),
+             ("d32f.wav", 44100, 2, "f32", 2.0), ("e8.wav", 44100, 2, 1, 1.0), ("mono16.wav", 48000, 1, 2, 2.0)]
+    expect = {}
+    paths = []
+    for name, rate, ch, width, secs in specs:
+        frames = int(rate * secs)
+        x = make_stereo(len(name) + frames, frames, rate, level=0.4)[:frames * ch] if ch == 2 else \
+            make_stereo(5, frames, rate, level=0.4)[0::2].copy()
+        if width == "f32":
+            data, _ = make_float_wav(x, ch, rate)
+            ref = x.astype(np.float32)
+        else:
+            full = {1: 127, 2: 32767, 3: 8388607}[width]
+            xi = np.round(x * full).astype(np.int32)
+            data, _ = make_wav(xi, ch, rate, width)
+            ref = (xi.astype(np.float64) / {1: 128.0, 2: 32768.0, 3: 8388608.0}[width]).astype(np.float32)
+        p = tmp_path / name
+        p.write_bytes(data)
+        paths.append(str(p))
+        m = oracle.Meter(ch, rate)
+        m.add_frames(ref)
+        expect[str(p)] = m
+    bad = tmp_path / "broken.wav"
+    bad.write_bytes(b"RIFF\x00\x00\x00\x00WAVEjunk")
+    out = ssa.analyze_wav_files(paths + [str(bad)], chunk_streams=2)
+    assert isinstance(out[str(bad)], ssa.AnalyzerError)
+    for p, m in expect.items():
+        integ, lra, tp, sp = out[p]
+        assert (integ == m.integrated()) or abs(integ - m.integrated()) <= 0.01, p
+        assert abs(lra - m.loudness_range()) <= 0.01
+        assert abs(tp[0] - m.true_peak(0)) <= 1e-4 * m.true_peak(0)
+        assert sp[0] == m.sample_peak(0)
