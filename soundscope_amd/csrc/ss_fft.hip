@@ -1,0 +1,997 @@
+// ss_fft.hip: spectrum kernels (N = 4096 mid/side, N = 16384, generic power of two) — hand-written gfx950 (CDNA4, wave64) kernels of the soundscope analyzer hot path.
+// Reference semantics: /root/reference/src/analyzer.rs (get_fft :55-105, get_waveform :107-137,
+// add_samples/getters :139-164, calculate_integrated_lufs :170-182) and src/audio_player.rs:400-419, plus the
+// arithmetic of ebur128 0.1.10 / spectrum-analyzer 1.7.0 / microfft 0.6.0 as restated in DESIGN.md.
+// Nothing here is translated from the reference: the reference has no GPU code.
+#include "ss_kernels.h"
+
+#ifndef SS_FFT_WAVES
+#define SS_FFT_WAVES 2   // min waves per SIMD the N=4096 pair kernel is register-allocated for
+#endif
+
+namespace ssk {
+
+// ============================================================================
+//  small complex helpers (f32)
+// ============================================================================
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
+// a * (c - i s)
+__device__ __forceinline__ float2 cmul_cs(float2 a, float c, float s) { return make_float2(a.x * c + a.y * s, a.y * c - a.x * s); }
+// a * (-i)
+__device__ __forceinline__ float2 cmul_mi(float2 a) { return make_float2(a.y, -a.x); }
+
+// ---- packed-f32 complex arithmetic -------------------------------------------------------------
+// A complex number lives in an even-aligned VGPR pair (re, im) and is processed with VOP3P packed
+// f32 instructions, two flops per lane per instruction.  Measured on gfx950 (tools/ubench3.hip):
+// v_pk_add_f32 issues in 5.7 cycles per wave-instruction at 2 waves/SIMD against 3.9 for v_add_f32,
+// i.e. 27 % fewer issue cycles per complex add.  The swizzles a radix-4 butterfly needs (multiply by
+// -i / +i, complex multiply) are expressed with op_sel / neg modifiers, which the compiler's SLP
+// packer does not find (it pays ~30 % v_mov to pair registers instead — hence -fno-slp-vectorize).
+typedef float v2f __attribute__((ext_vector_type(2)));
+// a - i b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ v2f pk_sub_ib(v2f a, v2f b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + i b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ v2f pk_add_ib(v2f a, v2f b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a * w (complex): m = (a.y w.y, a.y w.x); r = (a.x w.x - m.x, a.x w.y + m.y)
+__device__ __forceinline__ v2f pk_cmul(v2f a, v2f w)
+{
+    v2f m, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(m) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,0]"
+        : "=v"(r) : "v"(a), "v"(w), "v"(m));
+    return r;
+}
+// (a.x + a.y, a.y - a.x) = a - i a      [times R gives a * W16^2]
+__device__ __forceinline__ v2f pk_w2pre(v2f a) { return pk_sub_ib(a, a); }
+// (a.y - a.x, -(a.x + a.y))             [times R gives a * W16^6]
+__device__ __forceinline__ v2f pk_w6pre(v2f a)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(r) : "v"(a));
+    return r;
+}
+// a * (-i) = (a.y, -a.x)
+__device__ __forceinline__ v2f pk_mul_mi(v2f a)
+{
+    v2f r;
+    const v2f zero = {0.0f, 0.0f};
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(zero), "v"(a));
+    return r;
+}
+
+// forward radix-4 butterfly on (a0,a1,a2,a3) in place: A_k = sum_j a_j (-i)^(jk)  — 8 packed adds
+__device__ __forceinline__ void radix4(v2f &a0, v2f &a1, v2f &a2, v2f &a3)
+{
+    const v2f t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = a1 - a3;
+    a0 = t0 + t2;
+    a2 = t0 - t2;
+    a1 = pk_sub_ib(t1, t3);   // t1 - i t3
+    a3 = pk_add_ib(t1, t3);   // t1 + i t3
+}
+
+// Forward 16-point DFT in registers (81 packed instructions).  Input a[j] natural order; output
+// X[k] is left in a[R16(k)] with R16(k) = ((k & 3) << 2) | (k >> 2).
+#define R16(k) ((((k) & 3) << 2) | ((k) >> 2))
+__device__ __forceinline__ void fft16(v2f (&a)[16])
+{
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R = 0.70710678118654752f;
+    const v2f w1 = {C1, -S1}, w3 = {S1, -C1}, w9 = {-C1, S1};
+    // stage 1: 4-point DFTs over q of a[r + 4q]; result p lands in a[r + 4p]
+    radix4(a[0], a[4], a[8], a[12]);
+    radix4(a[1], a[5], a[9], a[13]);
+    radix4(a[2], a[6], a[10], a[14]);
+    radix4(a[3], a[7], a[11], a[15]);
+    // twiddle a[r + 4p] *= W16^(r p)
+    a[5] = pk_cmul(a[5], w1);            // r=1,p=1: W^1
+    a[9] = pk_w2pre(a[9]) * R;           // r=1,p=2: W^2
+    a[13] = pk_cmul(a[13], w3);          // r=1,p=3: W^3
+    a[6] = pk_w2pre(a[6]) * R;           // r=2,p=1: W^2
+    a[10] = pk_mul_mi(a[10]);            // r=2,p=2: W^4 = -i
+    a[14] = pk_w6pre(a[14]) * R;         // r=2,p=3: W^6 = (-R,-R)
+    a[7] = pk_cmul(a[7], w3);            // r=3,p=1: W^3
+    a[11] = pk_w6pre(a[11]) * R;         // r=3,p=2: W^6
+    a[15] = pk_cmul(a[15], w9);          // r=3,p=3: W^9 = (-C1, +S1)
+    // stage 2: 4-point DFTs over r of a[r + 4p]; result s lands in a[s + 4p] = X[p + 4s]
+    radix4(a[0], a[1], a[2], a[3]);
+    radix4(a[4], a[5], a[6], a[7]);
+    radix4(a[8], a[9], a[10], a[11]);
+    radix4(a[12], a[13], a[14], a[15]);
+}
+
+// dB of a squared magnitude q with dB = 10*log10(2)*log2(q) + off; q == 0 -> -150
+// (scale_to_dbfs, analyzer.rs:11-27: val == 0.0 => -150.0)
+__device__ __forceinline__ float db_from_sq(float q, float off)
+{
+    float r = fmaf(__log2f(q), 3.01029995663981195f, off);
+    return q == 0.0f ? -150.0f : r;
+}
+
+// ============================================================================
+//  Spectrum, N = 4096, stereo -> mid/side packed as one complex FFT.
+//
+//  z[n] = (mid[n] + i side[n]) * hann[n];  Z = FFT_4096(z);
+//  M[k] = (Z[k] + conj Z[N-k]) / 2,  S[k] = (Z[k] - conj Z[N-k]) / (2i).
+//  4096 = 16 x 16 x 16: three register-resident radix-16 passes, two full LDS
+//  exchanges plus a half-size mirror exchange.  256 threads = one window at a
+//  time; a workgroup walks `windows_per_block` consecutive windows of one
+//  stream and keeps the raw samples in registers, so with hop = 256*HS each
+//  sample is fetched from HBM once per workgroup (HS new slots per window).
+//
+//  Index algebra (n = t + 256 j, t = tb + 16 ta, k = ka + 16 kb + 256 kc):
+//   P1: A[ka]  = sum_j  z[t+256j] W16^(j ka)            ; *= W4096^(t ka)
+//   P2: B[kb]  = sum_ta A'[ka; tb+16ta] W16^(ta kb)     ; *= W256^(tb kb)
+//   P3: Z[ka+16kb+256kc] = sum_tb B'[ka,kb; tb] W16^(tb kc)
+//  Thread roles: P1 thread = t; P2 thread = tb + 16 ka; P3 thread = ka + 16 kb,
+//  which then owns bins v + 256 kc — stride-256, so output stores coalesce and
+//  the mirror bin N-k lives at thread 256-v, slot 15-kc.
+// ============================================================================
+constexpr int kX1Stride = 272;   // anyhop kernel: 256 + 16 de-phases the 4 ka-groups of a wave across banks
+constexpr int kX2Stride = 17;    // anyhop kernel: row of 16 padded to 17, conflict-free b64 row reads
+// pair kernel: both exchanges store rows of 16 complex padded to 18 (144 B): the reader's row is
+// 16-B aligned and contiguous (8 x ds_read_b128), 16-lane write groups and 16-lane read groups both
+// land on 16 distinct 4-bank slots (36*i mod 64 is a permutation of the multiples of 4).
+constexpr int kRow = 18;
+constexpr int kPlane = 16 * kRow;   // 288 complex per outer index; 16 planes = 4608 complex = 36864 B
+
+// Published spectrum layout: bin k lives at k with bit 1 flipped when bit 6 is set.  A lane that owns four
+// consecutive bins reads them as two aligned 16-byte pairs; the flip spreads the 16-lane groups of
+// ds_read_b128 (and the 32-lane groups of the mirror's ds_read_b64) over distinct banks, while the
+// publishing writes (16 consecutive k per 16-lane group) stay conflict-free.
+#define SPEC_POS(k) ((k) ^ ((((k) >> 6) & 1) << 1))
+
+// dB epilogue of one window.  xb holds the full spectrum Z[0..4095] in that order; a thread
+// owns groups of FOUR consecutive retained bins (g = t, t + 256), so both output rows are written
+// with 16-byte stores (rows are padded to a multiple of 4 floats): the 4-byte-per-lane stores of
+// a stride-256 ownership were store-issue bound (1.6 ms of 4.7 ms at the config-3 size).
+__device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t first_bin, uint32_t n_bins,
+                                                 float db_offset, const float *__restrict__ offpink,
+                                                 float *o_mid, float *o_side)
+{
+    const uint32_t ngroups = (n_bins + 3) >> 2;
+    // dB = 10 log10(2) * log2(q) + (db_offset + pink[bin]); an exact zero reads -150 (+ pink): feed the
+    // fma the log value that lands on -150 instead of selecting afterwards (one instruction less per bin)
+    constexpr float kDb = 3.01029995663981195f;
+    const float lg0 = (-150.0f - db_offset) / kDb;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const uint32_t g = (uint32_t)t + 256u * i;
+        if (g < ngroups) {
+            const uint32_t k0 = first_bin + 4 * g;
+            const float4 op = *reinterpret_cast<const float4 *>(offpink + 4 * g);   // table padded to the row stride
+            const float opv[4] = {op.x, op.y, op.z, op.w};
+            float rm[4], rs[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t k = k0 + e;                       // k <= 2051 < 4096: the mirror index stays positive
+                const v2f zk = xb[SPEC_POS(k)];
+                const v2f zm = xb[SPEC_POS(4096 - k)];           // Z[N - k]
+                v2f m2, s2;                                      // 2*M = (zk.x+zm.x, zk.y-zm.y); 2*S ~ (zk.y+zm.y, zk.x-zm.x)
+                asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,0] neg_hi:[0,1]" : "=v"(m2) : "v"(zk), "v"(zm));
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(s2) : "v"(zk), "v"(zm));
+                const float qm = fmaf(m2.x, m2.x, m2.y * m2.y);
+                const float qs = fmaf(s2.x, s2.x, s2.y * s2.y);
+                rm[e] = fmaf(qm == 0.0f ? lg0 : __log2f(qm), kDb, opv[e]);
+                rs[e] = fmaf(qs == 0.0f ? lg0 : __log2f(qs), kDb, opv[e]);
+            }
+#if defined(SS_ABL) && SS_ABL == 1      /* ablation: no output stores */
+            asm volatile("" ::"v"(rm[0]), "v"(rm[1]), "v"(rm[2]), "v"(rm[3]), "v"(rs[0]), "v"(rs[1]), "v"(rs[2]), "v"(rs[3]));
+            (void)o_mid; (void)o_side;
+#else
+            reinterpret_cast<float4 *>(o_mid)[g] = make_float4(rm[0], rm[1], rm[2], rm[3]);
+            reinterpret_cast<float4 *>(o_side)[g] = make_float4(rs[0], rs[1], rs[2], rs[3]);
+#endif
+        }
+    }
+}
+
+// HS = hop / 256.  A workgroup iteration transforms TWO consecutive windows: they share the
+// sliding sample registers (16 + HS slots) and every per-thread constant, and every barrier
+// phase carries two independent radix-16 problems (half the barriers per window, twice the
+// instruction-level parallelism to cover LDS latency).
+#if defined(SS_ABL) && SS_ABL == 4      /* ablation: no butterflies */
+#define SS_FFT16(z) asm volatile("" : "+v"(z[0]), "+v"(z[5]), "+v"(z[10]), "+v"(z[15]))
+#else
+#define SS_FFT16(z) fft16(z)
+#endif
+#if defined(SS_ABL) && SS_ABL == 5      /* ablation: no barriers (racy, timing only) */
+#define SS_SYNC() __builtin_amdgcn_wave_barrier()
+#else
+#define SS_SYNC() __syncthreads()
+#endif
+template <int HS>
+__global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams p)
+{
+    constexpr int NS = 16 + HS;                                              // sample slots held
+    __shared__ __attribute__((aligned(16))) v2f xbuf[2][16 * kPlane];     // 2 x 36864 B
+    // exchange 1: element (ka; tb, ta) at ka*272 + (tb + 16 ta): lane-linear b64 writes; the reader's 4
+    // ka-groups per wave are de-phased by the +16 pad (conflict-free b64 reads)
+#define X1W(ka, tb_, ta_) ((ka) * kX1Stride + (tb_) + 16 * (ta_))
+    // exchange 2: element (kb, ka; tb) in rows of 16 padded to 18 (144 B): contiguous b64 writes, and the
+    // reader's row is 16-B aligned and contiguous (8 x ds_read_b128; 36*i mod 64 is a permutation of the
+    // multiples of 4, so every 16-lane read group hits 16 distinct 4-bank slots)
+#define X2W(kb, ka_, tb_) ((kb) * kPlane + (ka_) * kRow + (tb_))
+    __shared__ __attribute__((aligned(16))) v2f tw2s[256];                //  2048 B
+
+    const int t = threadIdx.x;
+    const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
+    const uint32_t stream = blockIdx.x / groups;
+    const uint32_t grp = blockIdx.x - stream * groups;
+    const uint32_t w_begin = grp * p.windows_per_block;
+    uint32_t w_end = w_begin + p.windows_per_block;
+    const uint32_t n_win = p.windows_of ? p.windows_of[stream] : p.n_windows;     // ragged batches: this stream's own count
+    if (w_begin >= n_win) return;
+    if (w_end > n_win) w_end = n_win;
+
+    const float2 *src = reinterpret_cast<const float2 *>(p.pcm) + (size_t)stream * p.frames_per_stream +
+                        p.first_start + (size_t)w_begin * p.hop;
+
+    // per-thread constants, resident across the window loop
+    float hw[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) hw[j] = p.half_window[t + 256 * j];
+    v2f tw1[16];
+#pragma unroll
+    for (int ka = 1; ka < 16; ka++) tw1[ka] = reinterpret_cast<const v2f *>(p.tw_n)[t * ka];
+    tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[t];
+
+    const int tb = t & 15, hi = t >> 4;
+    const int tsw = SPEC_POS(t);
+    const size_t out_win_stride = (size_t)2 * p.bin_stride;
+    float *outp = p.out + ((size_t)stream * p.n_windows + w_begin) * out_win_stride;
+
+    // raw sums / differences of frame t + 256 j of the first window: (l + r, l - r)
+    float sm[NS], df[NS];
+    const bool two0 = (w_begin + 1 < w_end);
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+        float2 v = make_float2(0.f, 0.f);
+        if (j < 16 || two0) v = src[t + 256 * j];
+        sm[j] = v.x + v.y;
+        df[j] = v.x - v.y;
+    }
+
+    for (uint32_t w = w_begin; w < w_end; w += 2) {
+        const bool two = (w + 1 < w_end);
+        // prefetch the 2*HS new slots of the next pair (consumed after the epilogue)
+        float2 nx[2 * HS];
+        const bool more = (w + 2 < w_end), more2 = (w + 3 < w_end);
+        const float2 *nsrc = src + (size_t)(w - w_begin) * p.hop + t;
+#pragma unroll
+        for (int q = 0; q < 2 * HS; q++) {
+            nx[q] = make_float2(0.f, 0.f);
+            if (q < HS ? more : more2) nx[q] = nsrc[256 * (NS + q)];
+        }
+
+        // Every exchange is ordered  [reads] barrier [butterflies of window 0] [writes 0]
+        // [butterflies of window 1] [writes 1] barrier [reads]:  the write-after-read barrier sits
+        // right behind the reads, so one window's LDS writes drain while the other's butterflies issue.
+        v2f z0[16], z1[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) z0[j] = v2f{sm[j] * hw[j], df[j] * hw[j]};
+        // ---- pass 1 (the loop-end barrier has retired the previous pair's epilogue reads)
+        SS_FFT16(z0);
+        xbuf[0][X1W(0, tb, hi)] = z0[R16(0)];
+#pragma unroll
+        for (int ka = 1; ka < 16; ka++) xbuf[0][X1W(ka, tb, hi)] = pk_cmul(z0[R16(ka)], tw1[ka]);
+#pragma unroll
+        for (int j = 0; j < 16; j++) z1[j] = v2f{sm[j + HS] * hw[j], df[j + HS] * hw[j]};
+        SS_FFT16(z1);
+        xbuf[1][X1W(0, tb, hi)] = z1[R16(0)];
+#pragma unroll
+        for (int ka = 1; ka < 16; ka++) xbuf[1][X1W(ka, tb, hi)] = pk_cmul(z1[R16(ka)], tw1[ka]);
+        SS_SYNC();
+        // ---- pass 2 (thread = tb + 16 ka)
+#pragma unroll
+        for (int ta = 0; ta < 16; ta++) {
+            z0[ta] = xbuf[0][X1W(hi, tb, ta)];
+            z1[ta] = xbuf[1][X1W(hi, tb, ta)];
+        }
+        SS_SYNC();
+        SS_FFT16(z0);
+        xbuf[0][X2W(0, hi, tb)] = z0[R16(0)];
+#pragma unroll
+        for (int kb = 1; kb < 16; kb++) xbuf[0][X2W(kb, hi, tb)] = pk_cmul(z0[R16(kb)], tw2s[tb * kb]);
+        SS_FFT16(z1);
+        xbuf[1][X2W(0, hi, tb)] = z1[R16(0)];
+#pragma unroll
+        for (int kb = 1; kb < 16; kb++) xbuf[1][X2W(kb, hi, tb)] = pk_cmul(z1[R16(kb)], tw2s[tb * kb]);
+        SS_SYNC();
+        // ---- pass 3 (thread = ka + 16 kb): ka = tb, kb = hi
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            z0[q] = xbuf[0][X2W(hi, tb, q)];
+            z1[q] = xbuf[1][X2W(hi, tb, q)];
+        }
+        SS_SYNC();
+        SS_FFT16(z0);
+        // ---- publish the whole spectrum in (swizzled) natural order: Z[t + 256 kc] at SPEC_POS(k)
+#pragma unroll
+        for (int kc = 0; kc < 16; kc++) xbuf[0][kc * 256 + tsw] = z0[R16(kc)];
+        SS_FFT16(z1);
+#pragma unroll
+        for (int kc = 0; kc < 16; kc++) xbuf[1][kc * 256 + tsw] = z1[R16(kc)];
+        SS_SYNC();
+        // ---- epilogue: groups of four consecutive bins per thread, 16-byte stores
+        float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
+        fft4096_epilogue(xbuf[0], t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride);
+        if (two) fft4096_epilogue(xbuf[1], t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid + out_win_stride,
+                                  o_mid + out_win_stride + p.bin_stride);
+        // ---- slide the sample registers by two hops
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < NS - 2 * HS; j++) { sm[j] = sm[j + 2 * HS]; df[j] = df[j + 2 * HS]; }
+#pragma unroll
+            for (int q = 0; q < 2 * HS; q++) {
+                if (NS - 2 * HS + q >= 0) { sm[NS - 2 * HS + q] = nx[q].x + nx[q].y; df[NS - 2 * HS + q] = nx[q].x - nx[q].y; }
+            }
+        }
+        SS_SYNC();                             // epilogue reads are done before the next pair's pass-1 writes
+    }
+}
+#undef X1W
+#undef X2W
+
+// Single-window variant (one window per iteration): built for occupancy — three (TW6: four) workgroups
+// per CU instead of two.  With TW6 the 15 pass-1 twiddles W^(t ka) are rebuilt from six resident ones,
+// W^(t ka) = W^(t (ka & 3)) * W^(t (ka & 12)), at the price of 9 extra complex multiplies per window.
+#ifndef SS_FFT1_WAVES
+#define SS_FFT1_WAVES 3
+#endif
+// Wave priority by phase: a wave that is exchanging through LDS (writes, barrier, reads) runs at raised priority so
+// its few LDS instructions issue ahead of the other workgroups' butterflies; measured 3.15 -> 3.05 ms (A/B in one process)
+#ifndef SS_FFT_PRIO
+#define SS_FFT_PRIO 3
+#endif
+#if SS_FFT_PRIO > 0
+#define SS_PRIO_HI() __builtin_amdgcn_s_setprio(SS_FFT_PRIO)
+#define SS_PRIO_LO() __builtin_amdgcn_s_setprio(0)
+#else
+#define SS_PRIO_HI()
+#define SS_PRIO_LO()
+#endif
+#if defined(SS_FFT_PRIO_EPI)
+#define SS_PRIO_EPI() 
+#else
+#define SS_PRIO_EPI() SS_PRIO_LO()
+#endif
+template <int HS, bool TW6>
+__global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchParams p)
+{
+    __shared__ __attribute__((aligned(16))) v2f xbuf[16 * kPlane];        // 36864 B
+    __shared__ __attribute__((aligned(16))) v2f tw2s[256];                //  2048 B
+#define X1W(ka, tb_, ta_) ((ka) * kX1Stride + (tb_) + 16 * (ta_))
+#define X2W(kb, ka_, tb_) ((kb) * kPlane + (ka_) * kRow + (tb_))
+    const int t = threadIdx.x;
+    const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
+    const uint32_t stream = blockIdx.x / groups;
+    const uint32_t grp = blockIdx.x - stream * groups;
+    const uint32_t w_begin = grp * p.windows_per_block;
+    uint32_t w_end = w_begin + p.windows_per_block;
+    const uint32_t n_win = p.windows_of ? p.windows_of[stream] : p.n_windows;     // ragged batches: this stream's own count
+    if (w_begin >= n_win) return;
+    if (w_end > n_win) w_end = n_win;
+    const float2 *src = reinterpret_cast<const float2 *>(p.pcm) + (size_t)stream * p.frames_per_stream +
+                        p.first_start + (size_t)w_begin * p.hop;
+    const v2f *twn = reinterpret_cast<const v2f *>(p.tw_n);
+    float hw[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) hw[j] = p.half_window[t + 256 * j];
+    v2f tw1[16];
+    if (TW6) {
+        tw1[1] = twn[t]; tw1[2] = twn[2 * t]; tw1[3] = twn[3 * t];
+        tw1[4] = twn[4 * t]; tw1[8] = twn[8 * t]; tw1[12] = twn[12 * t];
+    } else {
+#pragma unroll
+        for (int ka = 1; ka < 16; ka++) tw1[ka] = twn[t * ka];
+    }
+    tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[t];
+    const int tb = t & 15, hi = t >> 4;
+    const int tsw = SPEC_POS(t);
+    const size_t out_win_stride = (size_t)2 * p.bin_stride;
+    float *outp = p.out + ((size_t)stream * p.n_windows + w_begin) * out_win_stride;
+    float sm[16], df[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const float2 v = src[t + 256 * j];
+        sm[j] = v.x + v.y;
+        df[j] = v.x - v.y;
+    }
+    __syncthreads();
+    for (uint32_t w = w_begin; w < w_end; ++w) {
+        float2 nx[HS];
+        const bool more = (w + 1 < w_end);
+#pragma unroll
+        for (int q = 0; q < HS; q++) {
+            nx[q] = make_float2(0.f, 0.f);
+            if (more) nx[q] = src[(size_t)(w + 1 - w_begin) * p.hop + t + 256 * (16 - HS + q)];
+        }
+        v2f z[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) z[j] = v2f{sm[j] * hw[j], df[j] * hw[j]};
+        SS_PRIO_LO();
+        fft16(z);
+        SS_PRIO_HI();
+        xbuf[X1W(0, tb, hi)] = z[R16(0)];
+#pragma unroll
+        for (int ka = 1; ka < 16; ka++) {
+            v2f v = z[R16(ka)];
+            if (TW6) {
+                if (ka & 3) v = pk_cmul(v, tw1[ka & 3]);
+                if (ka & 12) v = pk_cmul(v, tw1[ka & 12]);
+            } else {
+                v = pk_cmul(v, tw1[ka]);
+            }
+            xbuf[X1W(ka, tb, hi)] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ta = 0; ta < 16; ta++) z[ta] = xbuf[X1W(hi, tb, ta)];
+        __syncthreads();
+        SS_PRIO_LO();
+        fft16(z);
+        SS_PRIO_HI();
+        xbuf[X2W(0, hi, tb)] = z[R16(0)];
+#pragma unroll
+        for (int kb = 1; kb < 16; kb++) xbuf[X2W(kb, hi, tb)] = pk_cmul(z[R16(kb)], tw2s[tb * kb]);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; q++) z[q] = xbuf[X2W(hi, tb, q)];
+        __syncthreads();
+        SS_PRIO_LO();
+        fft16(z);
+        SS_PRIO_HI();
+#pragma unroll
+        for (int kc = 0; kc < 16; kc++)
+            if ((p.publish_mask >> kc) & 1u) xbuf[kc * 256 + tsw] = z[R16(kc)];   // blocks with no retained bin or mirror are skipped
+        __syncthreads();
+        SS_PRIO_EPI();
+        float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
+        fft4096_epilogue(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride);
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 16 - HS; j++) { sm[j] = sm[j + HS]; df[j] = df[j + HS]; }
+#pragma unroll
+            for (int q = 0; q < HS; q++) { sm[16 - HS + q] = nx[q].x + nx[q].y; df[16 - HS + q] = nx[q].x - nx[q].y; }
+        }
+        __syncthreads();
+    }
+#undef X1W
+#undef X2W
+}
+
+// generic hop (not a multiple of 256 or >= N/2 slots): one window per iteration, full reload
+__global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms_anyhop(FftBatchParams p)
+{
+    __shared__ __attribute__((aligned(16))) v2f xbuf[16 * kX1Stride];
+    __shared__ __attribute__((aligned(16))) v2f tw2s[256];
+    const int t = threadIdx.x;
+    const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
+    const uint32_t stream = blockIdx.x / groups;
+    const uint32_t grp = blockIdx.x - stream * groups;
+    const uint32_t w_begin = grp * p.windows_per_block;
+    uint32_t w_end = w_begin + p.windows_per_block;
+    const uint32_t n_win = p.windows_of ? p.windows_of[stream] : p.n_windows;     // ragged batches: this stream's own count
+    if (w_begin >= n_win) return;
+    if (w_end > n_win) w_end = n_win;
+    const float2 *src = reinterpret_cast<const float2 *>(p.pcm) + (size_t)stream * p.frames_per_stream +
+                        p.first_start + (size_t)w_begin * p.hop;
+    tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[t];
+    const int tb = t & 15, hi = t >> 4;
+    const size_t out_win_stride = (size_t)2 * p.bin_stride;
+    float *outp = p.out + ((size_t)stream * p.n_windows + w_begin) * out_win_stride;
+    for (uint32_t w = w_begin; w < w_end; ++w) {
+        v2f z[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const float2 v = src[(size_t)(w - w_begin) * p.hop + t + 256 * j];
+            const float hwj = p.half_window[t + 256 * j];
+            z[j] = v2f{(v.x + v.y) * hwj, (v.x - v.y) * hwj};
+        }
+        fft16(z);
+        __syncthreads();
+        xbuf[t] = z[R16(0)];
+#pragma unroll
+        for (int ka = 1; ka < 16; ka++) xbuf[ka * kX1Stride + t] = pk_cmul(z[R16(ka)], reinterpret_cast<const v2f *>(p.tw_n)[t * ka]);
+        __syncthreads();
+#pragma unroll
+        for (int ta = 0; ta < 16; ta++) z[ta] = xbuf[hi * kX1Stride + tb + 16 * ta];
+        fft16(z);
+        __syncthreads();
+        xbuf[hi * kX2Stride + tb] = z[R16(0)];
+#pragma unroll
+        for (int kb = 1; kb < 16; kb++) xbuf[kb * kX1Stride + hi * kX2Stride + tb] = pk_cmul(z[R16(kb)], tw2s[tb * kb]);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; q++) z[q] = xbuf[hi * kX1Stride + tb * kX2Stride + q];
+        fft16(z);
+        __syncthreads();
+#pragma unroll
+        for (int kc = 0; kc < 16; kc++) xbuf[kc * 256 + SPEC_POS(t)] = z[R16(kc)];
+        __syncthreads();
+        float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
+        fft4096_epilogue(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride);
+    }
+}
+
+// ============================================================================
+//  Spectrum, N = 16384 (the reference's native window, tui.rs:1488), one REAL channel per
+//  512-thread workgroup: real FFT through an 8192-point complex FFT, split by one radix-2
+//  decimation-in-frequency step into two 4096-point problems that reuse the radix-16 machinery:
+//    z[i] = (xw[2i], xw[2i+1]),  y_q[i] = (z[i] + (-1)^q z[i+4096]) W_8192^(i q),  Z[2k+q] = FFT_4096(y_q)[k]
+//    X[b] = (Z[b] + conj Z[8192-b])/2 - (i/2) W_16384^b (Z[b] - conj Z[8192-b])
+//  Threads 0-255 run q = 0, threads 256-511 run q = 1; the mirror 8192-b has the parity of b, so each
+//  half only mirrors inside its own published spectrum.  mode 0: mono buffer, 1: stereo -> mid/side
+//  (audio_player.rs:400-419), 2: channel `ch` of an interleaved buffer.
+// ============================================================================
+__global__ __launch_bounds__(512, 2) void k_fft16k(FftBatchParams p, int midside, uint32_t fft_ch)
+{
+    __shared__ __attribute__((aligned(16))) v2f xbuf2[2][16 * kPlane];       // 2 x 36864 B
+    __shared__ __attribute__((aligned(16))) v2f tw2s[256];
+#define X1W(ka, tb_, ta_) ((ka) * kX1Stride + (tb_) + 16 * (ta_))
+#define X2W(kb, ka_, tb_) ((kb) * kPlane + (ka_) * kRow + (tb_))
+    const int q = threadIdx.x >> 8;                 // which half-problem
+    const int t = threadIdx.x & 255;
+    v2f *xbuf = xbuf2[q];
+    uint32_t bid = blockIdx.x;
+    const uint32_t ch = bid % fft_ch; bid /= fft_ch;
+    const uint32_t w = bid % p.n_windows;
+    const uint32_t stream = bid / p.n_windows;
+    if (p.windows_of && w >= p.windows_of[stream]) return;                          // ragged batches
+    const size_t start = p.first_start + (size_t)w * p.hop;
+    const float *base = p.pcm + ((size_t)stream * p.frames_per_stream + start) * p.channels;
+    const v2f *tw16k = reinterpret_cast<const v2f *>(p.tw_n);       // W_16384^k, k < 8192
+    const v2f *tw4k = reinterpret_cast<const v2f *>(p.tw_core);     // W_4096^k
+    if (threadIdx.x < 256) tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[t];
+
+    // windowed real samples 2i, 2i+1 as one complex value
+    auto zload = [&](uint32_t i) -> v2f {
+        float x0, x1;
+        if (midside) {
+            const float2 va = reinterpret_cast<const float2 *>(base)[2 * (size_t)i];       // frames 2i, 2i+1: (l,r)
+            const float2 vb = reinterpret_cast<const float2 *>(base)[2 * (size_t)i + 1];
+            x0 = ch == 0 ? (va.x + va.y) * 0.5f : (va.x - va.y) * 0.5f;
+            x1 = ch == 0 ? (vb.x + vb.y) * 0.5f : (vb.x - vb.y) * 0.5f;
+        } else {
+            x0 = base[(size_t)(2 * i) * p.channels + ch];       // mono buffers have fft_ch == 1 => ch == 0
+            x1 = base[(size_t)(2 * i + 1) * p.channels + ch];
+        }
+        const float2 hw = *reinterpret_cast<const float2 *>(p.window + 2 * (size_t)i);
+        return v2f{x0 * hw.x, x1 * hw.y};
+    };
+    v2f z[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint32_t i = (uint32_t)t + 256u * j;
+        const v2f a = zload(i), b = zload(i + 4096u);
+        z[j] = q ? pk_cmul(a - b, tw16k[2 * i]) : a + b;             // W_8192^i = W_16384^(2i)
+    }
+    const int tb = t & 15, hi = t >> 4;
+    // ---- the 4096-point transform of y_q (same passes and LDS layouts as k_fft4096_ms)
+    // pass-1 twiddles W^(t ka) from six gathered ones: W^(t ka) = W^(t (ka & 3)) * W^(t (ka & 12))
+    // (scattered 8-byte gathers are the expensive part of this one-window-per-workgroup kernel)
+    v2f twg[16];
+    twg[1] = tw4k[t]; twg[2] = tw4k[2 * t]; twg[3] = tw4k[3 * t];
+    twg[4] = tw4k[4 * t]; twg[8] = tw4k[8 * t]; twg[12] = tw4k[12 * t];
+    fft16(z);
+    xbuf[X1W(0, tb, hi)] = z[R16(0)];
+#pragma unroll
+    for (int ka = 1; ka < 16; ka++) {
+        v2f v = z[R16(ka)];
+        if (ka & 3) v = pk_cmul(v, twg[ka & 3]);
+        if (ka & 12) v = pk_cmul(v, twg[ka & 12]);
+        xbuf[X1W(ka, tb, hi)] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ta = 0; ta < 16; ta++) z[ta] = xbuf[X1W(hi, tb, ta)];
+    __syncthreads();
+    fft16(z);
+    xbuf[X2W(0, hi, tb)] = z[R16(0)];
+#pragma unroll
+    for (int kb = 1; kb < 16; kb++) xbuf[X2W(kb, hi, tb)] = pk_cmul(z[R16(kb)], tw2s[tb * kb]);
+    __syncthreads();
+#pragma unroll
+    for (int qq = 0; qq < 16; qq++) z[qq] = xbuf[X2W(hi, tb, qq)];
+    __syncthreads();
+    fft16(z);
+    // publish Z_q[k] = Z[2k + q] at position k (natural order)
+#pragma unroll
+    for (int kc = 0; kc < 16; kc++) xbuf[kc * 256 + t] = z[R16(kc)];
+    __syncthreads();
+    // ---- real-FFT recombination + dB for the retained bins; consecutive threads own consecutive bins
+    float *o = p.out + (((size_t)stream * p.n_windows + w) * fft_ch + ch) * p.bin_stride;
+    for (uint32_t idx = threadIdx.x; idx < p.n_bins; idx += 512u) {
+        const uint32_t b = p.first_bin + idx;
+        float xr, xi;
+        if (b == 8192u) {                                           // Nyquist of the real signal
+            const v2f z0 = xbuf2[0][0];
+            xr = z0.x - z0.y; xi = 0.0f;
+        } else {
+            const uint32_t qb = b & 1u, k = b >> 1;
+            const uint32_t km = qb ? (4095u - k) : ((4096u - k) & 4095u);   // index of Z[8192 - b] in its half
+            const v2f zk = xbuf2[qb][k];
+            const v2f zc = xbuf2[qb][km];
+            const float sr = (zk.x + zc.x) * 0.5f, si = (zk.y - zc.y) * 0.5f;
+            const float dr = (zk.x - zc.x) * 0.5f, di = (zk.y + zc.y) * 0.5f;
+            const v2f wv = tw16k[b];
+            const float tr = wv.x * dr - wv.y * di;
+            const float ti = wv.x * di + wv.y * dr;
+            xr = sr + ti;
+            xi = si - tr;
+        }
+        const float qv = fmaf(xr, xr, xi * xi);
+        float r = fmaf(__log2f(qv), 3.01029995663981195f, p.db_offset);
+        r = (qv == 0.0f) ? -150.0f : r;
+        o[idx] = r + (p.pink ? p.pink[idx] : 0.0f);
+    }
+#undef X1W
+#undef X2W
+}
+
+// ============================================================================
+//  Spectrum, N = 16384 at hop 1024 for batches: one REAL channel per 512-thread workgroup that walks
+//  `windows_per_block` consecutive windows with sliding sample registers (hop 1024 samples = one slot,
+//  so a sample is fetched once per run instead of 16 times) and window weights rebuilt from two
+//  resident twiddles, w[n0 + 1024 j] = 1/2 - 1/2 cos(a0 + j pi/8).
+//  Decimation in time by four:  X[b] = A0[b] + W^b A1[b] + W^2b A2[b] + W^3b A3[b],  W = W_16384,
+//  A_r = FFT_4096 of the real sequence xw[4i + r].  Half q (both are carried by every thread) transforms the complex
+//  sequence z_q[i] = (xw[4i + 2q], xw[4i + 2q + 1]) on the radix-16 passes of k_fft4096_ms1; A_{2q}, A_{2q+1}
+//  are its even / odd parts (the mid/side split of the N = 4096 kernel), combined per bin by Horner.
+//  The two halves never exchange data before the epilogue.  MODE 0: mono buffer or channel `ch` of an
+//  interleaved buffer, 1: stereo -> mid/side (audio_player.rs:400-419).
+// ============================================================================
+template <bool MIDSIDE>
+__global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_t fft_ch)
+{
+    __shared__ __attribute__((aligned(16))) v2f xbuf2[2][16 * kPlane];       // 2 x 36864 B
+    __shared__ __attribute__((aligned(16))) v2f tw2s[256];                    //  2048 B
+    __shared__ __attribute__((aligned(16))) float stage[4][256];              //  4096 B: 79872 B per workgroup, two per CU
+#define X1W(ka, tb_, ta_) ((ka) * kX1Stride + (tb_) + 16 * (ta_))
+#define X2W(kb, ka_, tb_) ((kb) * kPlane + (ka_) * kRow + (tb_))
+    const int t = threadIdx.x;
+    const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
+    // Workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.  The channels of one run read the
+    // same interleaved lines, so they must sit on ONE XCD: logical id = (id mod 8) * ceil(total / 8) + id / 8 makes
+    // the ids of an XCD consecutive (the launcher pads the grid to a multiple of 8; surplus ids leave).
+    const uint32_t per_xcd = gridDim.x >> 3;
+    uint32_t bid = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (bid >= p.n_streams * groups * fft_ch) return;
+    const uint32_t ch = bid % fft_ch; bid /= fft_ch;            // the channels of one run are neighbours in the logical order
+    const uint32_t grp = bid % groups;
+    const uint32_t stream = bid / groups;
+    const uint32_t w_begin = grp * p.windows_per_block;
+    uint32_t w_end = w_begin + p.windows_per_block;
+    const uint32_t n_win = p.windows_of ? p.windows_of[stream] : p.n_windows;     // ragged batches: this stream's own count
+    if (w_begin >= n_win) return;
+    if (w_end > n_win) w_end = n_win;
+    const uint32_t C = p.channels;
+    const float *base = p.pcm + ((size_t)stream * p.frames_per_stream + p.first_start + (size_t)w_begin * 1024u) * C;
+    const v2f *tw16k = reinterpret_cast<const v2f *>(p.tw_n);       // W_16384^k, k < 8192
+    const v2f *tw4k = reinterpret_cast<const v2f *>(p.tw_core);     // W_4096^k
+    tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[t];
+
+    // samples n .. n + 3 of this workgroup's channel (n relative to the run's first window): the two
+    // halves' complex inputs z_0 = (x[n], x[n+1]), z_1 = (x[n+2], x[n+3])
+    auto ld4 = [&](size_t n, v2f &z0, v2f &z1) {
+        if (MIDSIDE) {
+            const float2 *f = reinterpret_cast<const float2 *>(base) + n;
+            const float2 a = f[0], b = f[1], c = f[2], d = f[3];
+            if (ch == 0) { z0 = v2f{(a.x + a.y) * 0.5f, (b.x + b.y) * 0.5f}; z1 = v2f{(c.x + c.y) * 0.5f, (d.x + d.y) * 0.5f}; }
+            else { z0 = v2f{(a.x - a.y) * 0.5f, (b.x - b.y) * 0.5f}; z1 = v2f{(c.x - c.y) * 0.5f, (d.x - d.y) * 0.5f}; }
+        } else {
+            const float *f = base + n * C + ch;
+            z0 = v2f{f[0], f[C]};
+            z1 = v2f{f[2 * (size_t)C], f[3 * (size_t)C]};
+        }
+    };
+    const uint32_t n0 = 4u * (uint32_t)t;           // slot j holds samples n0 + 1024 j .. +3 of the current window
+    v2f raw0[16], raw1[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) ld4((size_t)n0 + 1024u * j, raw0[j], raw1[j]);
+    // Hann weights of slot j: angle a_e + j pi/8, a_e = 2 pi (n0 + e) / 16384, e = 0..3 (table holds (cos, -sin))
+    const v2f wa = tw16k[n0], wb = tw16k[n0 + 1], wc = tw16k[n0 + 2], wd = tw16k[n0 + 3];
+    const v2f hc0 = {-0.5f * wa.x, -0.5f * wb.x}, hs0 = {-0.5f * wa.y, -0.5f * wb.y};   // -1/2 cos a_e, +1/2 sin a_e
+    const v2f hc1 = {-0.5f * wc.x, -0.5f * wd.x}, hs1 = {-0.5f * wc.y, -0.5f * wd.y};
+    const v2f half = {0.5f, 0.5f};
+    v2f twg[16];
+    twg[1] = tw4k[t]; twg[2] = tw4k[2 * t]; twg[3] = tw4k[3 * t];
+    twg[4] = tw4k[4 * t]; twg[8] = tw4k[8 * t]; twg[12] = tw4k[12 * t];
+    const int tb = t & 15, hi = t >> 4;
+    const int tsw = SPEC_POS(t);
+    const uint32_t ngroups = (p.n_bins + 3) >> 2;
+    constexpr float kDb = 3.01029995663981195f;
+    const float off2 = p.db_offset - 6.02059991327962390f;      // the epilogue carries 2 X
+    __syncthreads();
+
+    for (uint32_t w = w_begin; w < w_end; ++w) {
+        const bool more = (w + 1 < w_end);
+        v2f nx0 = {0.0f, 0.0f}, nx1 = {0.0f, 0.0f};
+        if (more) ld4((size_t)(w + 1 - w_begin) * 1024u + n0 + 1024u * 15u, nx0, nx1);
+        // the two halves are independent problems: every barrier phase carries both (half the barriers
+        // per transform, two instruction streams to cover LDS latency)
+        v2f z0[16], z1[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            // cos(j pi/8), sin(j pi/8)
+            constexpr float cj[16] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.0f,
+                                      -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.0f,
+                                      -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f, 0.0f,
+                                      0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f};
+            constexpr float sj[16] = {0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f, 1.0f,
+                                      0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.0f,
+                                      -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.0f,
+                                      -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f};
+            // w = 1/2 - 1/2 (cos a cj - sin a sj)
+            z0[j] = raw0[j] * (half + hc0 * cj[j] + hs0 * sj[j]);
+            z1[j] = raw1[j] * (half + hc1 * cj[j] + hs1 * sj[j]);
+        }
+        fft16(z0);
+        xbuf2[0][X1W(0, tb, hi)] = z0[R16(0)];
+#pragma unroll
+        for (int ka = 1; ka < 16; ka++) {
+            v2f v = z0[R16(ka)];
+            if (ka & 3) v = pk_cmul(v, twg[ka & 3]);
+            if (ka & 12) v = pk_cmul(v, twg[ka & 12]);
+            xbuf2[0][X1W(ka, tb, hi)] = v;
+        }
+        fft16(z1);
+        xbuf2[1][X1W(0, tb, hi)] = z1[R16(0)];
+#pragma unroll
+        for (int ka = 1; ka < 16; ka++) {
+            v2f v = z1[R16(ka)];
+            if (ka & 3) v = pk_cmul(v, twg[ka & 3]);
+            if (ka & 12) v = pk_cmul(v, twg[ka & 12]);
+            xbuf2[1][X1W(ka, tb, hi)] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ta = 0; ta < 16; ta++) { z0[ta] = xbuf2[0][X1W(hi, tb, ta)]; z1[ta] = xbuf2[1][X1W(hi, tb, ta)]; }
+        __syncthreads();
+        fft16(z0);
+        xbuf2[0][X2W(0, hi, tb)] = z0[R16(0)];
+#pragma unroll
+        for (int kb = 1; kb < 16; kb++) xbuf2[0][X2W(kb, hi, tb)] = pk_cmul(z0[R16(kb)], tw2s[tb * kb]);
+        fft16(z1);
+        xbuf2[1][X2W(0, hi, tb)] = z1[R16(0)];
+#pragma unroll
+        for (int kb = 1; kb < 16; kb++) xbuf2[1][X2W(kb, hi, tb)] = pk_cmul(z1[R16(kb)], tw2s[tb * kb]);
+        __syncthreads();
+#pragma unroll
+        for (int qq = 0; qq < 16; qq++) { z0[qq] = xbuf2[0][X2W(hi, tb, qq)]; z1[qq] = xbuf2[1][X2W(hi, tb, qq)]; }
+        __syncthreads();
+        fft16(z0);
+#pragma unroll
+        for (int kc = 0; kc < 16; kc++) xbuf2[0][kc * 256 + tsw] = z0[R16(kc)];   // Z_q[k] at SPEC_POS(k)
+        fft16(z1);
+#pragma unroll
+        for (int kc = 0; kc < 16; kc++) xbuf2[1][kc * 256 + tsw] = z1[R16(kc)];
+        __syncthreads();
+
+        // ---- epilogue.  Iteration `it` covers 1024 retained bins, wave wv the 256 of them starting at
+        // 1024 it + 256 wv.  Reading: lane l takes bins +l, +64+l, +128+l, +192+l, so every LDS read of the two
+        // published spectra (and of their mirrors, descending) is stride-1 across the wave: conflict-free
+        // whatever first_bin is.  Writing: the four dB values go through a wave-private 1 KB staging row so
+        // that lane l stores bins +4l..+4l+3 with one 16-byte store.  From one iteration to the next the bin
+        // index grows by 1024: positions move by +-1024 (SPEC_POS only looks at bits 1 and 6), twiddles turn by W_16^1.
+        float *o = p.out + (((size_t)stream * p.n_windows + w) * fft_ch + ch) * p.bin_stride;
+        {
+            const uint32_t lane = (uint32_t)t & 63u, wv = (uint32_t)t >> 6;
+            float *stg = stage[wv];
+            uint32_t pb[4], pm[4];
+            v2f wt[4];
+            uint32_t fb = p.first_bin;
+            asm volatile("" : "+s"(fb));        // per-window recomputation: hoisting these 16 registers out of the loop spills
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t b = fb + 256u * wv + 64u * e + lane;
+                const uint32_t bq = b & 4095u, mq = (4096u - bq) & 4095u;
+                pb[e] = SPEC_POS(bq); pm[e] = SPEC_POS(mq);
+                wt[e] = tw16k[b & 8191u];
+            }
+            const v2f rho = {0.92387953251128674f, -0.38268343236508977f};
+            const uint32_t n_iter = (4u * ngroups + 1023u) >> 10;
+            for (uint32_t it = 0; it < n_iter; it++) {
+                float r[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const v2f e0 = xbuf2[0][pb[e]], em = xbuf2[0][pm[e]];
+                    const v2f o0 = xbuf2[1][pb[e]], om = xbuf2[1][pm[e]];
+                    v2f a0, a1, a2, a3;        // 2 A_r[b]
+                    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,0] neg_hi:[0,1]" : "=v"(a0) : "v"(e0), "v"(em));
+                    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[1,0]" : "=v"(a1) : "v"(e0), "v"(em));
+                    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,0] neg_hi:[0,1]" : "=v"(a2) : "v"(o0), "v"(om));
+                    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[1,0]" : "=v"(a3) : "v"(o0), "v"(om));
+                    v2f x = pk_cmul(a3, wt[e]) + a2;
+                    x = pk_cmul(x, wt[e]) + a1;
+                    x = pk_cmul(x, wt[e]) + a0;
+                    const float qv = fmaf(x.x, x.x, x.y * x.y);
+                    const float db = fmaf(__log2f(qv), kDb, off2);
+                    r[e] = qv == 0.0f ? -150.0f : db;
+                    pb[e] = (pb[e] + 1024u) & 4095u;
+                    pm[e] = (pm[e] - 1024u) & 4095u;
+                    wt[e] = pk_cmul(wt[e], rho);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) stg[64 * e + lane] = r[e];
+                __builtin_amdgcn_wave_barrier();                      // LDS is in order per wave: ordering is all that is needed
+                const float4 v = reinterpret_cast<const float4 *>(stg)[lane];
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t g = 256u * it + 64u * wv + lane;        // group of four bins this lane stores
+                if (g < ngroups) {
+                    float4 pk = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p.pink) pk = *reinterpret_cast<const float4 *>(p.pink + 4u * g);
+                    reinterpret_cast<float4 *>(o)[g] = make_float4(v.x + pk.x, v.y + pk.y, v.z + pk.z, v.w + pk.w);
+                }
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 15; j++) { raw0[j] = raw0[j + 1]; raw1[j] = raw1[j + 1]; }
+            raw0[15] = nx0; raw1[15] = nx1;
+        }
+        __syncthreads();                    // epilogue reads are done before the next window's pass-1 writes
+    }
+#undef X1W
+#undef X2W
+}
+
+// runs of windows at hop 1024 (batches); `mode` as launch_fft16k
+hipError_t launch_fft16k_run(FftBatchParams p, int mode, hipStream_t s)
+{
+    if (p.n_windows == 0 || p.n_streams == 0 || p.n_bins == 0) return hipSuccess;
+    const uint32_t fft_ch = (mode == 0) ? 1u : (mode == 1 ? 2u : p.channels);
+    // enough workgroups to fill 256 CUs x 2, runs of at least 16 windows (the run's first window costs a full load)
+    const uint64_t pairs = (uint64_t)p.n_streams * fft_ch;
+    uint32_t groups = (uint32_t)((4096 + pairs - 1) / pairs);
+    const uint32_t max_groups = p.n_windows / 16u ? p.n_windows / 16u : 1u;
+    if (groups > max_groups) groups = max_groups;
+    if (groups < 1) groups = 1;
+    p.windows_per_block = (p.n_windows + groups - 1) / groups;
+    groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
+    const dim3 grid((uint32_t)((pairs * groups + 7) & ~(uint64_t)7)), block(256);      // multiple of 8: see the XCD mapping in the kernel
+    if (mode == 1) hipLaunchKernelGGL(k_fft16k_run<true>, grid, block, 0, s, p, fft_ch);
+    else hipLaunchKernelGGL(k_fft16k_run<false>, grid, block, 0, s, p, fft_ch);
+    return hipGetLastError();
+}
+
+hipError_t launch_fft16k(const FftBatchParams &p, int mode, hipStream_t s)
+{
+    if (p.n_windows == 0 || p.n_streams == 0 || p.n_bins == 0) return hipSuccess;
+    const uint32_t fft_ch = (mode == 0) ? 1u : (mode == 1 ? 2u : p.channels);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft16k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 0);
+        (void)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_fft16k, dim3(p.n_streams * p.n_windows * fft_ch), dim3(512), 0, s, p, mode == 1 ? 1 : 0, fft_ch);
+    return hipGetLastError();
+}
+
+hipError_t launch_fft4096_ms(const FftBatchParams &p, hipStream_t s)
+{
+    if (p.n_windows == 0 || p.n_streams == 0) return hipSuccess;
+    const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
+    dim3 grid(groups * p.n_streams), block(256);
+    // hop 1024 (the reference's cadence): the single-window kernel at 3 workgroups per CU measured 2.5 %
+    // faster than the window-pair kernel at 2 (A/B in one process, 3.48 vs 3.57 ms); -DSS_FFT_PAIR selects the latter
+#if defined(SS_FFT_PAIR)
+    if (p.hop == 1024) hipLaunchKernelGGL(k_fft4096_ms<4>, grid, block, 0, s, p);
+#else
+    if (p.hop == 1024) hipLaunchKernelGGL((k_fft4096_ms1<4, true>), grid, block, 0, s, p);
+#endif
+    else if (p.hop == 512) hipLaunchKernelGGL(k_fft4096_ms<2>, grid, block, 0, s, p);
+    else if (p.hop == 2048) hipLaunchKernelGGL(k_fft4096_ms<8>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(k_fft4096_ms_anyhop, grid, block, 0, s, p);
+    return hipGetLastError();
+}
+
+// ============================================================================
+//  Spectrum, generic power-of-two N (2..32768), one real channel per workgroup:
+//  real FFT through an N/2-point complex FFT held in LDS (in-place radix-2
+//  decimation in frequency, bit-reversed read-out), then the same epilogue.
+//  Used by the single-window API (analyzer.rs:55-105 takes any power of two)
+//  and by batch shapes the specialised kernel does not cover.
+// ============================================================================
+__device__ __forceinline__ uint32_t bitrev(uint32_t v, int bits) { return bits ? (__brev(v) >> (32 - bits)) : 0u; }
+
+__global__ __launch_bounds__(256) void k_fft_generic(FftBatchParams p, int mode, int log2m)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 zs[];
+    const uint32_t n = p.n, m = n >> 1;
+    const uint32_t fft_ch = (mode == 0) ? 1u : (mode == 1 ? 2u : p.channels);
+    // block -> (stream, window, channel)
+    uint32_t bid = blockIdx.x;
+    const uint32_t ch = bid % fft_ch; bid /= fft_ch;
+    const uint32_t w = bid % p.n_windows;
+    const uint32_t stream = bid / p.n_windows;
+    if (p.windows_of && w >= p.windows_of[stream]) return;                          // ragged batches
+    const size_t start = p.first_start + (size_t)w * p.hop;
+    const float *base = p.pcm + ((size_t)stream * p.frames_per_stream + start) * p.channels;
+
+    auto sample = [&](uint32_t i) -> float {
+        if (mode == 1) {
+            float2 v = reinterpret_cast<const float2 *>(base)[i];
+            // get_mid_and_side_samples: (l + r) / 2., (l - r) / 2.
+            return ch == 0 ? (v.x + v.y) * 0.5f : (v.x - v.y) * 0.5f;
+        }
+        return base[(size_t)i * p.channels + (mode == 0 ? 0 : ch)];
+    };
+    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+        float x0 = sample(2 * i) * p.window[2 * i];
+        float x1 = sample(2 * i + 1) * p.window[2 * i + 1];
+        zs[i] = make_float2(x0, x1);
+    }
+    // DIF radix-2 stages: span s = m/2 .. 1
+    for (uint32_t s = m >> 1; s >= 1; s >>= 1) {
+        __syncthreads();
+        const uint32_t tw_step = n / (2 * s) ;   // W_{2s}^r = W_n^(r * n/(2s))
+        for (uint32_t b = threadIdx.x; b < (m >> 1); b += blockDim.x) {
+            const uint32_t r = b & (s - 1);
+            const uint32_t i = ((b & ~(s - 1)) << 1) | r;
+            const uint32_t j = i + s;
+            const float2 a = zs[i], c = zs[j];
+            zs[i] = cadd(a, c);
+            zs[j] = cmul(csub(a, c), p.tw_n[r * tw_step]);
+        }
+    }
+    __syncthreads();
+    float *o = p.out + (((size_t)stream * p.n_windows + w) * fft_ch + ch) * p.bin_stride;
+    for (uint32_t idx = threadIdx.x; idx < p.n_bins; idx += blockDim.x) {
+        const uint32_t k = p.first_bin + idx;
+        float xr, xi;
+        const float2 z0 = zs[0];
+        if (k == m) { xr = z0.x - z0.y; xi = 0.0f; }                 // Nyquist
+        else if (k == 0) { xr = z0.x + z0.y; xi = 0.0f; }
+        else {
+            const float2 zk = zs[bitrev(k, log2m)];
+            const float2 zc = zs[bitrev(m - k, log2m)];
+            const float sr = (zk.x + zc.x) * 0.5f, si = (zk.y - zc.y) * 0.5f;
+            const float dr = (zk.x - zc.x) * 0.5f, di = (zk.y + zc.y) * 0.5f;
+            const float2 wv = p.tw_n[k];
+            const float tr = wv.x * dr - wv.y * di;
+            const float ti = wv.x * di + wv.y * dr;
+            xr = sr + ti;
+            xi = si - tr;
+        }
+        const float q = fmaf(xr, xr, xi * xi);
+        float r = fmaf(log2f(q), 3.01029995663981195f, p.db_offset);
+        r = (q == 0.0f) ? -150.0f : r;
+        o[idx] = r + (p.pink ? p.pink[idx] : 0.0f);
+    }
+}
+
+hipError_t launch_fft_generic(const FftBatchParams &p, int mode, hipStream_t s)
+{
+    if (p.n_windows == 0 || p.n_streams == 0 || p.n_bins == 0) return hipSuccess;
+    const uint32_t fft_ch = (mode == 0) ? 1u : (mode == 1 ? 2u : p.channels);
+    const uint32_t m = p.n >> 1;
+    int log2m = 0;
+    while ((1u << log2m) < m) log2m++;
+    const size_t lds = (size_t)(m ? m : 1) * sizeof(float2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_generic),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid(p.n_streams * p.n_windows * fft_ch), block(256);
+    hipLaunchKernelGGL(k_fft_generic, grid, block, lds, s, p, mode, log2m);
+    return hipGetLastError();
+}
+
+}  // namespace ssk

@@ -1,0 +1,276 @@
+// ss_loudness.hip: gating blocks, histograms, integrated loudness, LRA, ring energies — hand-written gfx950 (CDNA4, wave64) kernels of the soundscope analyzer hot path.
+// Reference semantics: /root/reference/src/analyzer.rs (get_fft :55-105, get_waveform :107-137,
+// add_samples/getters :139-164, calculate_integrated_lufs :170-182) and src/audio_player.rs:400-419, plus the
+// arithmetic of ebur128 0.1.10 / spectrum-analyzer 1.7.0 / microfft 0.6.0 as restated in DESIGN.md.
+// Nothing here is translated from the reference: the reference has no GPU code.
+#include "ss_kernels.h"
+
+namespace ssk {
+// ============================================================================
+//  Gating blocks, histograms, integrated loudness and LRA
+//  (ebur128 calc_gating_block / loudness_global / loudness_range, histogram mode)
+// ============================================================================
+// largest i with bounds[i] <= energy (the caller has checked energy >= bounds[0]) — what ebur128's binary search
+// over the bin boundaries returns.  bounds[i] is the energy of -70 + i/10 LUFS, so the index is guessed in closed
+// form and then corrected against the table itself (at most a step or two): two dependent loads instead of ten.
+__device__ __forceinline__ uint32_t hist_index(const double *__restrict__ bounds, double energy)
+{
+    const double g = (10.0 * log10(energy) - 0.691 + 70.0) * 10.0;
+    int i = g > 0.0 ? (g < (double)(kHistBins - 1) ? (int)g : kHistBins - 1) : 0;
+    while (i > 0 && energy < bounds[i]) i--;
+    while (i < kHistBins - 1 && energy >= bounds[i + 1]) i++;
+    return (uint32_t)i;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// one wave evaluates gate and LRA on an LDS histogram pair (block, short-term)
+__device__ void eval_hist(const unsigned long long *hb, const unsigned long long *hs,
+                          const double *__restrict__ en, const double *__restrict__ bd,
+                          double *out_i, double *out_lra)
+{
+    const int lane = threadIdx.x & 63;
+    // ---- integrated: relative gate at -10 LU of the mean of all blocks
+    double sum = 0.0; unsigned long long cnt = 0;
+    for (int i = lane; i < kHistBins; i += 64) { sum += (double)hb[i] * en[i]; cnt += hb[i]; }
+    sum = wave_sum(sum); cnt = wave_sum_u64(cnt);
+    double integrated;
+    if (cnt == 0) integrated = -INFINITY;
+    else {
+        const double rel = (sum / (double)cnt) * 0.1;
+        uint32_t start;
+        if (rel < bd[0]) start = 0;
+        else { start = hist_index(bd, rel); if (rel > en[start]) start++; }
+        double g = 0.0; unsigned long long c2 = 0;
+        for (int i = lane; i < kHistBins; i += 64) if ((uint32_t)i >= start) { g += (double)hb[i] * en[i]; c2 += hb[i]; }
+        g = wave_sum(g); c2 = wave_sum_u64(c2);
+        integrated = c2 ? 10.0 * log10(g / (double)c2) - 0.691 : -INFINITY;
+    }
+    // ---- LRA (EBU Tech 3342) on the short-term histogram
+    double power = 0.0; unsigned long long size = 0;
+    for (int i = lane; i < kHistBins; i += 64) { power += (double)hs[i] * en[i]; size += hs[i]; }
+    power = wave_sum(power); size = wave_sum_u64(size);
+    double lra = 0.0;
+    if (size != 0) {
+        const double integ = 0.01 * (power / (double)size);
+        uint32_t index;
+        if (integ < bd[0]) index = 0;
+        else { index = hist_index(bd, integ); if (integ > en[index]) index++; }
+        unsigned long long above = 0;
+        for (int i = lane; i < kHistBins; i += 64) if ((uint32_t)i >= index) above += hs[i];
+        above = wave_sum_u64(above);
+        if (above != 0 && lane == 0) {
+            const unsigned long long plow = (unsigned long long)((double)(above - 1) * 0.1 + 0.5);
+            const unsigned long long phigh = (unsigned long long)((double)(above - 1) * 0.95 + 0.5);
+            unsigned long long acc = 0; uint32_t j = index;
+            while (acc <= plow) acc += hs[j++];
+            const double l_en = en[j - 1];
+            while (acc <= phigh) acc += hs[j++];
+            const double h_en = en[j - 1];
+            lra = (10.0 * log10(h_en) - 0.691) - (10.0 * log10(l_en) - 0.691);
+        }
+        lra = __shfl(lra, 0, 64);
+    }
+    if (lane == 0) { if (out_i) *out_i = integrated; if (out_lra) *out_lra = lra; }
+}
+
+__global__ __launch_bounds__(64) void k_finalize(FinalizeParams p)
+{
+    __shared__ unsigned long long hb[kHistBins];
+    __shared__ unsigned long long hs[kHistBins];
+    __shared__ unsigned int counts[2];
+    const uint32_t stream = blockIdx.x;
+    const int lane = threadIdx.x;
+    unsigned long long *gh = reinterpret_cast<unsigned long long *>(p.hist) + (size_t)stream * 2 * kHistBins;
+    unsigned long long *corpus = reinterpret_cast<unsigned long long *>(p.corpus_hist);
+    for (int i = lane; i < kHistBins; i += 64) { hb[i] = gh[i]; hs[i] = gh[kHistBins + i]; }
+    if (lane < 2) counts[lane] = 0;
+    __syncthreads();
+
+    const uint32_t C = p.channels;
+    const double S = (double)p.k->s100;
+    const double *P = p.subblocks + (size_t)stream * p.sub_stride;
+    // gating block ending with sub-block j: j-3..j ; short-term block: j-29..j when (j-29) % 10 == 0
+    const uint64_t sub_end = p.sub_end_of ? p.sub_end_of[stream] : p.sub_end;          // ragged batches
+    for (uint64_t j = p.sub_begin + lane; j < sub_end; j += 64) {
+        if (j >= 3) {
+            double sum = 0.0;
+            for (uint32_t c = 0; c < C; c++) {
+                const double w = p.weights[c];
+                if (w == 0.0) continue;
+                double cs = 0.0;
+                for (int q = 3; q >= 0; q--) cs += P[(size_t)((j - q) % p.sub_cap) * C + c];
+                sum += w * cs;
+            }
+            sum /= 4.0 * S;
+            atomicAdd(&counts[0], 1u);
+            if (sum >= p.hist_bounds[0]) atomicAdd(&hb[hist_index(p.hist_bounds, sum)], 1ull);
+        }
+        if (j >= 29 && (j - 29) % 10 == 0) {
+            double sum = 0.0;
+            for (uint32_t c = 0; c < C; c++) {
+                const double w = p.weights[c];
+                if (w == 0.0) continue;
+                double cs = 0.0;
+                for (int q = 29; q >= 0; q--) cs += P[(size_t)((j - q) % p.sub_cap) * C + c];
+                sum += w * cs;
+            }
+            sum /= 30.0 * S;
+            atomicAdd(&counts[1], 1u);
+            if (sum >= p.hist_bounds[0]) atomicAdd(&hs[hist_index(p.hist_bounds, sum)], 1ull);
+        }
+    }
+    __syncthreads();
+    // corpus contribution = what this call added
+    for (int i = lane; i < kHistBins; i += 64) {
+        const unsigned long long db = hb[i] - gh[i], ds = hs[i] - gh[kHistBins + i];
+        if (corpus) {
+            if (db) atomicAdd(&corpus[i], db);
+            if (ds) atomicAdd(&corpus[kHistBins + i], ds);
+        }
+        gh[i] = hb[i];
+        gh[kHistBins + i] = hs[i];
+    }
+    if (p.out_counts && lane < 2) p.out_counts[stream * 2 + lane] += counts[lane];
+    eval_hist(hb, hs, p.hist_energies, p.hist_bounds,
+              p.out_integrated ? &p.out_integrated[stream] : nullptr,
+              p.out_lra ? &p.out_lra[stream] : nullptr);
+}
+
+// Streaming form (one handle, a few new sub-blocks per call, no per-call read-out): the same gating rules
+// with the histogram updated in place by global atomics instead of a 16 KB round trip through LDS.
+__global__ __launch_bounds__(64) void k_finalize_stream(FinalizeParams p)
+{
+    const int lane = threadIdx.x;
+    unsigned long long *gh = reinterpret_cast<unsigned long long *>(p.hist);
+    const uint32_t C = p.channels;
+    const double S = (double)p.k->s100;
+    const double *P = p.subblocks;
+    uint32_t nb = 0, ns = 0;
+    for (uint64_t j = p.sub_begin + lane; j < p.sub_end; j += 64) {
+        if (j >= 3) {
+            double sum = 0.0;
+            for (uint32_t c = 0; c < C; c++) {
+                const double w = p.weights[c];
+                if (w == 0.0) continue;
+                double cs = 0.0;
+                for (int q = 3; q >= 0; q--) cs += P[(size_t)((j - q) % p.sub_cap) * C + c];
+                sum += w * cs;
+            }
+            sum /= 4.0 * S;
+            nb++;
+            if (sum >= p.hist_bounds[0]) atomicAdd(&gh[hist_index(p.hist_bounds, sum)], 1ull);
+        }
+        if (j >= 29 && (j - 29) % 10 == 0) {
+            double sum = 0.0;
+            for (uint32_t c = 0; c < C; c++) {
+                const double w = p.weights[c];
+                if (w == 0.0) continue;
+                double cs = 0.0;
+                for (int q = 29; q >= 0; q--) cs += P[(size_t)((j - q) % p.sub_cap) * C + c];
+                sum += w * cs;
+            }
+            sum /= 30.0 * S;
+            ns++;
+            if (sum >= p.hist_bounds[0]) atomicAdd(&gh[kHistBins + hist_index(p.hist_bounds, sum)], 1ull);
+        }
+    }
+    if (p.out_counts) {
+        if (nb) atomicAdd(&p.out_counts[0], nb);
+        if (ns) atomicAdd(&p.out_counts[1], ns);
+    }
+}
+
+hipError_t launch_finalize(const FinalizeParams &p, hipStream_t s)
+{
+    if (p.n_streams == 0) return hipSuccess;
+    const bool streaming = p.n_streams == 1 && !p.corpus_hist && !p.out_integrated && !p.out_lra && p.sub_stride == 0;
+    if (streaming) hipLaunchKernelGGL(k_finalize_stream, dim3(1), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(k_finalize, dim3(p.n_streams), dim3(64), 0, s, p);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(64) void k_hist_eval(const unsigned long long *hist2000, const double *en,
+                                                  const double *bd, double *out2)
+{
+    __shared__ unsigned long long hb[kHistBins];
+    __shared__ unsigned long long hs[kHistBins];
+    for (int i = threadIdx.x; i < kHistBins; i += 64) { hb[i] = hist2000[i]; hs[i] = hist2000[kHistBins + i]; }
+    __syncthreads();
+    eval_hist(hb, hs, en, bd, &out2[0], &out2[1]);
+}
+
+hipError_t launch_hist_eval(const uint64_t *hist2000, const double *energies, const double *bounds,
+                            double *out2, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_hist_eval, dim3(1), dim3(64), 0, s,
+                       reinterpret_cast<const unsigned long long *>(hist2000), energies, bounds, out2);
+    return hipGetLastError();
+}
+
+// mean square over the last `frames` frames of the filtered ring, channel-weighted
+// (calc_gating_block on the ring "as is": loudness_shortterm / loudness_momentary).
+// Two stages with a fixed reduction shape (bit-reproducible): kRingBlocks partial sums, then one block.
+constexpr int kRingBlocks = 96;
+__global__ __launch_bounds__(256) void k_ring_energy(const double *ring, uint64_t ring_frames, uint32_t C,
+                                                     uint64_t end_frame, uint64_t frames,
+                                                     const double *weights, double *partial)
+{
+    __shared__ double red[256];
+    double acc = 0.0;
+    const uint64_t total = frames * C;
+    // ring position of absolute frame f is f % ring_frames; frames before 0 are the zeroed ring
+    const uint64_t begin = end_frame + ring_frames * 4 - frames;    // keep the subtraction non-negative
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)kRingBlocks * 256) {
+        const uint64_t f = i / C; const uint32_t c = (uint32_t)(i - f * C);
+        const double w = weights[c];
+        const double y = ring[((begin + f) % ring_frames) * C + c];
+        acc = fma(w * y, y, acc);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(128) void k_ring_final(const double *partial, uint64_t frames, double *out)
+{
+    __shared__ double red[128];
+    red[threadIdx.x] = threadIdx.x < kRingBlocks ? partial[threadIdx.x] : 0.0;
+    __syncthreads();
+    for (int s = 64; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double e = red[0] / (double)frames;
+        out[0] = e;
+        out[1] = e <= 0.0 ? -INFINITY : 10.0 * log10(e) - 0.691;   // energy_to_loudness
+    }
+}
+
+hipError_t launch_ring_energy(const double *ring, uint64_t ring_frames, uint32_t channels,
+                              uint64_t end_frame, uint64_t frames, const double *weights,
+                              double *out, double *scratch, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_ring_energy, dim3(kRingBlocks), dim3(256), 0, s, ring, ring_frames, channels,
+                       end_frame % ring_frames, frames, weights, scratch);
+    hipLaunchKernelGGL(k_ring_final, dim3(1), dim3(128), 0, s, scratch, frames, out);
+    return hipGetLastError();
+}
+
+}  // namespace ssk
