@@ -825,6 +825,7 @@ struct ss_batch {
     int tp_factor = 0;
     int fft_mode = 1;           // generic-kernel mode (1 mid/side, 2 per channel)
     bool fft_fast = false;      // N=4096 stereo kernel
+    bool fft_pairw = false;     // N=4096, hop 1024, mono / per-channel: two windows per transform
     uint64_t first_start = 0;
     uint32_t wave_window = 0;
     uint32_t windows_per_block = 16;
@@ -925,6 +926,7 @@ int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
         L.n_bins = (uint32_t)b->bt->count;
         L.first_bin = (uint32_t)b->bt->first;
         b->fft_fast = (C == 2 && n == 4096 && hop % 256 == 0);
+        b->fft_pairw = (C != 2 && n == 4096 && hop == 1024 && !std::getenv("SS_FFT_NO_PAIRW"));
         {
             // windows per workgroup: long runs amortise the per-workgroup constants and the 3-hop halo,
             // but keep >= ~4096 workgroups (8 rounds of the 512 resident ones) for load balance
@@ -1243,7 +1245,7 @@ int ss_batch_run(ss_batch *b)
         p.n = c.fft_n; p.first_bin = L.first_bin; p.n_bins = L.n_bins; p.bin_stride = L.fft_bin_stride;
         p.windows_per_block = b->windows_per_block;
         p.windows_of = b->ragged ? b->windows_d.p : nullptr;
-        if (b->fft_fast) {
+        if (b->fft_fast || b->fft_pairw) {
             p.db_offset = (float)(10.0 * std::log10(4.0 / ((double)c.fft_n * (double)c.fft_n)));
             p.offpink = b->bt->offpink4096_dev.p;
             {
@@ -1257,7 +1259,8 @@ int ss_batch_run(ss_batch *b)
                 }
                 p.publish_mask = mask;
             }
-            HIPCHK(ssk::launch_fft4096_ms(p, fft_stream));
+            if (b->fft_fast) HIPCHK(ssk::launch_fft4096_ms(p, fft_stream));
+            else HIPCHK(ssk::launch_fft4096_pairw(p, b->fft_mode, fft_stream));
         } else {
             p.db_offset = (float)(20.0 * std::log10(4.0 / (double)c.fft_n));
             if (c.fft_n == 16384) {
@@ -1535,6 +1538,7 @@ int ss_batch_timing_read(ss_batch *b, int kernel, double *total_ms, uint64_t *la
 const char *ss_batch_kernel_name(const ss_batch *b, int kernel)
 {
     if (!b || kernel != SS_KERNEL_FFT) return ss_kernel_name(kernel);
+    if (b->fft_pairw) return "k_fft4096_pairw";
     if (b->fft_fast) {
         const uint32_t hop = b->cfg.hop_frames;
         return hop == 1024 ? "k_fft4096_ms1" : ((hop == 512 || hop == 2048) ? "k_fft4096_ms" : "k_fft4096_ms_anyhop");

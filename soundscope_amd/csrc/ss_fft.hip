@@ -157,7 +157,7 @@ constexpr int kPlane = 16 * kRow;   // 288 complex per outer index; 16 planes = 
 // a stride-256 ownership were store-issue bound (1.6 ms of 4.7 ms at the config-3 size).
 __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t first_bin, uint32_t n_bins,
                                                  float db_offset, const float *__restrict__ offpink,
-                                                 float *o_mid, float *o_side)
+                                                 float *o_mid, float *o_side, bool store_side = true)
 {
     const uint32_t ngroups = (n_bins + 3) >> 2;
     // dB = 10 log10(2) * log2(q) + (db_offset + pink[bin]); an exact zero reads -150 (+ pink): feed the
@@ -190,7 +190,7 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
             (void)o_mid; (void)o_side;
 #else
             reinterpret_cast<float4 *>(o_mid)[g] = make_float4(rm[0], rm[1], rm[2], rm[3]);
-            reinterpret_cast<float4 *>(o_side)[g] = make_float4(rs[0], rs[1], rs[2], rs[3]);
+            if (store_side) reinterpret_cast<float4 *>(o_side)[g] = make_float4(rs[0], rs[1], rs[2], rs[3]);
 #endif
         }
     }
@@ -469,6 +469,126 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
     }
 #undef X1W
 #undef X2W
+}
+
+// One REAL channel (mono buffers, or channel `ch` of an interleaved one) at hop 1024: two consecutive windows w, w + 1
+// ride one complex transform the way mid and side do — z[n] = (x[n] + i x[n + 1024]) hann[n] — so the "mid" row of
+// the epilogue is window w and the "side" row window w + 1, and the whole of k_fft4096_ms1 carries over.  A workgroup
+// walks window PAIRS; the sliding registers hold 20 slots and advance by 8 (2048 frames) per iteration.
+__global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_pairw(FftBatchParams p, uint32_t fft_ch)
+{
+    __shared__ __attribute__((aligned(16))) v2f xbuf[16 * kPlane];        // 36864 B
+    __shared__ __attribute__((aligned(16))) v2f tw2s[256];                //  2048 B
+#define X1W(ka, tb_, ta_) ((ka) * kX1Stride + (tb_) + 16 * (ta_))
+#define X2W(kb, ka_, tb_) ((kb) * kPlane + (ka_) * kRow + (tb_))
+    const int t = threadIdx.x;
+    const uint32_t pairs_per_block = p.windows_per_block >> 1;            // the host keeps windows_per_block even
+    const uint32_t n_pairs_max = (p.n_windows + 1) >> 1;
+    const uint32_t groups = (n_pairs_max + pairs_per_block - 1) / pairs_per_block;
+    // channels of one run read the same interleaved lines: keep them on one XCD (see k_fft16k_run)
+    const uint32_t per_xcd = gridDim.x >> 3;
+    uint32_t bid = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (bid >= p.n_streams * groups * fft_ch) return;
+    const uint32_t ch = bid % fft_ch; bid /= fft_ch;
+    const uint32_t grp = bid % groups;
+    const uint32_t stream = bid / groups;
+    const uint32_t n_win = p.windows_of ? p.windows_of[stream] : p.n_windows;
+    const uint32_t n_pairs = (n_win + 1) >> 1;
+    const uint32_t pp_begin = grp * pairs_per_block;
+    uint32_t pp_end = pp_begin + pairs_per_block;
+    if (pp_begin >= n_pairs) return;
+    if (pp_end > n_pairs) pp_end = n_pairs;
+    const uint32_t C = p.channels;
+    const float *src = p.pcm + ((size_t)stream * p.frames_per_stream + p.first_start + (size_t)pp_begin * 2048u) * C + ch;
+    const v2f *twn = reinterpret_cast<const v2f *>(p.tw_n);
+    float hw[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) hw[j] = p.window[t + 256 * j];           // the full Hann window: no mid/side halving here
+    v2f tw1[16];
+    tw1[1] = twn[t]; tw1[2] = twn[2 * t]; tw1[3] = twn[3 * t];
+    tw1[4] = twn[4 * t]; tw1[8] = twn[8 * t]; tw1[12] = twn[12 * t];
+    tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[t];
+    const int tb = t & 15, hi = t >> 4;
+    const int tsw = SPEC_POS(t);
+    const size_t row_stride = (size_t)fft_ch * p.bin_stride;              // window w -> window w + 1 of the same channel
+    float *outp = p.out + (((size_t)stream * p.n_windows + 2u * pp_begin) * fft_ch + ch) * p.bin_stride;
+    // slot s holds frame t + 256 s of the current pair's first window; the second window is slots 4..19
+    float raw[20];
+    const bool two0 = (2u * pp_begin + 1u < n_win);
+#pragma unroll
+    for (int j = 0; j < 20; j++) raw[j] = (j < 16 || two0) ? src[(size_t)(t + 256 * j) * C] : 0.0f;
+    __syncthreads();
+    for (uint32_t pp = pp_begin; pp < pp_end; ++pp) {
+        const bool two = (2u * pp + 1u < n_win);
+        const bool more = (pp + 1 < pp_end);
+        const bool more2 = more && (2u * pp + 3u < n_win);
+        float nx[8];
+        const float *nsrc = src + ((size_t)(pp - pp_begin) * 2048u + t) * C;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            nx[q] = 0.0f;
+            if (q < 4 ? more : more2) nx[q] = nsrc[(size_t)(256 * (20 + q)) * C];
+        }
+        v2f z[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) z[j] = v2f{raw[j] * hw[j], raw[j + 4] * hw[j]};
+        SS_PRIO_LO();
+        fft16(z);
+        SS_PRIO_HI();
+        xbuf[X1W(0, tb, hi)] = z[R16(0)];
+#pragma unroll
+        for (int ka = 1; ka < 16; ka++) {
+            v2f v = z[R16(ka)];
+            if (ka & 3) v = pk_cmul(v, tw1[ka & 3]);
+            if (ka & 12) v = pk_cmul(v, tw1[ka & 12]);
+            xbuf[X1W(ka, tb, hi)] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ta = 0; ta < 16; ta++) z[ta] = xbuf[X1W(hi, tb, ta)];
+        __syncthreads();
+        SS_PRIO_LO();
+        fft16(z);
+        SS_PRIO_HI();
+        xbuf[X2W(0, hi, tb)] = z[R16(0)];
+#pragma unroll
+        for (int kb = 1; kb < 16; kb++) xbuf[X2W(kb, hi, tb)] = pk_cmul(z[R16(kb)], tw2s[tb * kb]);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; q++) z[q] = xbuf[X2W(hi, tb, q)];
+        __syncthreads();
+        SS_PRIO_LO();
+        fft16(z);
+        SS_PRIO_HI();
+#pragma unroll
+        for (int kc = 0; kc < 16; kc++)
+            if ((p.publish_mask >> kc) & 1u) xbuf[kc * 256 + tsw] = z[R16(kc)];
+        __syncthreads();
+        SS_PRIO_EPI();
+        float *o_first = outp + (size_t)(pp - pp_begin) * 2u * row_stride;
+        fft4096_epilogue(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_first, o_first + row_stride, two);
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 12; j++) raw[j] = raw[j + 8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) raw[12 + q] = nx[q];
+        }
+        __syncthreads();
+    }
+#undef X1W
+#undef X2W
+}
+
+hipError_t launch_fft4096_pairw(const FftBatchParams &p, int mode, hipStream_t s)
+{
+    if (p.n_windows == 0 || p.n_streams == 0) return hipSuccess;
+    const uint32_t fft_ch = (mode == 0) ? 1u : p.channels;
+    const uint32_t pairs_per_block = p.windows_per_block >> 1;
+    const uint32_t n_pairs = (p.n_windows + 1) >> 1;
+    const uint32_t groups = (n_pairs + pairs_per_block - 1) / pairs_per_block;
+    const uint64_t total = (uint64_t)p.n_streams * groups * fft_ch;
+    hipLaunchKernelGGL(k_fft4096_pairw, dim3((uint32_t)((total + 7) & ~(uint64_t)7)), dim3(256), 0, s, p, fft_ch);
+    return hipGetLastError();
 }
 
 // generic hop (not a multiple of 256 or >= N/2 slots): one window per iteration, full reload

@@ -45,6 +45,8 @@ hipError_t launch_fft4096_ms(const FftBatchParams &p, hipStream_t s);
 hipError_t launch_fft_generic(const FftBatchParams &p, int mode, hipStream_t s);
 // N = 16384 real FFT per channel (two radix-16 4096-point halves); same modes as the generic kernel
 hipError_t launch_fft16k(const FftBatchParams &p, int mode, hipStream_t s);
+// N = 4096, hop 1024, one real channel per workgroup run, two windows per transform (mode 0 mono, 2 per channel)
+hipError_t launch_fft4096_pairw(const FftBatchParams &p, int mode, hipStream_t s);
 hipError_t launch_fft16k_run(FftBatchParams p, int mode, hipStream_t s);   // hop 1024, runs of windows
 
 // ---- time domain ------------------------------------------------------------

@@ -772,3 +772,32 @@ def test_analyze_streams_of_different_lengths(oracle):
             assert rel_close(res[i][2][c], m.true_peak(c)) or (res[i][2][c] == 0.0 and m.true_peak(c) == 0.0)
         total += m.block_hist()
     assert np.array_equal(hist[:1000], total)
+
+
+@pytest.mark.parametrize("channels,frames", [(1, 48000 + 1024 * 3), (1, 4096 + 1024), (3, 48000 * 2), (6, 4096 + 2048 + 5)])
+def test_real_channel_window_pair_kernel(oracle, channels, frames):
+    """N = 4096 at hop 1024 on real channels (mono / per channel): two windows per complex transform
+    (k_fft4096_pairw).  Odd and even window counts, every window of every channel against the oracle, ragged too."""
+    rate = 48000
+    x = make_multich(31 + channels, frames, channels, rate)
+    short = frames - 1024 * 2 - 7 if frames > 4096 + 3072 else frames
+    xs = [x, make_multich(32 + channels, short, channels, rate)]
+    slot = max(frames, short)
+    buf = np.full((2, slot * channels), 3.0, np.float32)
+    for i, v in enumerate(xs):
+        buf[i, :v.size] = v
+    b = ssa.Batch(rate, channels, 2, slot, 4096, 1024, flags=L.SS_BATCH_FFT)
+    assert L.lib().ss_batch_kernel_name(b._h, L.SS_KERNEL_FFT) == b"k_fft4096_pairw"
+    b.set_lengths([frames, short])
+    b.upload(0, buf.reshape(-1))
+    b.run(); b.sync()
+    for i, v in enumerate(xs):
+        n = v.size // channels
+        nw = max(0, n // 1024 - 4)
+        assert b.stream_shape(i).n_windows == nw
+        fft = b.fft(i)
+        vm = v.reshape(n, channels)
+        for w in range(nw):
+            start = (w + 1) * 1024
+            for c in range(channels):
+                assert db_close(fft[w, c], oracle.get_fft(rate, vm[start:start + 4096, c])[:, 1], TOL_DB), (i, w, c)
