@@ -751,6 +751,11 @@ static hipError_t td_launch_c(const TdParams &p, hipStream_t s)
             if (fast == 3) return td_launch<FACTOR, false, 2, 3>(p, s);
             return td_launch<FACTOR, false, 2, 1>(p, s);
         }
+        if (p.channels == 1) {                                                   // mono corpora
+            const int fast = td_wave_int4(p);
+            if (fast == 2) return td_launch<FACTOR, false, 1, 2>(p, s);
+            return td_launch<FACTOR, false, 1, 1>(p, s);
+        }
         return td_launch<FACTOR, false, 0, 1>(p, s);
     }
     return p.channels == 2 ? td_launch<FACTOR, RING, 2, 0>(p, s) : td_launch<FACTOR, RING, 0, 0>(p, s);
