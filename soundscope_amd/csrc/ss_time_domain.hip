@@ -562,23 +562,28 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
                     }
                 }
             } else {
-                for (uint32_t gi = 0; gi < ngroups; gi++) {             // channel counts that do not divide 16
-                    const uint32_t q = gi * 16 + (uint32_t)mrow;
-                    const uint32_t bi = q / C, c = q - bi * C;
-                    const bool col_ok = q < ncol;
-                    const float *bp = tile + ((int)(bi * Cfg::BLK) - (Cfg::HIST - 1) + kq) * (int)C + (int)c;
-                    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int s = 0; s < Cfg::KSTEPS; s++)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s], col_ok ? bp[4 * s * (int)C] : 0.0f, acc, 0, 0, 0);
+                // channel counts that do not divide 16 (5.1 = 6 channels, 3, 5, 7 ...): channel-major groups — the 16
+                // columns of a group are 16 consecutive blocks of ONE channel, so a lane's running maximum belongs to
+                // that channel and one LDS atomic per channel and tile closes it (it was one per group)
+                const uint32_t gpc = (nblk + 15) >> 4;                  // groups per channel
+                for (uint32_t c = 0; c < C; c++) {
                     float m = 0.0f;
+                    for (uint32_t gi = 0; gi < gpc; gi++) {
+                        const uint32_t bi = gi * 16 + (uint32_t)mrow;
+                        const bool col_ok = bi < nblk;
+                        const float *bp = tile + ((int)(bi * Cfg::BLK) - (Cfg::HIST - 1) + kq) * (int)C + (int)c;
+                        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int reg = 0; reg < 4; reg++) {
-                        const int row = 4 * kq + reg;
-                        const bool ok = col_ok && (bi * Cfg::BLK + (uint32_t)(row % Cfg::BLK)) < seg;
-                        m = fmaxf(m, ok ? fabsf(acc[reg]) : 0.0f);
+                        for (int s = 0; s < Cfg::KSTEPS; s++)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s], col_ok ? bp[4 * s * (int)C] : 0.0f, acc, 0, 0, 0);
+#pragma unroll
+                        for (int reg = 0; reg < 4; reg++) {
+                            const int row = 4 * kq + reg;
+                            const bool ok = col_ok && (bi * Cfg::BLK + (uint32_t)(row % Cfg::BLK)) < seg;
+                            m = fmaxf(m, ok ? fabsf(acc[reg]) : 0.0f);
+                        }
                     }
-                    if (col_ok) atomicMax(&tpk[c], __float_as_uint(m));
+                    atomicMax(&tpk[c], __float_as_uint(m));
                 }
             }
         }
@@ -745,6 +750,7 @@ static hipError_t td_launch_c(const TdParams &p, hipStream_t s)
 {
     if (!RING && p.wave_out) {    // fused decimation is a batch feature (never together with the ring)
         if (p.channels == 8) return td_launch<FACTOR, false, 8, 1>(p, s);      // BASELINE config 5
+        if (p.channels == 6) return td_launch<FACTOR, false, 6, 1>(p, s);      // 5.1
         if (p.channels == 2) {
             const int fast = td_wave_int4(p);
             if (fast == 2) return td_launch<FACTOR, false, 2, 2>(p, s);
