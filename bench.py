@@ -1,18 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py — throughput of the soundscope analyzer hot path on MI355X.
+"""bench.py — throughput of the soundscope analyzer hot path on MI355X.  No PyTorch anywhere.
 
 One step = one pass of the whole hot path (mid/side 4096-pt Hann FFT spectrum at hop 1024,
 K-weighted gated loudness + LRA, 4x true peak, min-max decimation) over a batch of synthetic
-48 kHz stereo f32 streams already resident in HBM, followed by the corpus gate (one all-reduce
-of the 2x1000-bin histograms when N > 1).  Weak scaling: every rank holds `--streams` streams
-(1024 x 10 s = BASELINE config 3 per GPU; 8 ranks = config 4's 8192 streams).
+48 kHz stereo f32 streams already resident in HBM, followed by the corpus gate (one RCCL
+all-reduce of the 2x1000-bin u64 histograms when N > 1, issued by the C-ABI library itself).
+
+  N = 1 : BASELINE config 3 — 1024 streams x 10 s on the GPU.
+  N > 1 : BASELINE config 4 — 8192 streams IN TOTAL sharded over the ranks (strong scaling);
+          `--scaling weak` keeps `--streams` per GPU instead.
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+         (torchrun is only the process launcher: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT)
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -26,11 +31,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP32_VECTOR_PEAK_TFLOPS = 157.3
+LDS_PEAK_GBS = 256 * 128 * 2.4   # 256 CUs x 128 B/clk x 2.4 GHz
+CONFIG4_TOTAL_STREAMS = 8192
 
 
 def cpu_baseline(batch, rate, fft_n, hop, budget_s=15.0, all_cores_budget_s=8.0):
-    """Time the CPU restatement (oracle, kind 'port') on a bounded sample of the same streams."""
+    """The CPU leg: times the CPU restatement (oracle, kind 'port') on a bounded sample of the same streams and —
+    with the oracle's outputs for the first sampled stream in hand — checks the GPU results of the timed run
+    against them (so a driver-run number is never unaccompanied by a parity check)."""
     from oracle import pyoracle as po
     native = True
     try:
@@ -48,15 +58,19 @@ def cpu_baseline(batch, rate, fft_n, hop, budget_s=15.0, all_cores_budget_s=8.0)
         native = tt[1] < tt[0]
     n_streams = int(batch.cfg.n_streams)
     done, samples, t_used = 0, 0, 0.0
+    check = None
     while done < n_streams and t_used < budget_s:
         x = batch.download_input(done)
         t0 = time.perf_counter()
-        po.analyze_stream(rate, x, fft_n, hop, want_fft=True, want_wave=True, native=native)
-        t_used += time.perf_counter() - t0
-        samples += x.size
+        ref = po.analyze_stream(rate, x, fft_n, hop, want_fft=True, want_wave=True, native=False if done == 0 else native)
+        if done != 0:
+            t_used += time.perf_counter() - t0
+            samples += x.size
+        else:       # stream 0: the parity check (strict-FP build of the oracle), not part of the timing
+            check = self_check(batch, 0, ref)
         done += 1
     out = {"value": samples / t_used, "unit": "samples/s", "cores": 1, "kind": "port",
-           "sample": f"{done} of the batch's streams ({samples} samples), single thread, "
+           "sample": f"{done - 1} of the batch's streams ({samples} samples), single thread, "
                      f"gcc -O3{' -march=native' if native else ''}, full analyze_stream pass "
                      "(waveform + mid/side + 2 FFTs/window incl. the crate's stats sorts + meter with true peak)"}
     # the same pass on every host core, streams sharded over threads; ctypes drops the
@@ -73,7 +87,70 @@ def cpu_baseline(batch, rate, fft_n, hop, budget_s=15.0, all_cores_budget_s=8.0)
         out["all_cores"] = {"value": sum(x.size for x in xs) / dt, "cores": cores, "streams": len(xs)}
     except Exception as e:            # never let the informational leg break the bench line
         out["all_cores"] = {"error": str(e)}
-    return out
+    return out, check
+
+
+def self_check(batch, stream, ref):
+    """GPU results of the run just timed vs the oracle's for one stream, at the north_star tolerances."""
+    got = batch.fft(stream)
+    r = batch.results()[stream]
+    strong = ref["fft"] > -90.0
+    fft_err = float(np.abs(got[strong] - ref["fft"][strong]).max()) if strong.any() else 0.0
+    weak = ~strong
+    peak_lin = 10.0 ** (float(ref["fft"].max()) / 20.0)
+    weak_err = float(np.abs(10.0 ** (got[weak] / 20.0) - 10.0 ** (ref["fft"][weak] / 20.0)).max() / peak_lin) if weak.any() else 0.0
+    lufs_err = abs(r.integrated_lufs - ref["integrated"]) if math.isfinite(ref["integrated"]) else (0.0 if r.integrated_lufs == ref["integrated"] else float("inf"))
+    lra_err = abs(r.loudness_range - ref["lra"])
+    tp_rel = max(abs(r.true_peak[c] - ref["true_peak"][c]) / max(ref["true_peak"][c], 1e-30) for c in range(2))
+    wave_ok = bool(np.array_equal(batch.waveform(stream).reshape(-1), ref["wave"][:, 1].astype(np.float32)))
+    ok = fft_err <= 0.01 and weak_err <= 1e-4 and lufs_err <= 0.01 and lra_err <= 0.01 and tp_rel <= 1e-4 and wave_ok
+    return {"stream": stream, "windows": int(got.shape[0]), "fft_max_err_db_above_-90dB": fft_err,
+            "fft_max_err_rel_to_peak_below": weak_err, "integrated_err_lu": lufs_err, "lra_err_lu": lra_err,
+            "true_peak_rel_err": tp_rel, "decimation_bit_exact": wave_ok, "ok": bool(ok)}
+
+
+def time_config(ssa, L, rate, channels, streams, frames, fft_n, hop, tp_factor, steps, warmup=1):
+    """Per-kernel HIP-event times of one extra BASELINE configuration (informational lines under config.extra)."""
+    b = ssa.Batch(rate, channels, streams, frames, fft_n, hop, flags=L.SS_BATCH_ALL, true_peak_factor=tp_factor)
+    b.synthesize(0x5EED0000, 0)
+    for _ in range(warmup):
+        b.run(); b.sync()
+    b.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b.run(); b.sync()
+    wall_ms = (time.perf_counter() - t0) / steps * 1e3
+    kern = {}
+    for k in range(L.SS_KERNEL_COUNT):
+        ms, n = b.timing_read(k)
+        kern[L.lib().ss_batch_kernel_name(b._h, k).decode()] = round(ms / max(n, 1), 4)
+    lay, geo = b.layout, b.geometry
+    fft_ms = b.timing_read(L.SS_KERNEL_FFT)[0] / steps
+    td_ms = b.timing_read(L.SS_KERNEL_TIME_DOMAIN)[0] / steps
+    gpu_ms = sum(kern.values())
+    samples = streams * frames * channels
+    in_bytes = samples * 4
+    out_bytes = streams * lay.n_windows * lay.fft_channels * lay.n_bins * 4
+    res = {"ms_per_pass_wall": round(wall_ms, 4), "kernel_ms": kern, "gpu_ms": round(gpu_ms, 4),
+           "samples_per_s": samples / (gpu_ms * 1e-3) if gpu_ms > 0 else None,
+           "windows_per_stream": lay.n_windows, "fft_channels": lay.fft_channels, "bins": lay.n_bins,
+           "geometry": {"fft_windows_per_block": geo.fft_windows_per_block, "fft_blocks": geo.fft_blocks,
+                        "td_segments": geo.td_segments, "true_peak_factor": geo.td_true_peak_factor}}
+    if fft_ms > 0:
+        alg = in_bytes + out_bytes
+        flops = 5.0 * fft_n * math.log2(fft_n) * streams * lay.n_windows * (1 if (channels == 2 and fft_n == 4096) else lay.fft_channels)
+        res["spectrum_kernel"] = {"algorithmic_bytes": alg, "hbm_frac": alg / (fft_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "algorithmic_flops": flops, "fp32_frac": flops / (fft_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS}
+        if fft_n == 16384 and hop == 1024:
+            # k_fft16k_run moves, per window and channel, 2 halves x (3 exchanges written + read) of 4096 complex f32
+            # plus the 4 KB dB staging row: the design's LDS traffic against 128 B/clk/CU
+            lds = streams * lay.n_windows * lay.fft_channels * (2 * 3 * 2 * 4096 * 8 + 2 * 4 * lay.n_bins)
+            res["spectrum_kernel"]["lds_bytes_by_design"] = lds
+            res["spectrum_kernel"]["lds_frac"] = lds / (fft_ms * 1e-3) / 1e9 / LDS_PEAK_GBS
+    if td_ms > 0:
+        res["time_domain_kernel"] = {"algorithmic_bytes": in_bytes, "hbm_frac": in_bytes / (td_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    b.close()
+    return res
 
 
 def main():
@@ -81,15 +158,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=1024, help="streams per GPU (weak scaling, the default)")
-    ap.add_argument("--total-streams", type=int, default=0,
-                    help="strong scaling instead: this many streams in total, sharded over the ranks "
-                         "(BASELINE config 4: 8192; fits one GPU's 288 GB)")
+    ap.add_argument("--streams", type=int, default=1024, help="streams per GPU (config 3; weak scaling)")
+    ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto",
+                    help="auto: config 3 on one GPU, config 4 (8192 streams in total, strong scaling) on several")
+    ap.add_argument("--total-streams", type=int, default=0, help="strong scaling with this many streams in total")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--rate", type=int, default=48000)
     ap.add_argument("--fft-n", type=int, default=4096)
     ap.add_argument("--hop", type=int, default=1024)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--sequential", action="store_true", help="spectrum and time-domain kernels back to back instead of overlapped")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg (and its parity check)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config 2 / config 5 lines")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,87 +177,72 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    import torch
-    import torch.distributed as dist
-
     import soundscope_amd as ssa
     from soundscope_amd import _lib as L
-    from soundscope_amd.distributed import allreduce_histograms, corpus_gate, shard_streams
+    from soundscope_amd.distributed import Comm, corpus_gate, shard_streams
 
-    if not torch.cuda.is_available():
+    lib = L.lib()
+    if lib.ss_device_count() <= 0:
         raise SystemExit("bench.py needs a GPU (soundscope_amd has no CPU path)")
-    # SS_BENCH_SHARED_GPU=1 + SS_BENCH_BACKEND=gloo: launch-path check on a 1-GPU box (all ranks on device 0,
-    # collectives staged through host memory); the judged runs use one GPU per rank and RCCL
-    backend = os.environ.get("SS_BENCH_BACKEND", "nccl")
+    # SS_BENCH_SHARED_GPU=1 + SS_BENCH_TRANSPORT=host-tcp: launch-path check on a 1-GPU box (all ranks on device 0,
+    # the 16 kB exchange staged through host memory); the judged runs use one GPU per rank and RCCL
+    transport = os.environ.get("SS_BENCH_TRANSPORT", "rccl")
     dev = 0 if os.environ.get("SS_BENCH_SHARED_GPU") == "1" else local_rank
-    torch.cuda.set_device(dev)
-    rc = L.lib().ss_set_device(dev)
-    if rc:
-        raise SystemExit("ss_set_device failed: " + L.lib().ss_last_device_error().decode())
+    if lib.ss_set_device(dev):
+        raise SystemExit("ss_set_device failed: " + lib.ss_last_device_error().decode())
+    comm = None
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
-            try:        # prove the communicator before the timed region; a broken RCCL setup must not cost the whole line
-                probe = torch.ones(1, dtype=torch.int64, device="cuda")
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-                ok = int(probe.item()) == world
-            except Exception as e:
-                print(f"[bench] rank {rank}: RCCL all-reduce failed ({e!r})", file=sys.stderr, flush=True)
-                ok = False
-            if not ok:
-                raise SystemExit("RCCL all-reduce over the node's GPUs failed; set SS_BENCH_BACKEND=gloo to stage the "
-                                 "16 kB histogram exchange through host memory instead")
-        else:
-            dist.init_process_group(backend)
-    host_staged = world > 1 and backend != "nccl"
+        comm = Comm.from_env(transport)           # RCCL: ncclCommInitRank inside the library
+        comm.barrier()                            # proves the communicator before anything is timed
+        if comm.size != world:
+            raise SystemExit(f"communicator reports {comm.size} ranks, expected {world}")
 
     frames = int(round(args.seconds * args.rate))
-    strong = args.total_streams > 0
-    total_streams = args.total_streams if strong else args.streams * world
+    strong = args.scaling == "strong" or args.total_streams > 0 or (args.scaling == "auto" and world > 1)
+    total_streams = (args.total_streams or CONFIG4_TOTAL_STREAMS) if strong else args.streams * world
     first, count = shard_streams(total_streams, rank, world)
     b = ssa.Batch(args.rate, 2, count, frames, args.fft_n, args.hop, flags=L.SS_BATCH_ALL)
     b.synthesize(0x5EED0000, first)
     lay = b.layout
-    hist = torch.zeros(2000, dtype=torch.int64, device="cuda")
+    b.set_overlap(not args.sequential)
+    hist = [None]
 
     def step():
         b.run()
-        b.histograms_to_device(hist.data_ptr())      # syncs the batch's stream
-        if host_staged:
-            h = hist.cpu()
-            allreduce_histograms(h)
-            hist.copy_(h)
+        if comm is not None:
+            hist[0] = np.concatenate(b.allreduce_histograms(comm))     # ncclAllReduce in place on the batch's stream, then D2H + sync
         else:
-            allreduce_histograms(hist)                 # RCCL over xGMI when world > 1
-        if world > 1:
-            torch.cuda.current_stream().synchronize()  # the next step refills `hist`: the collective must be done
+            hist[0] = np.concatenate(b.histograms())                   # D2H + sync
 
     def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        lib.ss_device_synchronize()
+        if comm is not None:
+            comm.barrier()
+        lib.ss_device_synchronize()
 
     for _ in range(args.warmup):
         step()
-    b.timing_enable(True)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if host_staged else "cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    if comm is not None:
+        dt = float(comm.allreduce_max_f64(np.array([dt]))[0])
     b.sync()
 
     samples_per_step = total_streams * frames * 2
     value = samples_per_step * args.steps / dt
-    corpus_i, corpus_lra = corpus_gate(hist.cpu().numpy())
+    corpus_i, corpus_lra = corpus_gate(hist[0])
+
+    # per-kernel times: a separate SEQUENTIAL pass (with two kernels sharing the chip a per-kernel HIP-event time
+    # would not describe either of them); HIP events on the batch's own stream
+    b.timing_enable(True)
+    for _ in range(max(3, min(args.steps, 10))):
+        b.run(); b.sync()
+    if comm is not None:
+        comm.barrier()
 
     if rank == 0:
         # dominant kernel: the spectrum kernel.  Algorithmic bytes per launch:
@@ -189,42 +253,49 @@ def main():
         kernels = {}
         for k in range(L.SS_KERNEL_COUNT):
             ms, n = b.timing_read(k)
-            kernels[L.lib().ss_batch_kernel_name(b._h, k).decode()] = round(ms / max(n, 1), 4)
-        traffic = None
+            kernels[lib.ss_batch_kernel_name(b._h, k).decode()] = round(ms / max(n, 1), 4)
+        seq_ms = sum(kernels.values())
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "fft_hbm_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath):        # PMC counters cannot be read inside this run: committed rocprofv3 passes, labelled as such
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic_src = "profiles/fft_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run)"
             except Exception:
                 traffic = None
-        # second kernel of the pass: streaming + MFMA true peak.  HBM fraction live; pipe utilisation from the committed PMC run
         td_ms, td_n = b.timing_read(L.SS_KERNEL_TIME_DOMAIN)
-        td = {"kernel": L.lib().ss_batch_kernel_name(b._h, L.SS_KERNEL_TIME_DOMAIN).decode(),
+        td = {"kernel": lib.ss_batch_kernel_name(b._h, L.SS_KERNEL_TIME_DOMAIN).decode(),
               "algorithmic_bytes_per_launch": count * frames * 2 * 4}
         if td_ms > 0:
             td["achieved_GBps"] = td["algorithmic_bytes_per_launch"] / (td_ms / max(td_n, 1) * 1e-3) / 1e9
             td["hbm_frac"] = td["achieved_GBps"] / HBM_PEAK_GBS
-        try:
-            d = json.load(open(os.path.join(ROOT, "profiles", "td_pmc.json")))["derived"]
-            td.update({"mfma_busy_frac": d["mfma_busy_frac"], "valu_busy_frac": d["valu_busy_frac"],
-                       "lds_busy_frac": d["lds_busy_frac"], "pmc_source": "profiles/td_pmc.json"})
-        except Exception:
-            pass
+        geo = b.geometry
+        step_alg = alg_bytes + count * (lay.n_wave_points * 4 + 8 * 110)
         out = {
             "metric": "audio samples/s analyzed (48 kHz stereo)", "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32+f64",
-            "data": "synthetic",
-            "config": {"workload": f"{str(total_streams) + ' streams in total' if strong else str(args.streams) + ' streams/GPU'} x {args.seconds:g} s, {args.rate} Hz stereo f32 "
-                                   f"(BASELINE config 3 per GPU; config 4 at 8 GPUs): mid/side {args.fft_n}-pt Hann FFT "
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": "f32 (f16x3-split MFMA true peak) + f64", "data": "synthetic",
+            "config": {"workload": (f"{total_streams} streams in total (BASELINE config 4) sharded over {world} GPU(s)" if strong
+                                    else f"{args.streams} streams/GPU (BASELINE config 3)") +
+                                   f" x {args.seconds:g} s, {args.rate} Hz stereo f32: mid/side {args.fft_n}-pt Hann FFT "
                                    f"hop {args.hop} + K-weighted gated LUFS/LRA + 4x true peak + min-max decimation "
                                    "+ corpus gate (1 all-reduce of 2x1000 u64)",
-                       "streams_total": total_streams, "windows_per_stream": lay.n_windows, "bins": lay.n_bins,
-                       "sharding": f"streams, {world} rank(s)", "collective": ("none" if world == 1 else ("rccl" if not host_staged else backend + " (host staged)")), "corpus_integrated_lufs": corpus_i,
-                       "corpus_lra": corpus_lra, "kernel_ms": kernels, "time_domain_kernel": td},
-            "roofline": {"bound": "hbm", "kernel": L.lib().ss_batch_kernel_name(b._h, L.SS_KERNEL_FFT).decode(),
+                       "streams_total": total_streams, "streams_this_rank": count, "windows_per_stream": lay.n_windows, "bins": lay.n_bins,
+                       "sharding": f"streams, {world} rank(s)",
+                       "collective": ({"lib": "none", "nranks": 1} if comm is None else {"lib": comm.transport, "nranks": comm.size, "call": "ncclAllReduce(2000, ncclUint64, ncclSum) per step" if comm.transport == "rccl" else "host-staged sum over loopback TCP"}),
+                       "mode": "sequential" if args.sequential else "overlap (spectrum kernel on a second HIP stream beside the time-domain chain)",
+                       "geometry": {"fft_windows_per_block": geo.fft_windows_per_block, "fft_blocks": geo.fft_blocks,
+                                    "td_segments": geo.td_segments, "td_segment_subblocks": geo.td_segment_subblocks,
+                                    "waveform_fused": geo.waveform_fused},
+                       "corpus_integrated_lufs": corpus_i, "corpus_lra": corpus_lra,
+                       "kernel_ms": kernels, "kernel_ms_note": "separate sequential pass, HIP events on the batch's stream",
+                       "sequential_gpu_ms": round(seq_ms, 4),
+                       "step_hbm_frac": step_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                       "time_domain_kernel": td},
+            "roofline": {"bound": "hbm", "kernel": lib.ss_batch_kernel_name(b._h, L.SS_KERNEL_FFT).decode(),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         # PCIe-inclusive rate (informational, never `value`): host f32 -> HBM upload of a slice + its share of a pass
@@ -239,15 +310,32 @@ def main():
         except Exception:
             pass
         if world == 1 and not args.no_cpu:
-            cb = cpu_baseline(b, args.rate, args.fft_n, args.hop)
+            cb, check = cpu_baseline(b, args.rate, args.fft_n, args.hop)
             out["cpu_baseline"] = cb
+            out["config"]["self_check_vs_oracle"] = check
             out["config"]["gpu_over_cpu_1core"] = value / cb["value"]
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_extra:
+            b.close()
+            extra = []
+            try:      # config 2: one stream (10 s and the 600 s steady-state variant)
+                for secs in (10, 600):
+                    e = time_config(ssa, L, 48000, 2, 1, 48000 * secs, 4096, 1024, 0, steps=5)
+                    e["workload"] = f"config 2: 1 stream x {secs} s, 48 kHz stereo, N=4096 hop 1024, full path"
+                    extra.append(e)
+                # config 5: 96 kHz 8-channel, N = 16384 per channel; forced 4x (benchmark) and the crate rule's 2x
+                for tp, name in ((4, "forced 4x true peak"), (0, "rule 2x true peak")):
+                    e = time_config(ssa, L, 96000, 8, 64, 960000, 16384, 1024, tp, steps=3)
+                    e["workload"] = f"config 5: 64 streams x 10 s, 96 kHz 8 ch, N=16384 hop 1024 per channel, {name}"
+                    extra.append(e)
+            except Exception as ex:
+                extra.append({"error": repr(ex)})
+            out["config"]["extra"] = extra
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 if __name__ == "__main__":

@@ -56,7 +56,12 @@ int ss_abi_version(void);
 /* number of visible HIP devices (0 if none); ss_set_device binds the calling
  * process's subsequent handle/batch creations to a device. */
 int ss_device_count(void);
+/* Tables and scratch are cached PER DEVICE; every handle / batch / session / communicator remembers the device
+ * that was current when it was created and makes it current again at each of its entry points, so one process
+ * may drive several GPUs from several threads.  (The one-process-per-GPU flow calls ss_set_device once.) */
 int ss_set_device(int device);
+/* hipDeviceSynchronize on the calling thread's current device (bench fences) */
+int ss_device_synchronize(void);
 /* last HIP runtime error text seen by this library on this thread ("" if none) */
 const char *ss_last_device_error(void);
 
@@ -114,7 +119,7 @@ int ss_get_true_peak_channel(ss_analyzer *h, uint32_t channel, double *out);
 int ss_get_sample_peak_channel(ss_analyzer *h, uint32_t channel, double *out);
 /* true-peak oversampling: 0 = ebur128's rule (<96 kHz: 4x, <192 kHz: 2x, else
  * off); 2 or 4 = forced (BASELINE config 5 asks for 4x at 96 kHz).  Takes
- * effect at the next ss_analyzer_configure / ss_reset. */
+ * effect at the next ss_analyzer_configure or ss_reset (both start a fresh meter). */
 int ss_analyzer_set_true_peak_factor(ss_analyzer *h, int factor);
 
 /* ------------------------------------------------------------------------ *
@@ -241,6 +246,27 @@ int ss_batch_run(ss_batch *b);
 int ss_batch_sync(ss_batch *b);
 /* results (after ss_batch_sync) */
 int ss_batch_results(ss_batch *b, ss_stream_result *out, uint32_t cap);
+/* every channel's peaks of one stream (ss_stream_result only carries channels 0 and 1, like
+ * Analyzer::get_true_peak, analyzer.rs:159-164; ebur128 keeps them per channel and the app leaves the rest as
+ * "TODO: channels", tui.rs:1217-1221): true_pk[c] = max(true, sample) like EbuR128::true_peak(c), sample_pk[c]
+ * = EbuR128::sample_peak(c), linear.  Either array may be NULL; cap_channels >= the batch's channel count. */
+int ss_batch_peaks(ss_batch *b, uint32_t stream, double *true_pk, double *sample_pk, uint32_t cap_channels);
+/* the launch geometry this batch's shape selected (tests assert that the benchmark geometry is the one they check) */
+typedef struct ss_batch_geometry {
+    uint32_t fft_windows_per_block;  /* windows one spectrum workgroup walks                          */
+    uint32_t fft_blocks;             /* spectrum workgroups per pass                                  */
+    uint32_t td_segments;            /* time segments per stream in the time-domain kernel            */
+    uint32_t td_segment_subblocks;   /* 100 ms sub-blocks per segment (0: one segment)                */
+    uint32_t td_warm_subblocks;      /* filter run-in of segments > 0                                 */
+    uint32_t td_true_peak_factor;    /* 0, 2, 4                                                       */
+    uint32_t waveform_fused;         /* 1: decimation runs inside the time-domain kernel              */
+    uint32_t overlap;                /* 1: spectrum kernel runs beside the time-domain chain          */
+} ss_batch_geometry;                 /* 32 bytes */
+int ss_batch_geometry_get(const ss_batch *b, ss_batch_geometry *out);
+/* run the spectrum kernel on a second HIP stream beside the time-domain chain (they use different pipes: packed
+ * f32 VALU + LDS vs f64 VALU + matrix cores); results are identical either way.  Per-kernel event timing
+ * (ss_batch_timing_enable) always runs sequentially. */
+int ss_batch_set_overlap(ss_batch *b, int enable);
 /* spectrum of one stream: compact [n_windows][fft_channels][n_bins] f32 dB (pink-compensated);
  * on the device the rows are fft_bin_stride floats apart */
 int ss_batch_download_fft(ss_batch *b, uint32_t stream, float *out, size_t cap_floats);
@@ -260,6 +286,38 @@ int ss_batch_histograms_device(ss_batch *b, void *dst_device_2000_u64);
  * and loudness_range_multiple semantics.  Host-side, O(1000). */
 double ss_corpus_integrated_lufs(const uint64_t *block_hist1000);
 double ss_corpus_loudness_range(const uint64_t *st_hist1000);
+
+/* ------------------------------------------------------------------------- *
+ *  Multi-GPU: one process per GPU, streams sharded over the ranks, and exactly ONE exchange —
+ *  the SUM all-reduce of the two 1000-bin u64 histograms for the corpus-level integrated-LUFS gate
+ *  (ebur128 loudness_global_multiple semantics; the reference app has no collective).  The library talks to
+ *  RCCL itself (librccl is opened at ss_comm_init; ncclAllReduce(buf, buf, 2000, ncclUint64, ncclSum) on the
+ *  batch's stream, over xGMI) — no PyTorch, no MPI.
+ *    SS_COMM_RCCL      device buffers, RCCL
+ *    SS_COMM_HOST_TCP  the same calls staged through host memory over loopback TCP: CPU tests of the rank
+ *                      logic, and ranks that share one GPU
+ *  Rendezvous (one node): rank 0 publishes the RCCL unique id (and its TCP port) in `rendezvous_file`, the other
+ *  ranks poll for it.  ss_comm_init_from_env derives rank / world from RANK / WORLD_SIZE and the file name from
+ *  the launcher's process id and MASTER_PORT (torchrun as a launcher only), or takes SS_COMM_FILE.
+ * ------------------------------------------------------------------------- */
+typedef struct ss_comm ss_comm;
+enum { SS_COMM_RCCL = 0, SS_COMM_HOST_TCP = 1 };
+int ss_comm_init(int transport, int rank, int world, const char *rendezvous_file, ss_comm **out);
+int ss_comm_init_from_env(int transport, ss_comm **out);
+void ss_comm_destroy(ss_comm *c);
+int ss_comm_rank(const ss_comm *c);
+/* number of ranks as the transport itself reports it (ncclCommCount for RCCL) */
+int ss_comm_size(const ss_comm *c);
+const char *ss_comm_transport_name(const ss_comm *c);
+/* small host-buffer collectives (fences and the max-over-ranks clock of the benchmark) */
+int ss_comm_barrier(ss_comm *c);
+int ss_comm_allreduce_u64_sum(ss_comm *c, uint64_t *inout, size_t n);
+int ss_comm_allreduce_f64_max(ss_comm *c, double *inout, size_t n);
+/* the corpus gate's exchange: in-place SUM all-reduce of this batch's corpus histograms (block ++ short-term,
+ * 2000 u64) across the ranks, queued on the batch's stream behind ss_batch_run; out2000 (nullable) receives
+ * the reduced histograms after the stream has drained.  Afterwards ss_batch_histograms returns the corpus-wide
+ * histograms on every rank, and ss_corpus_integrated_lufs / ss_corpus_loudness_range evaluate the gate. */
+int ss_batch_allreduce_histograms(ss_batch *b, ss_comm *c, uint64_t *out2000);
 
 /* ------------------------------------------------------------------------- *
  *  Render-side reductions: the step after the path.

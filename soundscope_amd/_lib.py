@@ -34,6 +34,10 @@ SYMBOLS = [
     "ss_batch_download_waveform_columns", "ss_waveform_view", "ss_batch_kernel_name",
     "ss_host_register", "ss_host_unregister", "ss_batch_upload_pcm_async",
     "ss_batch_set_lengths", "ss_batch_stream_shape", "ss_batch_upload_samples",
+    "ss_device_synchronize", "ss_batch_peaks", "ss_batch_geometry_get", "ss_batch_set_overlap",
+    "ss_comm_init", "ss_comm_init_from_env", "ss_comm_destroy", "ss_comm_rank", "ss_comm_size",
+    "ss_comm_transport_name", "ss_comm_barrier", "ss_comm_allreduce_u64_sum", "ss_comm_allreduce_f64_max",
+    "ss_batch_allreduce_histograms",
 ]
 
 SS_OK = 0
@@ -44,6 +48,7 @@ SS_ERR_CAPACITY, SS_ERR_UNSUPPORTED, SS_ERR_INVALID_ARG, SS_ERR_DEVICE = 20, 21,
 SS_BATCH_FFT, SS_BATCH_LUFS, SS_BATCH_TRUE_PEAK, SS_BATCH_WAVEFORM, SS_BATCH_ALL = 1, 2, 4, 8, 15
 SS_PCM_U8, SS_PCM_S16, SS_PCM_S24, SS_PCM_S32, SS_PCM_F32, SS_PCM_F64 = 1, 2, 3, 4, 5, 6
 SS_GAIN_FIXED, SS_GAIN_REFERENCE = 0, 1
+SS_COMM_RCCL, SS_COMM_HOST_TCP = 0, 1
 SS_KERNEL_FFT, SS_KERNEL_TIME_DOMAIN, SS_KERNEL_FINALIZE, SS_KERNEL_WAVEFORM, SS_KERNEL_COUNT = 0, 1, 2, 3, 4
 
 
@@ -76,6 +81,12 @@ class TickResult(C.Structure):
 class StreamShape(C.Structure):
     _fields_ = [("frames", C.c_uint64), ("n_windows", C.c_uint32), ("n_subblocks", C.c_uint32),
                 ("n_wave_points", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class BatchGeometry(C.Structure):
+    _fields_ = [("fft_windows_per_block", C.c_uint32), ("fft_blocks", C.c_uint32), ("td_segments", C.c_uint32),
+                ("td_segment_subblocks", C.c_uint32), ("td_warm_subblocks", C.c_uint32),
+                ("td_true_peak_factor", C.c_uint32), ("waveform_fused", C.c_uint32), ("overlap", C.c_uint32)]
 
 
 class BatchLayout(C.Structure):
@@ -169,6 +180,20 @@ def _bind(lib):
         "ss_batch_set_lengths": (C.c_int, [vp, u64p, C.c_uint32]),
         "ss_batch_upload_samples": (C.c_int, [vp, C.c_uint32, vp, C.c_size_t, C.c_int]),
         "ss_batch_stream_shape": (C.c_int, [vp, C.c_uint32, C.POINTER(StreamShape)]),
+        "ss_device_synchronize": (C.c_int, []),
+        "ss_batch_peaks": (C.c_int, [vp, C.c_uint32, f64p, f64p, C.c_uint32]),
+        "ss_batch_geometry_get": (C.c_int, [vp, C.POINTER(BatchGeometry)]),
+        "ss_batch_set_overlap": (C.c_int, [vp, C.c_int]),
+        "ss_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)]),
+        "ss_comm_init_from_env": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "ss_comm_destroy": (None, [vp]),
+        "ss_comm_rank": (C.c_int, [vp]),
+        "ss_comm_size": (C.c_int, [vp]),
+        "ss_comm_transport_name": (C.c_char_p, [vp]),
+        "ss_comm_barrier": (C.c_int, [vp]),
+        "ss_comm_allreduce_u64_sum": (C.c_int, [vp, u64p, C.c_size_t]),
+        "ss_comm_allreduce_f64_max": (C.c_int, [vp, f64p, C.c_size_t]),
+        "ss_batch_allreduce_histograms": (C.c_int, [vp, vp, u64p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -83,6 +83,31 @@ class Batch:
         _check(L.lib().ss_batch_results(self._h, arr, n))
         return arr
 
+    def peaks(self, stream):
+        """Every channel's (true_peak, sample_peak) of one stream, linear: arrays [channels] f64."""
+        ch = int(self.cfg.channels)
+        tp, sp = np.empty(ch, np.float64), np.empty(ch, np.float64)
+        dp = C.POINTER(C.c_double)
+        _check(L.lib().ss_batch_peaks(self._h, stream, tp.ctypes.data_as(dp), sp.ctypes.data_as(dp), ch))
+        return tp, sp
+
+    @property
+    def geometry(self):
+        g = L.BatchGeometry()
+        _check(L.lib().ss_batch_geometry_get(self._h, C.byref(g)))
+        return g
+
+    def set_overlap(self, on=True):
+        """Spectrum kernel on a second HIP stream beside the time-domain chain (same results)."""
+        _check(L.lib().ss_batch_set_overlap(self._h, 1 if on else 0))
+
+    def allreduce_histograms(self, comm):
+        """The corpus gate's exchange: in-place SUM all-reduce of this batch's corpus histograms over `comm`
+        (soundscope_amd.distributed.Comm).  Returns (block_hist, shortterm_hist) of the whole corpus."""
+        out = np.empty(2000, np.uint64)
+        _check(L.lib().ss_batch_allreduce_histograms(self._h, comm._h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out[:1000].copy(), out[1000:].copy()
+
     def fft(self, stream):
         lay = self.layout
         out = np.empty((lay.n_windows, lay.fft_channels, lay.n_bins), np.float32)

@@ -17,6 +17,7 @@
 #include <utility>
 #include <vector>
 
+#include "ss_internal.h"
 #include "ss_kernels.h"
 #include "ss_tables.h"
 
@@ -57,6 +58,7 @@ struct DevBuf {
         return e;
     }
     hipError_t ensure(size_t count) { return count <= n ? hipSuccess : alloc(count); }
+    void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
     hipError_t upload(const std::vector<T> &h)
     {
         hipError_t e = alloc(h.size());
@@ -86,29 +88,82 @@ struct TdTables {
     DevBuf<ssk::TdConst> dev;
 };
 
+// One context per HIP device: device pointers are only valid on the device that allocated them, and
+// hipSetDevice is per thread, so the caches are looked up by the device current at the call.
 struct Ctx {
     std::mutex mu;
-    bool probed = false;
-    int n_devices = 0;
     std::map<size_t, std::unique_ptr<FftTables>> fft;
     std::map<std::pair<uint32_t, size_t>, std::unique_ptr<BinTables>> bins;
     std::map<std::pair<uint32_t, uint32_t>, std::unique_ptr<TdTables>> td;   // (rate, factor | channels << 8)
     DevBuf<double> hist_energies, hist_bounds;
-    // scratch for the handle-less entry points (ss_get_waveform, ss_mid_side)
-    DevBuf<float> scratch_in, scratch_out;
-    DevBuf<unsigned char> scratch_raw;
-    hipStream_t scratch_stream = nullptr;
 };
 
+struct Process {
+    std::mutex mu;
+    bool probed = false;
+    int n_devices = 0;
+    std::map<int, std::unique_ptr<Ctx>> per_device;
+};
+
+Process &process()
+{
+    static Process p;
+    return p;
+}
+
+int current_device()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    return d;
+}
+
+// the table cache of the calling thread's current device
 Ctx &ctx()
 {
-    static Ctx c;
-    return c;
+    Process &p = process();
+    const int d = current_device();
+    std::lock_guard<std::mutex> lk(p.mu);
+    auto &slot = p.per_device[d];
+    if (!slot) slot = std::make_unique<Ctx>();
+    return *slot;
 }
+
+// Scratch of the handle-less entry points (ss_get_waveform, ss_mid_side, ss_pcm_decode): one set per calling
+// thread and device, so concurrent callers never serialise on a shared buffer.
+struct Scratch {
+    DevBuf<float> in, out;
+    DevBuf<unsigned char> raw;
+    hipStream_t stream = nullptr;
+    ~Scratch() { if (stream) (void)hipStreamDestroy(stream); }
+};
+
+Scratch &scratch()
+{
+    thread_local std::map<int, std::unique_ptr<Scratch>> per_device;
+    auto &slot = per_device[current_device()];
+    if (!slot) slot = std::make_unique<Scratch>();
+    return *slot;
+}
+
+// makes `device` current for the scope of one entry point (handles are bound to the device they were created on)
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceScope(int device)
+    {
+        if (device < 0) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = (hipSetDevice(device) == hipSuccess);
+    }
+    ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+#define SS_ON_DEVICE(obj) DeviceScope device_scope_((obj) ? (obj)->device : -1)
 
 int probe_devices()
 {
-    Ctx &c = ctx();
+    Process &c = process();
     std::lock_guard<std::mutex> lk(c.mu);
     if (!c.probed) {
         int n = 0;
@@ -276,9 +331,12 @@ int meter_args_ok(uint32_t channels, uint32_t rate)
 //  handle
 // ============================================================================
 struct ss_analyzer {
+    int device = 0;            // the HIP device this handle's buffers live on
     uint32_t channels = 0, rate = 0;
+    uint32_t meter_rate = 0;   // the rate the current meter was built for (rate sticks on a failed configure, the meter does not change)
     int tp_cfg = 0;            // 0 = crate rule
     int tp_factor = 0;         // effective
+    int tp_cfg_applied = 0;    // the tp_cfg the current meter was built with
     bool meter_ok = false;
     hipStream_t stream = nullptr;
     TdTables *td = nullptr;
@@ -297,29 +355,37 @@ struct ss_analyzer {
 
 namespace {
 
+// EbuR128::new + assignment (analyzer.rs:49-53): the new meter replaces the old one only when every fallible step
+// has succeeded — on failure the handle keeps its previous meter (only sample_rate has changed by then).
 int handle_make_meter(ss_analyzer *h, uint32_t channels, uint32_t rate)
 {
-    h->meter_ok = false;
     int rc = meter_args_ok(channels, rate);
     if (rc) return rc;
-    h->channels = channels;
-    h->tp_factor = h->tp_cfg ? h->tp_cfg : sst::true_peak_factor_for_rate(rate);
-    rc = get_td_tables(rate, h->tp_factor, channels, &h->td);
+    const int tp_factor = h->tp_cfg ? h->tp_cfg : sst::true_peak_factor_for_rate(rate);
+    TdTables *td = nullptr;
+    rc = get_td_tables(rate, tp_factor, channels, &td);
     if (rc) return rc;
     const uint64_t s100 = (rate + 5) / 10;
     uint64_t ring_frames = (uint64_t)rate * 3000 / 1000;
     if (ring_frames % s100) ring_frames += s100 - ring_frames % s100;
-    h->ring_frames = ring_frames;
-    HIPCHK(h->state.alloc(1));
-    HIPCHK(h->hist.alloc(2 * sst::kHistBins));
-    HIPCHK(h->sub.alloc((size_t)ss_analyzer::kSubCap * channels));
-    HIPCHK(h->ring.alloc(ring_frames * channels));
-    HIPCHK(h->counts.alloc(2));
-    HIPCHK(h->out2.alloc(2));
-    HIPCHK(h->ring_scratch.alloc(128));
+    DevBuf<ssk::TdState> state;
+    DevBuf<uint64_t> hist;
+    DevBuf<double> sub, ring, weights, out2, ring_scratch;
+    DevBuf<uint32_t> counts;
+    HIPCHK(state.alloc(1));
+    HIPCHK(hist.alloc(2 * sst::kHistBins));
+    HIPCHK(sub.alloc((size_t)ss_analyzer::kSubCap * channels));
+    HIPCHK(ring.alloc(ring_frames * channels));
+    HIPCHK(counts.alloc(2));
+    HIPCHK(out2.alloc(2));
+    HIPCHK(ring_scratch.alloc(128));
     std::vector<double> w(channels);
     sst::channel_weights(channels, w.data());
-    HIPCHK(h->weights.upload(w));
+    HIPCHK(weights.upload(w));
+    // commit
+    h->channels = channels; h->meter_rate = rate; h->tp_factor = tp_factor; h->tp_cfg_applied = h->tp_cfg; h->td = td; h->ring_frames = ring_frames;
+    h->state.swap(state); h->hist.swap(hist); h->sub.swap(sub); h->ring.swap(ring); h->counts.swap(counts);
+    h->out2.swap(out2); h->ring_scratch.swap(ring_scratch); h->weights.swap(weights);
     h->meter_ok = true;
     return SS_OK;
 }
@@ -327,6 +393,11 @@ int handle_make_meter(ss_analyzer *h, uint32_t channels, uint32_t rate)
 int handle_reset(ss_analyzer *h)
 {
     if (!h->meter_ok) return SS_OK;
+    if (h->tp_cfg != h->tp_cfg_applied) {        // ss_analyzer_set_true_peak_factor since the meter was built
+        HIPCHK(hipStreamSynchronize(h->stream));
+        int rc = handle_make_meter(h, h->channels, h->meter_rate);
+        if (rc) return rc;
+    }
     HIPCHK(hipMemsetAsync(h->state.p, 0, sizeof(ssk::TdState), h->stream));
     HIPCHK(hipMemsetAsync(h->hist.p, 0, h->hist.n * sizeof(uint64_t), h->stream));
     HIPCHK(hipMemsetAsync(h->sub.p, 0, h->sub.n * sizeof(double), h->stream));
@@ -369,6 +440,12 @@ int ss_set_device(int device)
     HIPCHK(hipSetDevice(device));
     return SS_OK;
 }
+int ss_device_synchronize(void)
+{
+    if (require_device()) return SS_ERR_DEVICE;
+    HIPCHK(hipDeviceSynchronize());
+    return SS_OK;
+}
 const char *ss_last_device_error(void) { return g_last_err.c_str(); }
 
 int ss_analyzer_create(uint32_t channels, uint32_t rate, ss_analyzer **out)
@@ -376,21 +453,24 @@ int ss_analyzer_create(uint32_t channels, uint32_t rate, ss_analyzer **out)
     if (!out) return SS_ERR_INVALID_ARG;
     *out = nullptr;
     if (require_device()) return SS_ERR_DEVICE;
-    auto h = std::make_unique<ss_analyzer>();
+    // destroyed (stream included) on every early return
+    std::unique_ptr<ss_analyzer, decltype(&ss_analyzer_destroy)> h(new ss_analyzer(), &ss_analyzer_destroy);
+    h->device = current_device();
     h->rate = rate;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(h->in.alloc(32768));
     HIPCHK(h->fft_out.alloc(16385));
     int rc = handle_make_meter(h.get(), channels, rate);
-    if (rc) { (void)hipStreamDestroy(h->stream); return rc; }
+    if (rc) return rc;
     rc = handle_reset(h.get());
-    if (rc) { (void)hipStreamDestroy(h->stream); return rc; }
+    if (rc) return rc;
     *out = h.release();
     return SS_OK;
 }
 
 void ss_analyzer_destroy(ss_analyzer *h)
 {
+    SS_ON_DEVICE(h);
     if (!h) return;
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
     delete h;
@@ -398,6 +478,7 @@ void ss_analyzer_destroy(ss_analyzer *h)
 
 int ss_analyzer_configure(ss_analyzer *h, uint32_t channels, uint32_t rate)
 {
+    SS_ON_DEVICE(h);
     if (!h) return SS_ERR_INVALID_ARG;
     h->rate = rate;                         // analyzer.rs:50: before the fallible call
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -408,6 +489,7 @@ int ss_analyzer_configure(ss_analyzer *h, uint32_t channels, uint32_t rate)
 
 int ss_analyzer_set_true_peak_factor(ss_analyzer *h, int factor)
 {
+    SS_ON_DEVICE(h);
     if (!h || (factor != 0 && factor != 2 && factor != 4)) return SS_ERR_INVALID_ARG;
     h->tp_cfg = factor;
     return SS_OK;
@@ -416,6 +498,7 @@ int ss_analyzer_set_true_peak_factor(ss_analyzer *h, int factor)
 int ss_get_fft(const ss_analyzer *hc, const float *samples, size_t n,
                double *out_xy, size_t cap_pairs, size_t *out_n)
 {
+    SS_ON_DEVICE(hc);
     ss_analyzer *h = const_cast<ss_analyzer *>(hc);
     if (out_n) *out_n = 0;
     if (!h || (!samples && n) || !out_xy) return SS_ERR_INVALID_ARG;
@@ -523,20 +606,19 @@ int ss_get_waveform(const float *samples, size_t n, double waveform_window,
     if (window == 0 || n == 0) return SS_OK;        // loop body never pushes a point
     if (bins > 0xFFFFFFFFull) return SS_ERR_UNSUPPORTED;
     if (2 * bins > cap_pairs) return SS_ERR_CAPACITY;
-    Ctx &c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
-    if (!c.scratch_stream) HIPCHK(hipStreamCreateWithFlags(&c.scratch_stream, hipStreamNonBlocking));
-    HIPCHK(c.scratch_in.ensure(n));
-    HIPCHK(c.scratch_out.ensure(2 * bins));
-    HIPCHK(hipMemcpyAsync(c.scratch_in.p, samples, n * sizeof(float), hipMemcpyHostToDevice, c.scratch_stream));
+    Scratch &c = scratch();
+    if (!c.stream) HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    HIPCHK(c.in.ensure(n));
+    HIPCHK(c.out.ensure(2 * bins));
+    HIPCHK(hipMemcpyAsync(c.in.p, samples, n * sizeof(float), hipMemcpyHostToDevice, c.stream));
     ssk::WaveParams p{};
-    p.pcm = c.scratch_in.p; p.stream_stride = n; p.n_samples = n; p.n_streams = 1;
-    p.window = (uint32_t)window; p.out = c.scratch_out.p; p.out_stride = 2 * bins;
+    p.pcm = c.in.p; p.stream_stride = n; p.n_samples = n; p.n_streams = 1;
+    p.window = (uint32_t)window; p.out = c.out.p; p.out_stride = 2 * bins;
     if (window > 0xFFFFFFFFull) return SS_ERR_UNSUPPORTED;
-    HIPCHK(ssk::launch_waveform(p, c.scratch_stream));
+    HIPCHK(ssk::launch_waveform(p, c.stream));
     std::vector<float> mm(2 * bins);
-    HIPCHK(hipMemcpyAsync(mm.data(), c.scratch_out.p, 2 * bins * sizeof(float), hipMemcpyDeviceToHost, c.scratch_stream));
-    HIPCHK(hipStreamSynchronize(c.scratch_stream));
+    HIPCHK(hipMemcpyAsync(mm.data(), c.out.p, 2 * bins * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
     for (size_t i = 0; i < bins; i++) {
         out_xy[4 * i + 0] = (double)i; out_xy[4 * i + 1] = (double)mm[2 * i];
         out_xy[4 * i + 2] = (double)i; out_xy[4 * i + 3] = (double)mm[2 * i + 1];
@@ -552,16 +634,15 @@ int ss_mid_side(const float *interleaved, size_t n, float *mid, float *side, siz
     if (!frames) return SS_OK;
     if (!interleaved || !mid || !side) return SS_ERR_INVALID_ARG;
     if (require_device()) return SS_ERR_DEVICE;
-    Ctx &c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
-    if (!c.scratch_stream) HIPCHK(hipStreamCreateWithFlags(&c.scratch_stream, hipStreamNonBlocking));
-    HIPCHK(c.scratch_in.ensure(2 * frames));
-    HIPCHK(c.scratch_out.ensure(2 * frames));
-    HIPCHK(hipMemcpyAsync(c.scratch_in.p, interleaved, 2 * frames * sizeof(float), hipMemcpyHostToDevice, c.scratch_stream));
-    HIPCHK(ssk::launch_mid_side(c.scratch_in.p, frames, c.scratch_out.p, c.scratch_out.p + frames, c.scratch_stream));
-    HIPCHK(hipMemcpyAsync(mid, c.scratch_out.p, frames * sizeof(float), hipMemcpyDeviceToHost, c.scratch_stream));
-    HIPCHK(hipMemcpyAsync(side, c.scratch_out.p + frames, frames * sizeof(float), hipMemcpyDeviceToHost, c.scratch_stream));
-    HIPCHK(hipStreamSynchronize(c.scratch_stream));
+    Scratch &c = scratch();
+    if (!c.stream) HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    HIPCHK(c.in.ensure(2 * frames));
+    HIPCHK(c.out.ensure(2 * frames));
+    HIPCHK(hipMemcpyAsync(c.in.p, interleaved, 2 * frames * sizeof(float), hipMemcpyHostToDevice, c.stream));
+    HIPCHK(ssk::launch_mid_side(c.in.p, frames, c.out.p, c.out.p + frames, c.stream));
+    HIPCHK(hipMemcpyAsync(mid, c.out.p, frames * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipMemcpyAsync(side, c.out.p + frames, frames * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
     if (out_frames) *out_frames = frames;
     return SS_OK;
 }
@@ -635,15 +716,14 @@ int ss_pcm_decode(const void *pcm, size_t n_samples, int format, float *out)
     if (!n_samples) return SS_OK;
     if (!pcm || !out) return SS_ERR_INVALID_ARG;
     if (require_device()) return SS_ERR_DEVICE;
-    Ctx &c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
-    if (!c.scratch_stream) HIPCHK(hipStreamCreateWithFlags(&c.scratch_stream, hipStreamNonBlocking));
-    HIPCHK(c.scratch_raw.ensure(n_samples * sb + 8));
-    HIPCHK(c.scratch_out.ensure(n_samples));
-    HIPCHK(hipMemcpyAsync(c.scratch_raw.p, pcm, n_samples * sb, hipMemcpyHostToDevice, c.scratch_stream));
-    HIPCHK(ssk::launch_pcm_to_f32(c.scratch_raw.p, n_samples, format, c.scratch_out.p, c.scratch_stream));
-    HIPCHK(hipMemcpyAsync(out, c.scratch_out.p, n_samples * sizeof(float), hipMemcpyDeviceToHost, c.scratch_stream));
-    HIPCHK(hipStreamSynchronize(c.scratch_stream));
+    Scratch &c = scratch();
+    if (!c.stream) HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    HIPCHK(c.raw.ensure(n_samples * sb + 8));
+    HIPCHK(c.out.ensure(n_samples));
+    HIPCHK(hipMemcpyAsync(c.raw.p, pcm, n_samples * sb, hipMemcpyHostToDevice, c.stream));
+    HIPCHK(ssk::launch_pcm_to_f32(c.raw.p, n_samples, format, c.out.p, c.stream));
+    HIPCHK(hipMemcpyAsync(out, c.out.p, n_samples * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
     return SS_OK;
 }
 
@@ -651,6 +731,7 @@ int ss_pcm_decode(const void *pcm, size_t n_samples, int format, float *out)
 // no staging copy and no synchronisation — everything is only enqueued on the handle's stream.
 static int add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool on_device)
 {
+    SS_ON_DEVICE(h);
     if (!h) return SS_ERR_INVALID_ARG;
     if (!h->meter_ok) return SS_ERR_INVALID_MODE;
     if (n == 0) return SS_OK;
@@ -698,17 +779,20 @@ static int add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool
 
 int ss_add_samples(ss_analyzer *h, const float *samples, size_t n)
 {
+    SS_ON_DEVICE(h);
     return add_samples_impl(h, samples, n, false);
 }
 
 void ss_reset(ss_analyzer *h)
 {
+    SS_ON_DEVICE(h);
     if (h) (void)handle_reset(h);
 }
 
 // energy of the last `frames` frames of the filtered ring -> out2[1] = loudness (enqueue only)
 static int ring_loudness_enqueue(ss_analyzer *h, uint64_t frames)
 {
+    SS_ON_DEVICE(h);
     HIPCHK(ssk::launch_ring_energy(h->ring.p, h->ring_frames, h->channels, h->frames_fed, frames,
                                    h->weights.p, h->out2.p, h->ring_scratch.p, h->stream));
     return SS_OK;
@@ -716,6 +800,7 @@ static int ring_loudness_enqueue(ss_analyzer *h, uint64_t frames)
 
 static int ring_loudness(ss_analyzer *h, uint64_t frames, double *out)
 {
+    SS_ON_DEVICE(h);
     if (!h || !out) return SS_ERR_INVALID_ARG;
     if (!h->meter_ok) return SS_ERR_INVALID_MODE;
     if (frames > h->ring_frames) return SS_ERR_INVALID_MODE;
@@ -730,18 +815,21 @@ static int ring_loudness(ss_analyzer *h, uint64_t frames, double *out)
 
 int ss_get_shortterm_lufs(ss_analyzer *h, double *out)
 {
+    SS_ON_DEVICE(h);
     if (!h || !h->meter_ok) return h ? SS_ERR_INVALID_MODE : SS_ERR_INVALID_ARG;
     return ring_loudness(h, (uint64_t)h->td->host.s100 * 30, out);
 }
 
 int ss_get_momentary_lufs(ss_analyzer *h, double *out)
 {
+    SS_ON_DEVICE(h);
     if (!h || !h->meter_ok) return h ? SS_ERR_INVALID_MODE : SS_ERR_INVALID_ARG;
     return ring_loudness(h, (uint64_t)h->td->host.s100 * 4, out);
 }
 
 static int hist_eval(ss_analyzer *h, double r[2])
 {
+    SS_ON_DEVICE(h);
     if (!h) return SS_ERR_INVALID_ARG;
     if (!h->meter_ok) return SS_ERR_INVALID_MODE;
     const double *he, *hb;
@@ -755,6 +843,7 @@ static int hist_eval(ss_analyzer *h, double r[2])
 
 int ss_get_integrated_lufs(ss_analyzer *h, double *out)
 {
+    SS_ON_DEVICE(h);
     if (!out) return SS_ERR_INVALID_ARG;
     double r[2];
     int rc = hist_eval(h, r);
@@ -765,6 +854,7 @@ int ss_get_integrated_lufs(ss_analyzer *h, double *out)
 
 int ss_get_loudness_range(ss_analyzer *h, double *out)
 {
+    SS_ON_DEVICE(h);
     if (!out) return SS_ERR_INVALID_ARG;
     double r[2];
     int rc = hist_eval(h, r);
@@ -775,6 +865,7 @@ int ss_get_loudness_range(ss_analyzer *h, double *out)
 
 static int read_peaks(ss_analyzer *h, uint32_t ch, double *sample_pk, double *true_pk)
 {
+    SS_ON_DEVICE(h);
     if (!h) return SS_ERR_INVALID_ARG;
     if (!h->meter_ok) return SS_ERR_INVALID_MODE;
     if (ch >= h->channels) return SS_ERR_INVALID_CHANNEL;
@@ -789,6 +880,7 @@ static int read_peaks(ss_analyzer *h, uint32_t ch, double *sample_pk, double *tr
 
 int ss_get_true_peak(ss_analyzer *h, double *left, double *right)
 {
+    SS_ON_DEVICE(h);
     if (!left || !right) return SS_ERR_INVALID_ARG;
     double l, r;
     int rc = read_peaks(h, 0, nullptr, &l);     // analyzer.rs:160
@@ -801,12 +893,14 @@ int ss_get_true_peak(ss_analyzer *h, double *left, double *right)
 
 int ss_get_true_peak_channel(ss_analyzer *h, uint32_t channel, double *out)
 {
+    SS_ON_DEVICE(h);
     if (!out) return SS_ERR_INVALID_ARG;
     return read_peaks(h, channel, nullptr, out);
 }
 
 int ss_get_sample_peak_channel(ss_analyzer *h, uint32_t channel, double *out)
 {
+    SS_ON_DEVICE(h);
     if (!out) return SS_ERR_INVALID_ARG;
     return read_peaks(h, channel, out, nullptr);
 }
@@ -819,6 +913,7 @@ uint32_t ss_sample_rate(const ss_analyzer *h) { return h ? h->rate : 0; }
 //  batch
 // ============================================================================
 struct ss_batch {
+    int device = 0;             // the HIP device this batch lives on
     ss_batch_config cfg{};
     ss_batch_layout lay{};
     hipStream_t stream = nullptr;
@@ -856,12 +951,19 @@ struct ss_batch {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap = false;
     bool timing = false;
-    hipEvent_t ev[2 * SS_KERNEL_COUNT];
+    hipEvent_t ev[2 * SS_KERNEL_COUNT] = {};
     bool ev_ready = false;
     double t_ms[SS_KERNEL_COUNT] = {0, 0, 0, 0};
     uint64_t t_n[SS_KERNEL_COUNT] = {0, 0, 0, 0};
     bool pending_events = false;
 };
+
+namespace ssi {
+void *batch_corpus_device(ss_batch *b) { return b ? b->corpus.p : nullptr; }
+hipStream_t batch_stream(ss_batch *b) { return b ? b->stream : nullptr; }
+int batch_device(const ss_batch *b) { return b ? b->device : 0; }
+void set_last_error(const std::string &text) { g_last_err = text; }
+}  // namespace ssi
 
 namespace {
 
@@ -889,7 +991,9 @@ int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
     if (require_device()) return SS_ERR_DEVICE;
     if (cfg->n_streams == 0 || cfg->frames_per_stream == 0) return SS_ERR_INVALID_ARG;
     if ((cfg->flags & SS_BATCH_ALL) == 0) return SS_ERR_INVALID_ARG;
-    auto b = std::make_unique<ss_batch>();
+    // destroyed (streams and events included) on every early return
+    std::unique_ptr<ss_batch, decltype(&ss_batch_destroy)> b(new ss_batch(), &ss_batch_destroy);
+    b->device = current_device();
     b->cfg = *cfg;
     const uint32_t C = cfg->channels;
     const uint64_t F = cfg->frames_per_stream;
@@ -926,7 +1030,10 @@ int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
         L.n_bins = (uint32_t)b->bt->count;
         L.first_bin = (uint32_t)b->bt->first;
         b->fft_fast = (C == 2 && n == 4096 && hop % 256 == 0);
-        b->fft_pairw = (C != 2 && n == 4096 && hop == 1024 && !std::getenv("SS_FFT_NO_PAIRW"));
+        b->fft_pairw = (C != 2 && n == 4096 && hop == 1024);
+#ifdef SS_TUNING        // development builds only: the shipped library takes no kernel selection from the environment
+        if (std::getenv("SS_FFT_NO_PAIRW")) b->fft_pairw = false;
+#endif
         {
             // windows per workgroup: long runs amortise the per-workgroup constants and the 3-hop halo,
             // but keep >= ~4096 workgroups (8 rounds of the 512 resident ones) for load balance
@@ -937,7 +1044,9 @@ int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
             wpb = (wpb + 1) & ~1u;
             b->windows_per_block = wpb < 2 ? 2 : wpb;
         }
-        if (const char *e = std::getenv("SS_FFT_WPB")) { int v = std::atoi(e); if (v >= 2 && v <= 4096) b->windows_per_block = (uint32_t)(v & ~1); }   // tuning knob
+#ifdef SS_TUNING
+        if (const char *e = std::getenv("SS_FFT_WPB")) { int v = std::atoi(e); if (v >= 2 && v <= 4096) b->windows_per_block = (uint32_t)(v & ~1); }
+#endif
         L.fft_bin_stride = (L.n_bins + 3u) & ~3u;        // rows start 16-B aligned: 16-byte stores
         L.fft_bytes = (uint64_t)cfg->n_streams * L.n_windows * L.fft_channels * L.fft_bin_stride * sizeof(float);
         HIPCHK(b->fft.alloc((size_t)(L.fft_bytes / sizeof(float))));
@@ -1008,7 +1117,9 @@ int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
             const double sc = score_of(seg, (nsub + seg - 1) / seg);
             if (sc > best * 1.0000001) { best = sc; best_seg = seg; }
         }
-        if (const char *e = std::getenv("SS_TD_SEG_SUB")) best_seg = (uint32_t)std::atoi(e);   // tuning knob
+#ifdef SS_TUNING
+        if (const char *e = std::getenv("SS_TD_SEG_SUB")) best_seg = (uint32_t)std::atoi(e);
+#endif
         if (best_seg >= kTdWarmSub && best_seg < nsub) {
             b->td_seg_sub = best_seg;
             b->td_nseg = (nsub + best_seg - 1) / best_seg;
@@ -1018,30 +1129,26 @@ int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
     }
     for (auto &e : b->ev) HIPCHK(hipEventCreate(&e));
     b->ev_ready = true;
-    if (const char *e = std::getenv("SS_BATCH_OVERLAP")) b->overlap = std::atoi(e) != 0;
-    if (b->overlap) {
-        HIPCHK(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
-    }
     *out = b.release();
     return SS_OK;
 }
 
 void ss_batch_destroy(ss_batch *b)
 {
+    SS_ON_DEVICE(b);
     if (!b) return;
     if (b->stream) { (void)hipStreamSynchronize(b->stream); }
     if (b->stream2) { (void)hipStreamSynchronize(b->stream2); (void)hipStreamDestroy(b->stream2); }
     if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
     if (b->ev_join) (void)hipEventDestroy(b->ev_join);
-    if (b->ev_ready) for (auto &e : b->ev) (void)hipEventDestroy(e);
+    for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
 }
 
 int ss_batch_layout_get(const ss_batch *b, ss_batch_layout *out)
 {
+    SS_ON_DEVICE(b);
     if (!b || !out) return SS_ERR_INVALID_ARG;
     *out = b->lay;
     return SS_OK;
@@ -1049,6 +1156,7 @@ int ss_batch_layout_get(const ss_batch *b, ss_batch_layout *out)
 
 int ss_batch_upload(ss_batch *b, uint32_t first, uint32_t count, const float *pcm)
 {
+    SS_ON_DEVICE(b);
     if (!b || !pcm) return SS_ERR_INVALID_ARG;
     if ((uint64_t)first + count > b->cfg.n_streams) return SS_ERR_INVALID_ARG;
     const size_t per = (size_t)b->cfg.frames_per_stream * b->cfg.channels;
@@ -1060,6 +1168,7 @@ int ss_batch_upload(ss_batch *b, uint32_t first, uint32_t count, const float *pc
 
 int ss_batch_upload_pcm(ss_batch *b, uint32_t first, uint32_t count, const void *pcm, int format)
 {
+    SS_ON_DEVICE(b);
     const size_t sb = ss_pcm_sample_bytes(format);
     if (!b || !pcm || !sb) return SS_ERR_INVALID_ARG;
     if ((uint64_t)first + count > b->cfg.n_streams) return SS_ERR_INVALID_ARG;
@@ -1079,6 +1188,7 @@ int ss_batch_upload_pcm(ss_batch *b, uint32_t first, uint32_t count, const void 
 // batch.  Slots are uploaded as before (the tail of a short stream's slot is never read).
 int ss_batch_set_lengths(ss_batch *b, const uint64_t *frames, uint32_t count)
 {
+    SS_ON_DEVICE(b);
     if (!b || !frames || count != b->cfg.n_streams) return SS_ERR_INVALID_ARG;
     const ss_batch_config &c = b->cfg;
     const uint32_t C = c.channels;
@@ -1113,6 +1223,7 @@ int ss_batch_set_lengths(ss_batch *b, const uint64_t *frames, uint32_t count)
 
 int ss_batch_stream_shape(const ss_batch *b, uint32_t stream, ss_stream_shape *out)
 {
+    SS_ON_DEVICE(b);
     if (!b || !out || stream >= b->cfg.n_streams) return SS_ERR_INVALID_ARG;
     if (b->ragged) {
         out->frames = b->frames_h[stream]; out->n_windows = b->windows_h[stream];
@@ -1147,6 +1258,7 @@ int ss_host_unregister(void *ptr)
 // `pcm` must stay valid (and should be page-locked) until the next ss_batch_sync / ss_batch_results on this batch
 int ss_batch_upload_pcm_async(ss_batch *b, uint32_t first, uint32_t count, const void *pcm, int format)
 {
+    SS_ON_DEVICE(b);
     const size_t sb = ss_pcm_sample_bytes(format);
     if (!b || !pcm || !sb) return SS_ERR_INVALID_ARG;
     if ((uint64_t)first + count > b->cfg.n_streams) return SS_ERR_INVALID_ARG;
@@ -1172,6 +1284,7 @@ int ss_batch_upload_pcm_async(ss_batch *b, uint32_t first, uint32_t count, const
 // a stream shorter than the slot).  Queued on the batch's stream like ss_batch_upload_pcm_async.
 int ss_batch_upload_samples(ss_batch *b, uint32_t stream, const void *pcm, size_t n_samples, int format)
 {
+    SS_ON_DEVICE(b);
     const size_t sb = ss_pcm_sample_bytes(format);
     if (!b || (!pcm && n_samples) || !sb || stream >= b->cfg.n_streams) return SS_ERR_INVALID_ARG;
     const size_t per = (size_t)b->cfg.frames_per_stream * b->cfg.channels;
@@ -1195,6 +1308,7 @@ int ss_batch_upload_samples(ss_batch *b, uint32_t stream, const void *pcm, size_
 
 int ss_batch_download_input(ss_batch *b, uint32_t stream, float *pcm, size_t cap)
 {
+    SS_ON_DEVICE(b);
     if (!b || !pcm || stream >= b->cfg.n_streams) return SS_ERR_INVALID_ARG;
     const size_t per = (size_t)b->cfg.frames_per_stream * b->cfg.channels;
     if (cap < per) return SS_ERR_CAPACITY;
@@ -1207,6 +1321,7 @@ void *ss_batch_input_device_ptr(ss_batch *b) { return b ? b->pcm.p : nullptr; }
 
 int ss_batch_synthesize(ss_batch *b, uint64_t seed, uint32_t first_stream_id)
 {
+    SS_ON_DEVICE(b);
     if (!b) return SS_ERR_INVALID_ARG;
     HIPCHK(ssk::launch_synth(b->pcm.p, b->cfg.n_streams, b->cfg.frames_per_stream, b->cfg.channels,
                              b->cfg.sample_rate, seed, first_stream_id, b->stream));
@@ -1216,6 +1331,7 @@ int ss_batch_synthesize(ss_batch *b, uint64_t seed, uint32_t first_stream_id)
 
 int ss_batch_run(ss_batch *b)
 {
+    SS_ON_DEVICE(b);
     if (!b) return SS_ERR_INVALID_ARG;
     int rc = batch_collect_timing(b);
     if (rc) return rc;
@@ -1265,7 +1381,11 @@ int ss_batch_run(ss_batch *b)
             p.db_offset = (float)(20.0 * std::log10(4.0 / (double)c.fft_n));
             if (c.fft_n == 16384) {
                 p.tw_core = b->ft->core_tw4096; p.tw_256 = b->ft->core_tw256;
-                if (c.hop_frames == 1024 && L.n_windows >= 8 && !std::getenv("SS_FFT16K_SINGLE"))
+                bool run_kernel = (c.hop_frames == 1024 && L.n_windows >= 8);
+#ifdef SS_TUNING
+                if (std::getenv("SS_FFT16K_SINGLE")) run_kernel = false;
+#endif
+                if (run_kernel)
                     HIPCHK(ssk::launch_fft16k_run(p, b->fft_mode, fft_stream));
                 else
                     HIPCHK(ssk::launch_fft16k(p, b->fft_mode, fft_stream));
@@ -1332,6 +1452,7 @@ int ss_batch_run(ss_batch *b)
 
 int ss_batch_sync(ss_batch *b)
 {
+    SS_ON_DEVICE(b);
     if (!b) return SS_ERR_INVALID_ARG;
     HIPCHK(hipStreamSynchronize(b->stream));
     return batch_collect_timing(b);
@@ -1339,6 +1460,7 @@ int ss_batch_sync(ss_batch *b)
 
 int ss_batch_results(ss_batch *b, ss_stream_result *out, uint32_t cap)
 {
+    SS_ON_DEVICE(b);
     if (!b || !out) return SS_ERR_INVALID_ARG;
     const uint32_t n = b->cfg.n_streams;
     if (cap < n) return SS_ERR_CAPACITY;
@@ -1366,8 +1488,77 @@ int ss_batch_results(ss_batch *b, ss_stream_result *out, uint32_t cap)
     return SS_OK;
 }
 
+// every channel's peaks of one stream: EbuR128::true_peak(c) = max(true, sample) and EbuR128::sample_peak(c)
+int ss_batch_peaks(ss_batch *b, uint32_t stream, double *true_pk, double *sample_pk, uint32_t cap_channels)
+{
+    SS_ON_DEVICE(b);
+    if (!b || stream >= b->cfg.n_streams) return SS_ERR_INVALID_ARG;
+    if (!b->state.p) return SS_ERR_INVALID_MODE;                 // the batch runs no meter pass
+    const uint32_t C = b->cfg.channels;
+    if (cap_channels < C) return SS_ERR_CAPACITY;
+    float sp[ssk::kMaxChannels], tp[ssk::kMaxChannels];
+    const ssk::TdState *st = b->state.p + stream;
+    HIPCHK(hipMemcpyAsync(sp, st->sample_peak, C * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(tp, st->true_peak, C * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (uint32_t c = 0; c < C; c++) {
+        if (sample_pk) sample_pk[c] = (double)sp[c];
+        if (true_pk) true_pk[c] = (double)(tp[c] > sp[c] ? tp[c] : sp[c]);
+    }
+    return SS_OK;
+}
+
+int ss_batch_geometry_get(const ss_batch *b, ss_batch_geometry *out)
+{
+    if (!b || !out) return SS_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof *out);
+    const ss_batch_layout &L = b->lay;
+    if ((b->cfg.flags & SS_BATCH_FFT) && L.n_windows) {
+        out->fft_windows_per_block = b->windows_per_block;
+        const bool run16k = b->cfg.fft_n == 16384 && b->cfg.hop_frames == 1024 && L.n_windows >= 8 && !b->fft_fast && !b->fft_pairw;
+        if (b->fft_fast) {
+            out->fft_blocks = b->cfg.n_streams * ((L.n_windows + b->windows_per_block - 1) / b->windows_per_block);
+        } else if (b->fft_pairw) {
+            const uint32_t ppb = b->windows_per_block >> 1, np = (L.n_windows + 1) >> 1;
+            out->fft_blocks = b->cfg.n_streams * L.fft_channels * ((np + ppb - 1) / ppb);
+        } else if (run16k) {
+            uint32_t wpb = 0, groups = 0;
+            ssk::fft16k_run_geometry(b->cfg.n_streams, L.fft_channels, L.n_windows, &wpb, &groups);
+            out->fft_windows_per_block = wpb;
+            out->fft_blocks = b->cfg.n_streams * L.fft_channels * groups;
+        } else {
+            out->fft_windows_per_block = 1;
+            out->fft_blocks = b->cfg.n_streams * L.n_windows * L.fft_channels;
+        }
+    }
+    if (b->td) {
+        out->td_segments = b->td_nseg;
+        out->td_segment_subblocks = b->td_seg_sub;
+        out->td_warm_subblocks = b->td_nseg > 1 ? kTdWarmSub : 0;
+        out->td_true_peak_factor = (uint32_t)b->tp_factor;
+    }
+    out->waveform_fused = (b->wave_fused && !b->ragged) ? 1u : 0u;
+    out->overlap = b->overlap ? 1u : 0u;
+    return SS_OK;
+}
+
+int ss_batch_set_overlap(ss_batch *b, int enable)
+{
+    SS_ON_DEVICE(b);
+    if (!b) return SS_ERR_INVALID_ARG;
+    if (enable && !b->stream2) {
+        HIPCHK(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+    }
+    HIPCHK(hipStreamSynchronize(b->stream));
+    b->overlap = enable != 0;
+    return SS_OK;
+}
+
 int ss_batch_download_fft(ss_batch *b, uint32_t stream, float *out, size_t cap)
 {
+    SS_ON_DEVICE(b);
     if (!b || !out || stream >= b->cfg.n_streams) return SS_ERR_INVALID_ARG;
     const size_t rows = (size_t)b->lay.n_windows * b->lay.fft_channels;
     const size_t per = rows * b->lay.n_bins;
@@ -1384,6 +1575,7 @@ int ss_batch_download_fft(ss_batch *b, uint32_t stream, float *out, size_t cap)
 
 int ss_batch_bin_tables(const ss_batch *b, double *chart_x, double *freq, double *pink_db)
 {
+    SS_ON_DEVICE(b);
     if (!b || !b->bt) return SS_ERR_INVALID_ARG;
     const size_t n = b->bt->count;
     if (chart_x) std::memcpy(chart_x, b->bt->chart_x.data(), n * sizeof(double));
@@ -1394,6 +1586,7 @@ int ss_batch_bin_tables(const ss_batch *b, double *chart_x, double *freq, double
 
 int ss_batch_download_waveform(ss_batch *b, uint32_t stream, float *out, size_t cap)
 {
+    SS_ON_DEVICE(b);
     if (!b || !out || stream >= b->cfg.n_streams) return SS_ERR_INVALID_ARG;
     const size_t pts = b->lay.n_wave_points;
     if (cap < pts) return SS_ERR_CAPACITY;
@@ -1406,6 +1599,7 @@ int ss_batch_download_waveform(ss_batch *b, uint32_t stream, float *out, size_t 
 
 int ss_batch_download_subblocks(ss_batch *b, uint32_t stream, double *out, size_t cap)
 {
+    SS_ON_DEVICE(b);
     if (!b || !out || stream >= b->cfg.n_streams || !b->sub.p) return SS_ERR_INVALID_ARG;
     const size_t per = (size_t)b->lay.n_subblocks * b->cfg.channels;
     if (cap < per) return SS_ERR_CAPACITY;
@@ -1417,6 +1611,7 @@ int ss_batch_download_subblocks(ss_batch *b, uint32_t stream, double *out, size_
 
 int ss_batch_histograms(ss_batch *b, uint64_t *out2000)
 {
+    SS_ON_DEVICE(b);
     if (!b || !out2000 || !b->corpus.p) return SS_ERR_INVALID_ARG;
     HIPCHK(hipMemcpyAsync(out2000, b->corpus.p, 2 * sst::kHistBins * sizeof(uint64_t), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -1425,6 +1620,7 @@ int ss_batch_histograms(ss_batch *b, uint64_t *out2000)
 
 int ss_batch_histograms_device(ss_batch *b, void *dst)
 {
+    SS_ON_DEVICE(b);
     if (!b || !dst || !b->corpus.p) return SS_ERR_INVALID_ARG;
     HIPCHK(hipMemcpyAsync(dst, b->corpus.p, 2 * sst::kHistBins * sizeof(uint64_t), hipMemcpyDeviceToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -1437,6 +1633,7 @@ double ss_corpus_loudness_range(const uint64_t *h) { return h ? sst::loudness_ra
 // ---- render-side reductions ---------------------------------
 int ss_batch_render_spectrum(ss_batch *b, uint32_t cols, int gain_mode, float gain_db)
 {
+    SS_ON_DEVICE(b);
     if (!b || cols == 0 || cols > 65536 || (gain_mode != SS_GAIN_FIXED && gain_mode != SS_GAIN_REFERENCE))
         return SS_ERR_INVALID_ARG;
     const ss_batch_layout &L = b->lay;
@@ -1470,6 +1667,7 @@ int ss_batch_render_spectrum(ss_batch *b, uint32_t cols, int gain_mode, float ga
 
 int ss_batch_download_spectrum_columns(ss_batch *b, uint32_t stream, float *out, size_t cap)
 {
+    SS_ON_DEVICE(b);
     if (!b || !out || stream >= b->cfg.n_streams || !b->render_cols) return SS_ERR_INVALID_ARG;
     const size_t per = (size_t)b->lay.n_windows * b->lay.fft_channels * b->render_cols;
     if (cap < per) return SS_ERR_CAPACITY;
@@ -1480,6 +1678,7 @@ int ss_batch_download_spectrum_columns(ss_batch *b, uint32_t stream, float *out,
 
 int ss_batch_render_waveform(ss_batch *b, uint32_t cols, uint32_t x_min, uint32_t x_max)
 {
+    SS_ON_DEVICE(b);
     if (!b || cols == 0 || cols > 65536 || x_max <= x_min) return SS_ERR_INVALID_ARG;
     if (!(b->cfg.flags & SS_BATCH_WAVEFORM) || !b->wave_window) return SS_ERR_INVALID_MODE;
     HIPCHK(b->render_wave.ensure((size_t)b->cfg.n_streams * cols * 2));
@@ -1491,6 +1690,7 @@ int ss_batch_render_waveform(ss_batch *b, uint32_t cols, uint32_t x_min, uint32_
 
 int ss_batch_download_waveform_columns(ss_batch *b, uint32_t stream, float *out, size_t cap)
 {
+    SS_ON_DEVICE(b);
     if (!b || !out || stream >= b->cfg.n_streams || !b->render_wave_cols) return SS_ERR_INVALID_ARG;
     const size_t per = (size_t)2 * b->render_wave_cols;
     if (cap < per) return SS_ERR_CAPACITY;
@@ -1516,6 +1716,7 @@ void ss_waveform_view(double playhead_ms, double waveform_window_s, size_t chart
 
 int ss_batch_timing_enable(ss_batch *b, int enable)
 {
+    SS_ON_DEVICE(b);
     if (!b) return SS_ERR_INVALID_ARG;
     int rc = batch_collect_timing(b);
     if (rc) return rc;
@@ -1526,6 +1727,7 @@ int ss_batch_timing_enable(ss_batch *b, int enable)
 
 int ss_batch_timing_read(ss_batch *b, int kernel, double *total_ms, uint64_t *launches)
 {
+    SS_ON_DEVICE(b);
     if (!b || kernel < 0 || kernel >= SS_KERNEL_COUNT) return SS_ERR_INVALID_ARG;
     int rc = batch_collect_timing(b);
     if (rc) return rc;
@@ -1598,6 +1800,7 @@ static int integrated_oneshot(uint32_t rate, uint32_t channels, const float *sam
 
 int ss_calculate_integrated_lufs(ss_analyzer *h, uint32_t channels, const float *samples, size_t n, double *out)
 {
+    SS_ON_DEVICE(h);
     if (!h || !out) return SS_ERR_INVALID_ARG;
     return integrated_oneshot(h->rate, channels, samples, n, false, out);
 }
@@ -1608,6 +1811,7 @@ int ss_calculate_integrated_lufs(ss_analyzer *h, uint32_t channels, const float 
 //  Tick drivers: App's per-file / per-device analysis state
 // ============================================================================
 struct ss_session {
+    int device = 0;                     // the HIP device this session lives on
     ss_analyzer *an = nullptr;          // file_analyzer / device_analyzer
     bool is_file = false;
     uint32_t file_channels = 2, rate = 0;
@@ -1732,6 +1936,7 @@ extern "C" {
 
 void ss_session_close(ss_session *s)
 {
+    SS_ON_DEVICE(s);
     if (!s) return;
     if (s->fft_stream) { (void)hipStreamSynchronize(s->fft_stream); (void)hipStreamDestroy(s->fft_stream); }
     if (s->an) ss_analyzer_destroy(s->an);
@@ -1750,6 +1955,7 @@ int ss_session_open_file(const float *interleaved, size_t n_samples, uint32_t ch
     if ((!interleaved && n_samples) || channels == 0 || sample_rate == 0) return SS_ERR_INVALID_ARG;
     if (require_device()) return SS_ERR_DEVICE;
     std::unique_ptr<ss_session, void (*)(ss_session *)> s(new ss_session(), ss_session_close);
+    s->device = current_device();
     s->is_file = true; s->file_channels = channels; s->n_samples = n_samples;
     int rc = session_common_init(s.get(), 2, sample_rate);          // meter: 2 channels (tui.rs:1217-1221)
     if (rc) return rc;
@@ -1806,6 +2012,7 @@ int ss_session_open_capture(uint32_t channels, uint32_t sample_rate, ss_session 
     if ((uint64_t)15 * sample_rate < SS_TICK_WINDOW) return SS_ERR_INVALID_ARG;   // 15*sr - 2^14 underflows (tui.rs:1431)
     if (require_device()) return SS_ERR_DEVICE;
     std::unique_ptr<ss_session, void (*)(ss_session *)> s(new ss_session(), ss_session_close);
+    s->device = current_device();
     s->is_file = false; s->file_channels = channels; s->n_samples = (size_t)30 * sample_rate;
     int rc = session_common_init(s.get(), channels, sample_rate);
     if (rc) return rc;
@@ -1822,6 +2029,7 @@ int ss_session_open_capture(uint32_t channels, uint32_t sample_rate, ss_session 
 
 int ss_session_waveform(ss_session *s, double *out_xy, size_t cap_pairs, size_t *out_n)
 {
+    SS_ON_DEVICE(s);
     if (out_n) *out_n = 0;
     if (!s || !s->is_file || (!out_xy && cap_pairs)) return SS_ERR_INVALID_ARG;
     const size_t pairs = s->waveform_xy.size() / 2;
@@ -1833,6 +2041,7 @@ int ss_session_waveform(ss_session *s, double *out_xy, size_t cap_pairs, size_t 
 
 int ss_session_gain_db(ss_session *s, float *out)
 {
+    SS_ON_DEVICE(s);
     if (!s || !out) return SS_ERR_INVALID_ARG;
     *out = s->gain_db;
     return SS_OK;
@@ -1840,6 +2049,7 @@ int ss_session_gain_db(ss_session *s, float *out)
 
 int ss_session_duration_ms(ss_session *s, uint64_t *out)
 {
+    SS_ON_DEVICE(s);
     if (!s || !out || !s->is_file) return SS_ERR_INVALID_ARG;
     *out = s->duration_ms;
     return SS_OK;
@@ -1847,6 +2057,7 @@ int ss_session_duration_ms(ss_session *s, uint64_t *out)
 
 int ss_session_restart(ss_session *s)
 {
+    SS_ON_DEVICE(s);
     if (!s) return SS_ERR_INVALID_ARG;
     for (double &v : s->lufs) v = -100.0;
     ss_reset(s->an);
@@ -1855,6 +2066,7 @@ int ss_session_restart(ss_session *s)
 
 int ss_session_lufs_history(ss_session *s, double *out300)
 {
+    SS_ON_DEVICE(s);
     if (!s || !out300) return SS_ERR_INVALID_ARG;
     std::memcpy(out300, s->lufs, sizeof s->lufs);
     return SS_OK;
@@ -1864,6 +2076,7 @@ int ss_session_lufs_history(ss_session *s, double *out300)
 int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side_xy,
                          size_t cap_pairs, ss_tick_result *res)
 {
+    SS_ON_DEVICE(s);
     if (!s || !s->is_file || !res || !mid_xy || !side_xy) return SS_ERR_INVALID_ARG;
     if (cap_pairs < s->bt->count || cap_pairs < 1) return SS_ERR_CAPACITY;
     ss_analyzer *h = s->an;
@@ -1936,6 +2149,7 @@ int ss_session_tick_capture(ss_session *s, const float *latest, size_t n, double
                             double *side_xy, size_t cap_pairs, double *wave_xy,
                             size_t wave_cap_pairs, size_t *wave_n, ss_tick_result *res)
 {
+    SS_ON_DEVICE(s);
     if (wave_n) *wave_n = 0;
     if (!s || s->is_file || !res || !mid_xy || !side_xy || !latest) return SS_ERR_INVALID_ARG;
     if (n != s->n_samples) return SS_ERR_INVALID_ARG;

@@ -1,0 +1,453 @@
+// ss_comm.cpp — the one exchange step of the path: SUM all-reduce of the corpus histograms.
+//
+// One process per GPU; streams are sharded over the ranks with no data-path exchange, and the corpus-level
+// integrated-LUFS gate needs exactly one collective: the element-wise sum of every rank's two 1000-bin u64
+// histograms (ebur128 loudness_global_multiple semantics).  The reference has no collective (it analyses one
+// file on one thread); this is north_star's extension.
+//
+// Transport SS_COMM_RCCL: the library opens librccl itself and issues
+//     ncclAllReduce(buf, buf, 2000, ncclUint64, ncclSum, comm, batch_stream)
+// in place on the batch's device histograms — 16 000 bytes, latency-bound on xGMI.  No PyTorch, no MPI.
+// Transport SS_COMM_HOST_TCP: the same entry points staged through host memory over loopback TCP (star through
+// rank 0).  It exists so the rank logic can be run on CPU-only machines and by ranks that share one GPU.
+//
+// Rendezvous (one node): rank 0 writes "<magic> <tcp port> <rccl unique id in hex>" to a file (write + rename,
+// so readers never see a partial file), the other ranks poll for it; rank 0 removes it once every rank has joined.
+#include "../../include/soundscope_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>          // types and enum values only: the functions are resolved with dlsym at ss_comm_init
+
+#include <arpa/inet.h>
+#include <dlfcn.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/socket.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "ss_internal.h"
+
+namespace {
+
+constexpr const char *kMagic = "ssc1";
+constexpr int kJoinTimeoutS = 180;
+
+struct Rccl {
+    void *dl = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+bool rccl_open(Rccl &r, std::string &err)
+{
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        r.dl = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.dl) break;
+    }
+    if (!r.dl) { err = std::string("dlopen(librccl): ") + (dlerror() ? dlerror() : "not found"); return false; }
+    auto sym = [&](const char *n) { return dlsym(r.dl, n); };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.CommCount || !r.AllReduce || !r.GetErrorString) {
+        err = "librccl lacks an expected nccl* symbol";
+        return false;
+    }
+    return true;
+}
+
+// ---- blocking socket helpers --------------------------------------------------------------------------------
+bool send_all(int fd, const void *buf, size_t n)
+{
+    const char *p = static_cast<const char *>(buf);
+    while (n) {
+        const ssize_t k = ::send(fd, p, n, MSG_NOSIGNAL);
+        if (k < 0) { if (errno == EINTR) continue; return false; }
+        p += k; n -= (size_t)k;
+    }
+    return true;
+}
+
+bool recv_all(int fd, void *buf, size_t n)
+{
+    char *p = static_cast<char *>(buf);
+    while (n) {
+        const ssize_t k = ::recv(fd, p, n, 0);
+        if (k < 0) { if (errno == EINTR) continue; return false; }
+        if (k == 0) return false;
+        p += k; n -= (size_t)k;
+    }
+    return true;
+}
+
+std::string hex_of(const unsigned char *p, size_t n)
+{
+    static const char *d = "0123456789abcdef";
+    std::string s(2 * n, '0');
+    for (size_t i = 0; i < n; i++) { s[2 * i] = d[p[i] >> 4]; s[2 * i + 1] = d[p[i] & 15]; }
+    return s;
+}
+
+bool unhex(const std::string &s, unsigned char *p, size_t n)
+{
+    if (s.size() != 2 * n) return false;
+    auto v = [](char c) { return c >= '0' && c <= '9' ? c - '0' : (c >= 'a' && c <= 'f' ? c - 'a' + 10 : -1); };
+    for (size_t i = 0; i < n; i++) {
+        const int a = v(s[2 * i]), b = v(s[2 * i + 1]);
+        if (a < 0 || b < 0) return false;
+        p[i] = (unsigned char)(a * 16 + b);
+    }
+    return true;
+}
+
+bool write_rendezvous(const std::string &path, int port, const ncclUniqueId *id)
+{
+    const std::string tmp = path + ".tmp";
+    FILE *f = std::fopen(tmp.c_str(), "w");
+    if (!f) return false;
+    const std::string hex = id ? hex_of(reinterpret_cast<const unsigned char *>(id->internal), sizeof id->internal) : std::string("-");
+    std::fprintf(f, "%s %d %s\n", kMagic, port, hex.c_str());
+    std::fclose(f);
+    return std::rename(tmp.c_str(), path.c_str()) == 0;
+}
+
+bool read_rendezvous(const std::string &path, int *port, std::string *hex)
+{
+    FILE *f = std::fopen(path.c_str(), "r");
+    if (!f) return false;
+    char magic[16] = {0}, idbuf[600] = {0};
+    int p = 0;
+    const int n = std::fscanf(f, "%15s %d %599s", magic, &p, idbuf);
+    std::fclose(f);
+    if (n != 3 || std::strcmp(magic, kMagic) != 0) return false;
+    *port = p; *hex = idbuf;
+    return true;
+}
+
+}  // namespace
+
+struct ss_comm {
+    int transport = SS_COMM_RCCL, rank = 0, world = 1, device = 0;
+    std::string file;
+    // RCCL
+    Rccl rccl;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    void *dev_scratch = nullptr;           // kScratchBytes, for the small host-buffer collectives
+    // host TCP (star through rank 0)
+    int listen_fd = -1;
+    std::vector<int> peers;                // rank 0: socket of rank r at [r]; others: [0] = socket to rank 0
+    static constexpr size_t kScratchBytes = 1 << 16;
+};
+
+namespace {
+
+int fail(const std::string &text)
+{
+    ssi::set_last_error(text);
+    return SS_ERR_DEVICE;
+}
+
+#define COMM_HIP(expr)                                                            \
+    do {                                                                          \
+        hipError_t e_ = (expr);                                                   \
+        if (e_ != hipSuccess) return fail(std::string(#expr ": ") + hipGetErrorString(e_)); \
+    } while (0)
+#define COMM_NCCL(c, expr)                                                        \
+    do {                                                                          \
+        ncclResult_t r_ = (expr);                                                 \
+        if (r_ != ncclSuccess) return fail(std::string(#expr ": ") + (c)->rccl.GetErrorString(r_)); \
+    } while (0)
+
+// ---- host TCP: every rank connects to rank 0 -----------------------------------------------------------------
+int tcp_listen(ss_comm *c, int *port_out)
+{
+    c->listen_fd = ::socket(AF_INET, SOCK_STREAM, 0);
+    if (c->listen_fd < 0) return fail("socket() failed");
+    sockaddr_in a{};
+    a.sin_family = AF_INET; a.sin_addr.s_addr = htonl(INADDR_LOOPBACK); a.sin_port = 0;     // ephemeral port on 127.0.0.1
+    if (::bind(c->listen_fd, reinterpret_cast<sockaddr *>(&a), sizeof a) != 0 || ::listen(c->listen_fd, 128) != 0)
+        return fail("bind/listen on 127.0.0.1 failed");
+    socklen_t len = sizeof a;
+    ::getsockname(c->listen_fd, reinterpret_cast<sockaddr *>(&a), &len);
+    *port_out = ntohs(a.sin_port);
+    return SS_OK;
+}
+
+int tcp_accept_all(ss_comm *c)
+{
+    c->peers.assign((size_t)c->world, -1);
+    for (int k = 1; k < c->world; k++) {
+        timeval tv{kJoinTimeoutS, 0};
+        fd_set rd; FD_ZERO(&rd); FD_SET(c->listen_fd, &rd);
+        if (::select(c->listen_fd + 1, &rd, nullptr, nullptr, &tv) <= 0) return fail("rank 0: timed out waiting for the other ranks");
+        const int fd = ::accept(c->listen_fd, nullptr, nullptr);
+        if (fd < 0) return fail("accept() failed");
+        int one = 1;
+        ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+        int32_t r = -1;
+        if (!recv_all(fd, &r, sizeof r) || r <= 0 || r >= c->world || c->peers[(size_t)r] != -1) { ::close(fd); return fail("bad rank handshake"); }
+        c->peers[(size_t)r] = fd;
+    }
+    return SS_OK;
+}
+
+int tcp_connect(ss_comm *c, int port)
+{
+    const int fd = ::socket(AF_INET, SOCK_STREAM, 0);
+    if (fd < 0) return fail("socket() failed");
+    sockaddr_in a{};
+    a.sin_family = AF_INET; a.sin_addr.s_addr = htonl(INADDR_LOOPBACK); a.sin_port = htons((uint16_t)port);
+    if (::connect(fd, reinterpret_cast<sockaddr *>(&a), sizeof a) != 0) { ::close(fd); return fail("connect to rank 0 failed"); }
+    int one = 1;
+    ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+    const int32_t r = c->rank;
+    if (!send_all(fd, &r, sizeof r)) { ::close(fd); return fail("rank handshake failed"); }
+    c->peers.assign(1, fd);
+    return SS_OK;
+}
+
+// element-wise reduction of `n` 8-byte words across the ranks, in place (op 0: u64 sum, 1: f64 max)
+int tcp_allreduce(ss_comm *c, void *buf, size_t n, int op)
+{
+    if (c->world == 1) return SS_OK;
+    const size_t bytes = n * 8;
+    if (c->rank == 0) {
+        std::vector<unsigned char> tmp(bytes);
+        for (int r = 1; r < c->world; r++) {
+            if (!recv_all(c->peers[(size_t)r], tmp.data(), bytes)) return fail("host all-reduce: receive failed");
+            if (op == 0) {
+                uint64_t *a = static_cast<uint64_t *>(buf);
+                const uint64_t *b = reinterpret_cast<const uint64_t *>(tmp.data());
+                for (size_t i = 0; i < n; i++) a[i] += b[i];
+            } else {
+                double *a = static_cast<double *>(buf);
+                const double *b = reinterpret_cast<const double *>(tmp.data());
+                for (size_t i = 0; i < n; i++) a[i] = b[i] > a[i] ? b[i] : a[i];
+            }
+        }
+        for (int r = 1; r < c->world; r++)
+            if (!send_all(c->peers[(size_t)r], buf, bytes)) return fail("host all-reduce: send failed");
+    } else {
+        if (!send_all(c->peers[0], buf, bytes) || !recv_all(c->peers[0], buf, bytes)) return fail("host all-reduce: exchange with rank 0 failed");
+    }
+    return SS_OK;
+}
+
+// RCCL all-reduce of a small host buffer through the communicator's device scratch
+int rccl_allreduce_host(ss_comm *c, void *buf, size_t n, ncclDataType_t dt, ncclRedOp_t op)
+{
+    const size_t bytes = n * 8;
+    if (bytes > ss_comm::kScratchBytes) return SS_ERR_CAPACITY;
+    COMM_HIP(hipMemcpyAsync(c->dev_scratch, buf, bytes, hipMemcpyHostToDevice, c->stream));
+    COMM_NCCL(c, c->rccl.AllReduce(c->dev_scratch, c->dev_scratch, n, dt, op, c->comm, c->stream));
+    COMM_HIP(hipMemcpyAsync(buf, c->dev_scratch, bytes, hipMemcpyDeviceToHost, c->stream));
+    COMM_HIP(hipStreamSynchronize(c->stream));
+    return SS_OK;
+}
+
+struct DeviceScope {
+    int prev = -1; bool switched = false;
+    explicit DeviceScope(int device)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = (hipSetDevice(device) == hipSuccess);
+    }
+    ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+};
+
+}  // namespace
+
+extern "C" {
+
+void ss_comm_destroy(ss_comm *c)
+{
+    if (!c) return;
+    if (c->transport == SS_COMM_RCCL) {
+        DeviceScope ds(c->device);
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        if (c->comm && c->rccl.CommDestroy) (void)c->rccl.CommDestroy(c->comm);
+        if (c->dev_scratch) (void)hipFree(c->dev_scratch);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        // librccl stays loaded: unloading a library that owns device state is not worth the risk
+    }
+    for (int fd : c->peers) if (fd >= 0) ::close(fd);
+    if (c->listen_fd >= 0) ::close(c->listen_fd);
+    if (c->rank == 0 && !c->file.empty()) ::unlink(c->file.c_str());
+    delete c;
+}
+
+int ss_comm_init(int transport, int rank, int world, const char *rendezvous_file, ss_comm **out)
+{
+    if (!out) return SS_ERR_INVALID_ARG;
+    *out = nullptr;
+    if ((transport != SS_COMM_RCCL && transport != SS_COMM_HOST_TCP) || world < 1 || rank < 0 || rank >= world) return SS_ERR_INVALID_ARG;
+    if (world > 1 && (!rendezvous_file || !*rendezvous_file)) return SS_ERR_INVALID_ARG;
+    struct Guard { ss_comm *c; ~Guard() { if (c) ss_comm_destroy(c); } } g{new ss_comm()};
+    ss_comm *c = g.c;
+    c->transport = transport; c->rank = rank; c->world = world;
+    c->file = rendezvous_file ? rendezvous_file : "";
+    std::string err;
+    ncclUniqueId id;
+    std::memset(&id, 0, sizeof id);
+    if (transport == SS_COMM_RCCL) {
+        if (ss_device_count() <= 0) return SS_ERR_DEVICE;
+        COMM_HIP(hipGetDevice(&c->device));
+        if (!rccl_open(c->rccl, err)) return fail(err);
+        if (rank == 0) COMM_NCCL(c, c->rccl.GetUniqueId(&id));
+    }
+    int port = 0;
+    if (world > 1) {
+        if (rank == 0) {
+            if (transport == SS_COMM_HOST_TCP) { int rc = tcp_listen(c, &port); if (rc) return rc; }
+            ::unlink(c->file.c_str());
+            if (!write_rendezvous(c->file, port, transport == SS_COMM_RCCL ? &id : nullptr)) return fail("cannot write the rendezvous file " + c->file);
+        } else {
+            std::string hex;
+            const auto t0 = std::chrono::steady_clock::now();
+            while (!read_rendezvous(c->file, &port, &hex)) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(kJoinTimeoutS)) return fail("timed out waiting for rank 0's rendezvous file " + c->file);
+                std::this_thread::sleep_for(std::chrono::milliseconds(20));
+            }
+            if (transport == SS_COMM_RCCL && !unhex(hex, reinterpret_cast<unsigned char *>(id.internal), sizeof id.internal))
+                return fail("rendezvous file holds no RCCL id (mixed transports?)");
+            if (transport == SS_COMM_HOST_TCP && port <= 0) return fail("rendezvous file holds no TCP port (mixed transports?)");
+        }
+    }
+    if (transport == SS_COMM_RCCL) {
+        COMM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        COMM_HIP(hipMalloc(&c->dev_scratch, ss_comm::kScratchBytes));
+        COMM_NCCL(c, c->rccl.CommInitRank(&c->comm, world, id, rank));       // synchronises all ranks: everyone has read the file
+    } else if (world > 1) {
+        int rc = rank == 0 ? tcp_accept_all(c) : tcp_connect(c, port);
+        if (rc) return rc;
+    }
+    if (rank == 0 && world > 1) { ::unlink(c->file.c_str()); }
+    g.c = nullptr;
+    *out = c;
+    return SS_OK;
+}
+
+// Launchers that export RANK / WORLD_SIZE (torchrun, used purely as a process launcher): the rendezvous file is
+// SS_COMM_FILE if set, otherwise /tmp/ss_comm_<launcher pid>_<launcher start time>_<MASTER_PORT> — all ranks are
+// children of one launcher process, and the start time keeps a recycled pid from matching a stale file.
+int ss_comm_init_from_env(int transport, ss_comm **out)
+{
+    const char *r = std::getenv("RANK"), *w = std::getenv("WORLD_SIZE");
+    const int rank = r ? std::atoi(r) : 0, world = w ? std::atoi(w) : 1;
+    std::string file;
+    if (const char *f = std::getenv("SS_COMM_FILE")) {
+        file = f;
+    } else {
+        const long ppid = (long)::getppid();
+        unsigned long long start = 0;
+        char path[64];
+        std::snprintf(path, sizeof path, "/proc/%ld/stat", ppid);
+        if (FILE *f = std::fopen(path, "r")) {
+            char buf[1024];
+            if (std::fgets(buf, sizeof buf, f)) {
+                if (const char *p = std::strrchr(buf, ')')) {           // field 22 (starttime), counted after the command name
+                    int field = 2;
+                    for (p++; *p && field < 22; p++) if (*p == ' ') field++;
+                    start = std::strtoull(p, nullptr, 10);
+                }
+            }
+            std::fclose(f);
+        }
+        const char *mp = std::getenv("MASTER_PORT");
+        file = "/tmp/ss_comm_" + std::to_string(ppid) + "_" + std::to_string(start) + "_" + (mp ? mp : "0") + ".rdzv";
+    }
+    return ss_comm_init(transport, rank, world, file.c_str(), out);
+}
+
+int ss_comm_rank(const ss_comm *c) { return c ? c->rank : -1; }
+
+int ss_comm_size(const ss_comm *c)
+{
+    if (!c) return 0;
+    if (c->transport == SS_COMM_RCCL && c->comm) {
+        int n = 0;
+        if (c->rccl.CommCount(c->comm, &n) == ncclSuccess) return n;
+        return 0;
+    }
+    if (c->world == 1) return 1;
+    if (c->rank == 0) { int n = 1; for (int fd : c->peers) if (fd >= 0) n++; return n; }
+    return c->world;
+}
+
+const char *ss_comm_transport_name(const ss_comm *c)
+{
+    if (!c) return "none";
+    return c->transport == SS_COMM_RCCL ? "rccl" : "host-tcp";
+}
+
+int ss_comm_allreduce_u64_sum(ss_comm *c, uint64_t *inout, size_t n)
+{
+    if (!c || (!inout && n)) return SS_ERR_INVALID_ARG;
+    if (!n) return SS_OK;
+    if (c->transport == SS_COMM_RCCL) { DeviceScope ds(c->device); return rccl_allreduce_host(c, inout, n, ncclUint64, ncclSum); }
+    return tcp_allreduce(c, inout, n, 0);
+}
+
+int ss_comm_allreduce_f64_max(ss_comm *c, double *inout, size_t n)
+{
+    if (!c || (!inout && n)) return SS_ERR_INVALID_ARG;
+    if (!n) return SS_OK;
+    if (c->transport == SS_COMM_RCCL) { DeviceScope ds(c->device); return rccl_allreduce_host(c, inout, n, ncclFloat64, ncclMax); }
+    return tcp_allreduce(c, inout, n, 1);
+}
+
+int ss_comm_barrier(ss_comm *c)
+{
+    uint64_t one = 1;
+    int rc = ss_comm_allreduce_u64_sum(c, &one, 1);
+    if (rc) return rc;
+    return one == (uint64_t)c->world ? SS_OK : fail("barrier: rank count mismatch");
+}
+
+int ss_batch_allreduce_histograms(ss_batch *b, ss_comm *c, uint64_t *out2000)
+{
+    if (!b || !c) return SS_ERR_INVALID_ARG;
+    void *hist = ssi::batch_corpus_device(b);
+    if (!hist) return SS_ERR_INVALID_MODE;                     // the batch runs no meter pass
+    DeviceScope ds(ssi::batch_device(b));
+    hipStream_t s = ssi::batch_stream(b);
+    constexpr size_t kWords = 2000;
+    if (c->transport == SS_COMM_RCCL) {
+        if (c->device != ssi::batch_device(b)) return SS_ERR_INVALID_ARG;
+        // in place on the batch's stream, behind the kernels of ss_batch_run
+        COMM_NCCL(c, c->rccl.AllReduce(hist, hist, kWords, ncclUint64, ncclSum, c->comm, s));
+        if (out2000) {
+            COMM_HIP(hipMemcpyAsync(out2000, hist, kWords * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+            COMM_HIP(hipStreamSynchronize(s));
+        }
+        return SS_OK;
+    }
+    std::vector<uint64_t> h(kWords);
+    COMM_HIP(hipMemcpyAsync(h.data(), hist, kWords * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    COMM_HIP(hipStreamSynchronize(s));
+    int rc = tcp_allreduce(c, h.data(), kWords, 0);
+    if (rc) return rc;
+    COMM_HIP(hipMemcpyAsync(hist, h.data(), kWords * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    COMM_HIP(hipStreamSynchronize(s));
+    if (out2000) std::memcpy(out2000, h.data(), kWords * sizeof(uint64_t));
+    return SS_OK;
+}
+
+}  // extern "C"

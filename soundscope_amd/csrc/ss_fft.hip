@@ -967,19 +967,28 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
 #undef X2W
 }
 
+// run geometry of k_fft16k_run: enough workgroups to fill 256 CUs x 2, runs of at least 16 windows (the run's first
+// window costs a full load)
+void fft16k_run_geometry(uint32_t n_streams, uint32_t fft_ch, uint32_t n_windows, uint32_t *windows_per_block, uint32_t *groups_out)
+{
+    const uint64_t pairs = (uint64_t)n_streams * fft_ch;
+    uint32_t groups = (uint32_t)((4096 + pairs - 1) / pairs);
+    const uint32_t max_groups = n_windows / 16u ? n_windows / 16u : 1u;
+    if (groups > max_groups) groups = max_groups;
+    if (groups < 1) groups = 1;
+    const uint32_t wpb = (n_windows + groups - 1) / groups;
+    *windows_per_block = wpb;
+    *groups_out = (n_windows + wpb - 1) / wpb;
+}
+
 // runs of windows at hop 1024 (batches); `mode` as launch_fft16k
 hipError_t launch_fft16k_run(FftBatchParams p, int mode, hipStream_t s)
 {
     if (p.n_windows == 0 || p.n_streams == 0 || p.n_bins == 0) return hipSuccess;
     const uint32_t fft_ch = (mode == 0) ? 1u : (mode == 1 ? 2u : p.channels);
-    // enough workgroups to fill 256 CUs x 2, runs of at least 16 windows (the run's first window costs a full load)
     const uint64_t pairs = (uint64_t)p.n_streams * fft_ch;
-    uint32_t groups = (uint32_t)((4096 + pairs - 1) / pairs);
-    const uint32_t max_groups = p.n_windows / 16u ? p.n_windows / 16u : 1u;
-    if (groups > max_groups) groups = max_groups;
-    if (groups < 1) groups = 1;
-    p.windows_per_block = (p.n_windows + groups - 1) / groups;
-    groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
+    uint32_t groups = 1;
+    fft16k_run_geometry(p.n_streams, fft_ch, p.n_windows, &p.windows_per_block, &groups);
     const dim3 grid((uint32_t)((pairs * groups + 7) & ~(uint64_t)7)), block(256);      // multiple of 8: see the XCD mapping in the kernel
     if (mode == 1) hipLaunchKernelGGL(k_fft16k_run<true>, grid, block, 0, s, p, fft_ch);
     else hipLaunchKernelGGL(k_fft16k_run<false>, grid, block, 0, s, p, fft_ch);
@@ -990,13 +999,6 @@ hipError_t launch_fft16k(const FftBatchParams &p, int mode, hipStream_t s)
 {
     if (p.n_windows == 0 || p.n_streams == 0 || p.n_bins == 0) return hipSuccess;
     const uint32_t fft_ch = (mode == 0) ? 1u : (mode == 1 ? 2u : p.channels);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft16k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 0);
-        (void)e;
-        attr_set = true;
-    }
     hipLaunchKernelGGL(k_fft16k, dim3(p.n_streams * p.n_windows * fft_ch), dim3(512), 0, s, p, mode == 1 ? 1 : 0, fft_ch);
     return hipGetLastError();
 }
@@ -1102,12 +1104,11 @@ hipError_t launch_fft_generic(const FftBatchParams &p, int mode, hipStream_t s)
     int log2m = 0;
     while ((1u << log2m) < m) log2m++;
     const size_t lds = (size_t)(m ? m : 1) * sizeof(float2);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> prepared{0};
+    if (first_use_on_device(prepared)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_generic),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        if (e != hipSuccess) return e;
-        attr_set = true;
+        if (e != hipSuccess) { prepared = 0; return e; }
     }
     dim3 grid(p.n_streams * p.n_windows * fft_ch), block(256);
     hipLaunchKernelGGL(k_fft_generic, grid, block, lds, s, p, mode, log2m);

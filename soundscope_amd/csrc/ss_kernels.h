@@ -3,10 +3,23 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 
 namespace ssk {
+
+// hipFuncSetAttribute applies to the current device only: a launcher remembers, per device, whether its kernel has
+// been prepared there (bit d of the mask).  Returns true when the caller still has to prepare device d.
+inline bool first_use_on_device(std::atomic<uint64_t> &mask)
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    const uint64_t bit = 1ull << (d & 63);
+    if (mask.load(std::memory_order_relaxed) & bit) return false;
+    mask.fetch_or(bit, std::memory_order_relaxed);
+    return true;
+}
 
 constexpr int kHistBins = 1000;
 constexpr int kMaxChannels = 64;
@@ -48,6 +61,7 @@ hipError_t launch_fft16k(const FftBatchParams &p, int mode, hipStream_t s);
 // N = 4096, hop 1024, one real channel per workgroup run, two windows per transform (mode 0 mono, 2 per channel)
 hipError_t launch_fft4096_pairw(const FftBatchParams &p, int mode, hipStream_t s);
 hipError_t launch_fft16k_run(FftBatchParams p, int mode, hipStream_t s);   // hop 1024, runs of windows
+void fft16k_run_geometry(uint32_t n_streams, uint32_t fft_ch, uint32_t n_windows, uint32_t *windows_per_block, uint32_t *groups);
 
 // ---- time domain ------------------------------------------------------------
 struct TdConst {                 // one per (rate, true-peak factor), device resident

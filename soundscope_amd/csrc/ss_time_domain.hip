@@ -713,12 +713,11 @@ static hipError_t td_launch(const TdParams &p, hipStream_t s)
     wave_floats = (wave_floats + 3u) & ~3u;
     const size_t lds = (size_t)wave_floats * 4 * kTdWavesPerBlock;
     auto fn = k_time_domain<FACTOR, RING, CT, WAVE>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> prepared{0};
+    if (first_use_on_device(prepared)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
+        if (e != hipSuccess) { prepared = 0; return e; }
     }
     const uint32_t waves = p.n_streams * p.nseg;
     const uint32_t blocks = (waves + kTdWavesPerBlock - 1) / kTdWavesPerBlock;

@@ -1,8 +1,9 @@
 """Worker for tests/test_distributed_gloo.py: one rank of the sharded corpus gate on CPU (gloo).
 
 Each rank computes the block / short-term histograms of ITS shard of streams (with the oracle,
-standing in for the per-GPU kernels), the ranks all-reduce the 2x1000 histograms with the same
-helper bench.py uses, and every rank evaluates the gate redundantly."""
+standing in for the per-GPU kernels), the ranks all-reduce the 2x1000 histograms over gloo (torch is
+test-side transport here; the product's own collective is covered by _comm_worker.py), and every rank
+evaluates the gate redundantly with the product's host logic."""
 import os
 import sys
 
@@ -16,7 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from conftest import make_stereo  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
-from soundscope_amd.distributed import allreduce_histograms, corpus_gate, shard_streams  # noqa: E402
+from soundscope_amd.distributed import corpus_gate, shard_streams  # noqa: E402
 
 N_STREAMS, RATE, FRAMES = 7, 48000, 48000 * 4
 
@@ -40,7 +41,7 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     first, count = shard_streams(N_STREAMS, rank, world)
     t = torch.from_numpy(hist_of(range(first, first + count)))
-    allreduce_histograms(t)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
     got_i, got_lra = corpus_gate(t.numpy())
     ref = hist_of(range(N_STREAMS))
     assert np.array_equal(t.numpy(), ref), "all-reduced histogram != single-process sum"
