@@ -10,7 +10,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsoundscope_hip.so")
+# SOUNDSCOPE_HIP_LIB: load another build of the same library (A/B runs of kernel variants, tools/ab_libs.sh)
+LIB_PATH = os.environ.get("SOUNDSCOPE_HIP_LIB") or os.path.join(_HERE, "lib", "libsoundscope_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 # every symbol include/soundscope_hip.h declares (checked by tests/test_abi.py)

@@ -51,6 +51,7 @@ namespace ssk {
 // ============================================================================
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
 
 
 template <int FACTOR>
@@ -72,8 +73,17 @@ __device__ __forceinline__ void mat4_apply_add(const double *__restrict__ M, con
 #ifndef SS_TP_F16
 #define SS_TP_F16 1
 #endif
+#ifndef SS_TP_K32
+#define SS_TP_K32 0      // 1: v_mfma_f32_16x16x32_f16 for A_hi (B_hi + B_lo).  Measured no faster than three K = 16 products, and with
+                         // it the spectrum kernel running BESIDE this one (overlap mode) returned isolated wrong windows (tools/probe_overlap_race.py);
+                         // never with the K = 16 form.  Kept for the record, not compiled.
+#endif
 constexpr int kTdHaloFrames = 24;     // minimum halo: >= HIST-1 of the longest branch (multiple of 4: the tile stays 16-B aligned)
-constexpr int kTdTailFrames = 16;     // slack past the tile end for the last MFMA window
+constexpr int kTdTailFrames = 16;     // zeroed slack past the tile end: K-weighting look-ahead and the last f32 MFMA window
+// floats of slack behind a wave's tile: the zeroed frames above, or — larger — room for the planar f16 true-peak layout
+// (12 frames of history + the last 256-byte block, which may run past the tile); kept tight: at 8 channels 64 more
+// floats per wave would cost a quarter of the resident waves
+__host__ __device__ constexpr uint32_t td_slack_floats(uint32_t C) { return (12u * C + 64u) > (16u * C) ? (12u * C + 64u) : (16u * C); }
 constexpr int kTdWavesPerBlock = 4;
 #ifndef SS_TD_PREFETCH
 #define SS_TD_PREFETCH 8
@@ -122,6 +132,23 @@ constexpr int kTdBatch = 11;          // LDS reads issued together in the sequen
     u3 = fma(b3, v0_, u4);                       \
     u4 = b4 * v0_;
 
+// maximum over the wave of a non-negative float, as its bit pattern in an SGPR (non-negative floats order like
+// unsigned integers): four DPP row rotations and three scalar maxima — no LDS crossbar traffic
+__device__ __forceinline__ uint32_t wave_max_nonneg_bits(float v)
+{
+#define SS_ROW_ROR_(x, n_) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x120 | (n_), 0xF, 0xF, false))
+    v = fmaxf(v, SS_ROW_ROR_(v, 8));
+    v = fmaxf(v, SS_ROW_ROR_(v, 4));
+    v = fmaxf(v, SS_ROW_ROR_(v, 2));
+    v = fmaxf(v, SS_ROW_ROR_(v, 1));
+#undef SS_ROW_ROR_
+    const int b = __float_as_int(v);
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane(b, 0), r1 = (uint32_t)__builtin_amdgcn_readlane(b, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane(b, 32), r3 = (uint32_t)__builtin_amdgcn_readlane(b, 48);
+    const uint32_t m01 = r0 > r1 ? r0 : r1, m23 = r2 > r3 ? r2 : r3;
+    return m01 > m23 ? m01 : m23;
+}
+
 // CT: compile-time channel count (0 = runtime)
 // WAVE: 0 no decimation, 1 fused get_waveform (any bin geometry), 2 the same for an exact-integer samples-per-bin that is
 // a multiple of four (<= 128) with 16-byte aligned tiles (the host checks), 3 the same for 128 < spp <= 1000
@@ -132,11 +159,21 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
     using Cfg = TpCfg<FACTOR>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave_in_block = threadIdx.x >> 6;
+    // wave-uniform by construction: tell the compiler, so that everything derived from it (stream, segment, tile
+    // geometry, loop bounds) lives in SGPRs and branches on the scalar unit instead of through exec masks
+    const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t gw = blockIdx.x * kTdWavesPerBlock + wave_in_block;   // global wave = (stream, segment)
     if (gw >= p.n_streams * p.nseg) return;                                // whole wave leaves (no barriers used)
     const uint32_t stream = gw / p.nseg, sg = gw - stream * p.nseg;
 
+#ifdef SS_TD_SKEW
+    // Waves of a SIMD run tiles of equal length in step, so their matrix-pipe phases (true peak) coincide and nothing
+    // overlaps them.  Delay each wave by its slot in the SIMD times a fraction of a tile.
+    if (p.nseg > 1) {
+        const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3u;      // HW_ID.wave_id
+        for (uint32_t i = 0; i < slot * SS_TD_SKEW; i++) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     float *tilebuf = reinterpret_cast<float *>(smem) + (size_t)wave_in_block * wave_lds_floats;
     const TdConst &K = *p.k;
     const uint32_t C = CT ? (uint32_t)CT : p.channels;
@@ -221,29 +258,52 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
         }
         tp_lane_off = ((int)((uint32_t)mrow / C) * Cfg::BLK - (Cfg::HIST - 1) + kq) * (int)C + (int)tp_c;
     }
-    // f16 form of the same product (factor 4, K = 16 in ONE v_mfma_f32_16x16x16_f16): taps and samples are split
-    // into f16 pairs, c = c_hi + c_lo, 256 x = x_hi + x_lo, and hi*hi + hi*lo + lo*hi accumulate in f32 (the dropped
-    // lo*lo and the split remainders are < 1e-6 relative).  18 cycles per MFMA instead of 32 and four times the
-    // depth, and unlike the f32 MFMA it runs beside other waves' f64 VALU work (tools/ubench4.hip).
-    // Lane (mrow, kq) holds A[mrow][4 kq + j] and B[4 kq + j][mrow], j = 0..3.
-    constexpr bool kTpF16 = (FACTOR == 4) && (SS_TP_F16 != 0);
-    halfx4 a16_hi = {0, 0, 0, 0}, a16_lo = {0, 0, 0, 0};
-    int tp_lane_off16 = 0;
-    if (kTpF16) {
-        const int fph = mrow / Cfg::BLK, r = mrow - fph * Cfg::BLK;
+    // Planar f16-split form of the same product (factor 4, channel counts that divide 16): after the K-weighting
+    // passes of a tile every sample is converted ONCE to an f16 pair, s x = x_hi + x_lo with s a power of two taken
+    // from the tile's own sample peak (so accuracy does not depend on level and nothing over- or underflows), and
+    // stored IN PLACE over the f32 tile (dead by then; the next tile's halo is copied out first) in 256-byte blocks
+    // of FB = 64 / C frames: [hi c = 0 .. C-1][lo c = 0 .. C-1], FB halves each, block k holding converted frames
+    // [k FB - 12, (k + 1) FB - 12).  A block occupies exactly the bytes of FB source frames, so the conversion walks
+    // the blocks from the top down and never overwrites a sample it still has to read.
+    // Column (channel, block of 4 outputs b) then reads its 16-sample window [4 b - 12, 4 b + 4) as aligned 8-byte
+    // pieces, and D = A_hi (B_hi + B_lo) + A_lo B_hi runs as
+    //   v_mfma_f32_16x16x32_f16  A = [a_hi | a_hi], B = [x_hi ; x_lo]     (K = 32 at the issue cost of K = 16)
+    //   v_mfma_f32_16x16x16_f16  A = a_lo,          B = x_hi
+    // with rows (phase f, output r), A[(f,r)][k] = c_f[12 + r - k]; the dropped lo*lo term and the split
+    // remainders are < 2^-21 of the tile's peak.  One group of 16 columns advances every window by exactly one block,
+    // so the three read addresses of a lane just step by 256 bytes per group.  Unlike the f32 MFMA this runs beside
+    // other waves' f64 VALU work (tools/ubench4.hip), and the per-window split that used to cost 18 VALU
+    // lane-instructions per sample is about 4.
+    constexpr bool kTpPlanar = (FACTOR == 4) && (SS_TP_F16 != 0);
+    // MFMA 1 (v_mfma_f32_16x16x32_f16, K = 32 at the issue cost of K = 16): A = [a_hi | a_hi], B = [x_hi ; x_lo]
+    // MFMA 2 (v_mfma_f32_16x16x16_f16):                                     A = a_lo,          B = x_hi
+    halfx8 a32 = {0, 0, 0, 0, 0, 0, 0, 0};              // lane (mrow, kq): a_hi[8 (kq & 1) + j], j = 0..7
+    halfx4 a16_lo = {0, 0, 0, 0};                       // lane (mrow, kq): a_lo[4 kq + j], j = 0..3
+    halfx4 a16_hi = {0, 0, 0, 0};                       // (SS_TP_K32 == 0: three K = 16 products instead)
+    if (kTpPlanar) {
+        const int fph = mrow >> 2, r = mrow & 3;       // rows 0..11 = (phase, output); rows 12..15 are zero
+        auto tap = [&](int k) -> float {               // A[(f, r)][k] = c_f[12 + r - k]
+            const int t = 12 + r - k;
+            return (mrow < 12 && t >= 0 && t < 12) ? K.tp[fph][t] : 0.0f;
+        };
+#pragma unroll
+        for (int j = 0; j < 8; j++) a32[j] = (_Float16)tap(8 * (kq & 1) + j);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int k = 4 * kq + j;
-            const int t = Cfg::HIST - 1 + r - k;
-            const float c = (mrow < Cfg::ROWS && t >= 0 && t < Cfg::HIST) ? K.tp[fph][t] : 0.0f;
-            const _Float16 ch_ = (_Float16)c;
-            a16_hi[j] = ch_;
-            a16_lo[j] = (_Float16)(c - (float)ch_);
+            const float c = tap(4 * kq + j);
+            a16_lo[j] = (_Float16)(c - (float)(_Float16)c);
+            a16_hi[j] = (_Float16)c;
         }
-        tp_lane_off16 = ((int)((uint32_t)mrow / C) * Cfg::BLK - (Cfg::HIST - 1) + 4 * kq) * (int)C + (int)tp_c;
     }
-    float tp_run16 = 0.0f;                              // running max of the f16 path, in units of 256
-    uint32_t tp_clean = carry_in ? 0u : 0x40000000u;    // frames before the current tile known to be within +-128 (a carried halo may hold anything)
+    // sample peak (as bits of a non-negative float) of the 12 frames in front of the current tile: the FIR window
+    // reaches them, so they take part in the choice of the tile's scale.  A streaming call starts from carried history.
+    uint32_t tp_prev_bits = 0;
+    if (kTpPlanar && carry_in) {
+        float h = 0.0f;
+        if (lane < C)
+            for (int q = 1; q <= 12; q++) h = fmaxf(h, fabsf(tile[-(int)(q * C) + (int)lane]));
+        tp_prev_bits = wave_max_nonneg_bits(h);
+    }
     const double a1 = K.a[1], a2 = K.a[2], a3 = K.a[3], a4 = K.a[4];
     const double b0 = K.b[0], b1 = K.b[1], b2 = K.b[2], b3 = K.b[3], b4 = K.b[4];
 
@@ -497,43 +557,20 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
             }
             if (!warm) { e_run += e; sp_run = fmaxf(sp_run, sp); }
         }
-        // the f16 true-peak product needs 256 |x| inside the f16 range: a wave-uniform test on the sample peaks of this
-        // tile and of the frames before it that the FIR window can reach
-        const bool tp_big_now = kTpF16 && (__ballot(sp > 128.0f) != 0ull);
-        const bool tp_big = tp_big_now || tp_clean < (uint32_t)(Cfg::HIST - 1);
-        tp_clean = tp_big_now ? 0u : (tp_clean + seg < 0x40000000u ? tp_clean + seg : 0x40000000u);
         // ---- true peak on the matrix pipe (not during the run-in)
+        bool halo_done = false;
+        const uint32_t tp_now_bits = kTpPlanar ? wave_max_nonneg_bits(sp) : 0u;      // this tile's sample peak, wave-uniform
         if (FACTOR != 0 && !warm) {
-            const uint32_t nblk = (seg + Cfg::BLK - 1) / Cfg::BLK;     // blocks per channel
-            const uint32_t ncol = nblk * C;
-            const uint32_t ngroups = (ncol + 15) >> 4;
-            if (tp_fixed) {
-                constexpr int GS = 16 * Cfg::BLK;                      // floats per group (16 columns x BLK outputs)
-                const uint32_t nfull = seg / (tp_bpg * Cfg::BLK);      // groups whose every output lies inside the tile
+            // f32 product (bit-exact fmaf chain) over `nfr` frames starting at float offset `base_f` of the tile
+            auto tp_f32_range = [&](uint32_t first_frame, uint32_t nfr) {
+                const float *t0 = tile + (size_t)first_frame * C;
+                const uint32_t nblk = (nfr + Cfg::BLK - 1) / Cfg::BLK;     // blocks per channel
+                const uint32_t ncol = nblk * C;
+                const uint32_t ngroups = (ncol + 15) >> 4;
+                constexpr int GS = 16 * Cfg::BLK;                          // floats per group (16 columns x BLK outputs)
+                const uint32_t nfull = nfr / (tp_bpg * Cfg::BLK);          // groups whose every output lies inside the range
                 uint32_t gi = 0;
-                if (kTpF16 && !tp_big) {                                // anything beyond +-128 full scale takes the f32 product below
-                    const float *bq = tile + tp_lane_off16;
-                    for (; gi + 2 <= nfull; gi += 2, bq += 2 * GS) {
-                        halfx4 h0, l0, h1, l1;
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const float x0 = bq[j * (int)C] * 256.0f, x1 = bq[GS + j * (int)C] * 256.0f;
-                            const _Float16 xh0 = (_Float16)x0, xh1 = (_Float16)x1;
-                            h0[j] = xh0; l0[j] = (_Float16)(x0 - (float)xh0);      // exact remainder, then rounded to f16
-                            h1[j] = xh1; l1[j] = (_Float16)(x1 - (float)xh1);
-                        }
-                        floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_hi, h0, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_hi, h1, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_hi, l0, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_hi, l1, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_lo, h0, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_lo, h1, acc1, 0, 0, 0);
-                        tp_run16 = fmaxf(fmaxf(tp_run16, fmaxf(fabsf(acc0[0]), fabsf(acc0[1]))), fmaxf(fabsf(acc0[2]), fabsf(acc0[3])));
-                        tp_run16 = fmaxf(fmaxf(tp_run16, fmaxf(fabsf(acc1[0]), fabsf(acc1[1]))), fmaxf(fabsf(acc1[2]), fabsf(acc1[3])));
-                    }
-                }
-                const float *bp = tile + tp_lane_off + (size_t)gi * GS;
+                const float *bp = t0 + tp_lane_off;
                 for (; gi + 2 <= nfull; gi += 2, bp += 2 * GS) {
                     floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                     float bv0[Cfg::KSTEPS], bv1[Cfg::KSTEPS];
@@ -547,7 +584,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
                     tp_run = fmaxf(fmaxf(tp_run, fmaxf(fabsf(acc0[0]), fabsf(acc0[1]))), fmaxf(fabsf(acc0[2]), fabsf(acc0[3])));
                     tp_run = fmaxf(fmaxf(tp_run, fmaxf(fabsf(acc1[0]), fabsf(acc1[1]))), fmaxf(fabsf(acc1[2]), fabsf(acc1[3])));
                 }
-                for (; gi < ngroups; gi++, bp += GS) {                 // odd full group and the masked tail
+                for (; gi < ngroups; gi++, bp += GS) {                     // odd full group and the masked tail
                     const uint32_t bi = gi * tp_bpg + (uint32_t)mrow / C;
                     const bool col_ok = (gi * 16 + (uint32_t)mrow) < ncol;
                     floatx4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -557,14 +594,197 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
 #pragma unroll
                     for (int reg = 0; reg < 4; reg++) {
                         const int row = 4 * kq + reg;
-                        const bool ok = col_ok && (bi * Cfg::BLK + (uint32_t)(row % Cfg::BLK)) < seg;
+                        const bool ok = col_ok && (bi * Cfg::BLK + (uint32_t)(row % Cfg::BLK)) < nfr;
                         tp_run = fmaxf(tp_run, ok ? fabsf(acc[reg]) : 0.0f);
                     }
+                }
+            };
+            if (tp_fixed) {
+                // planar f16 product for the whole groups of the tile, f32 product for what is left (and for tiles
+                // whose peak, or whose predecessor's, is not finite)
+                uint32_t nplanar = 0;                                      // groups (16 columns x 4 outputs) on the f16 path
+                uint32_t scale_bits = 0, inv_bits = 0;
+                if (kTpPlanar) {
+                    const uint32_t pkb = tp_now_bits > tp_prev_bits ? tp_now_bits : tp_prev_bits;
+                    const uint32_t e = pkb >> 23;                          // biased exponent of the peak (sign is 0)
+                    nplanar = (seg >> 2) / tp_bpg;
+                    if (e == 255u || C > 8u) nplanar = 0;                 // (16 channels: round 0 would not hold the 12 history frames)
+                    // scale = 2^(14 - floor(log2 peak)): the scaled peak lies in [2^14, 2^15), inside the f16 range
+                    uint32_t sf = 268u - e;                                // biased exponent of the scale
+                    sf = sf > 254u ? 254u : sf;
+                    scale_bits = sf << 23;
+                    inv_bits = (254u - sf) << 23;                          // exact reciprocal (0 when the peak is below 2^-113)
+                }
+                const uint32_t f0 = nplanar * tp_bpg * 4;                  // frames covered by the planar path
+                if (f0 < seg) tp_f32_range(f0, seg - f0);
+#if defined(SS_ABL_TP) && SS_ABL_TP == 2
+                nplanar = 0;
+#endif
+                if (nplanar) {
+                    const float scale = __uint_as_float(scale_bits);
+                    const uint32_t ps = f0 + 12;                           // converted frames: [-12, f0), even
+                    const uint32_t FB = 64u / C, lb = 31u - (uint32_t)__clz((int)FB);    // frames per block (a power of two >= 4)
+                    // a conversion round is two blocks: lane -> (block of the round, pair of the block) = frames 2 fpl, 2 fpl + 1 of channel cc
+                    const uint32_t half = lane >> 5, pr = lane & 31u, fpl = pr / C, cc = pr - fpl * C;
+                    // (1) the 12 frames in front of the tile live in the halo, which (2) is about to replace
+                    float s0 = 0.0f, s1 = 0.0f;
+                    {
+                        const uint32_t q = lane < 6u * C ? lane : 0u, qf = q / C, qc = q - qf * C;      // pair q: frames -12 + 2 qf, channel qc
+                        const float *xp = tile + ((int)(2 * qf) - 12) * (int)C + (int)qc;
+                        s0 = xp[0]; s1 = xp[C];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    // (2) the next tile's halo leaves the f32 tile before it is overwritten
+                    {
+                        const uint32_t hn = halo_frames * C;
+                        float *dst = tile - hn;
+                        const float *srcp = dst + (size_t)seg * C;
+                        for (uint32_t j = lane; j < hn; j += 64u) {
+                            const float v = srcp[j];
+                            __builtin_amdgcn_wave_barrier();
+                            dst[j] = v;
+                        }
+                        halo_done = true;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    // (3) convert in place, rounds (two blocks each: 128 floats in, 128 dwords out) from the top down, four
+                    // rounds per batch: all reads of a batch, then its writes.  Lane addresses step by 512 bytes per round.
+                    // The top block may run past the converted range into the slack (sized for it); nothing reads that.
+                    const uint32_t nblocks = (ps + FB - 1) >> lb;
+                    const int nround = (int)((nblocks + 1u) >> 1);
+                    const bool top_ok = 2u * (uint32_t)(nround - 1) + half < nblocks;     // odd block count: the top round's upper block does not exist
+                    const float *rbase = tile + ((int)(half * FB + 2u * fpl) - 12) * (int)C + (int)cc;    // round 0; + 128 floats per round
+                    uint32_t *wbase = reinterpret_cast<uint32_t *>(tile) + half * 64u + cc * (FB >> 1) + fpl;   // hi pair; lo: + 32
+                    const bool saver = half * FB + 2u * fpl < 12u;         // this lane saved its round-0 pair from the old halo (lane < 6 C)
+                    for (int top = nround; top > 0; top -= 4) {
+                        float x0[4], x1[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            int rd = top - 1 - u;
+                            rd = rd < 0 ? 0 : rd;                          // wave-uniform; a repeated round 0 rewrites the same values
+                            x0[u] = rbase[rd * 128]; x1[u] = rbase[rd * 128 + (int)C];
+                            if (rd == 0) { x0[u] = saver ? s0 : x0[u]; x1[u] = saver ? s1 : x1[u]; }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            int rd = top - 1 - u;
+                            rd = rd < 0 ? 0 : rd;
+                            // (hi, hi) = f16(s x0), f16(s x1);  (lo, lo) = f16(s x - hi): four v_fma_mix
+                            uint32_t hh, ll;
+                            asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hh) : "v"(x0[u]), "s"(scale));
+                            asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hh) : "v"(x1[u]), "s"(scale));
+                            asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ll) : "v"(x0[u]), "s"(scale), "v"(hh));
+                            asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ll) : "v"(x1[u]), "s"(scale), "v"(hh));
+                            if (rd != nround - 1 || top_ok) {
+                                wbase[rd * 128] = hh;
+                                wbase[rd * 128 + 32] = ll;
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    // (4) column (channel tp_c, block of outputs b = 16/C g + mrow / C) reads its window [4 b, 4 b + 16) of
+                    // converted frames as three aligned 4-half pieces: for the K = 32 product halves 8 (kq & 1) .. + 8 of the hi
+                    // (kq < 2) or lo (kq >= 2) plane, for the K = 16 product halves 4 kq .. + 4 of the hi plane.
+                    const char *tb = reinterpret_cast<const char *>(tile);
+                    auto plane_addr = [&](uint32_t j, uint32_t lo) -> const char * {
+                        return tb + ((j >> lb) << 8) + (lo << 7) + ((tp_c * FB + (j & (FB - 1u))) << 1);
+                    };
+                    const uint32_t jb = 4u * ((uint32_t)mrow / C);
+                    auto ld4 = [](const char *q, int off) -> halfx4 { return __builtin_bit_cast(halfx4, *reinterpret_cast<const uint2 *>(q + off)); };
+                    float m16 = 0.0f;
+#if SS_TP_K32
+                    const uint32_t j32 = jb + 8u * ((uint32_t)kq & 1u);
+                    const char *p32a = plane_addr(j32, (uint32_t)kq >> 1), *p32b = plane_addr(j32 + 4u, (uint32_t)kq >> 1);
+                    const char *p16 = plane_addr(jb + 4u * (uint32_t)kq, 0);
+                    auto ld8 = [](const char *qa, const char *qb, int off) -> halfx8 {
+                        const uint2 a = *reinterpret_cast<const uint2 *>(qa + off), b = *reinterpret_cast<const uint2 *>(qb + off);
+                        const uint4 v = make_uint4(a.x, a.y, b.x, b.y);
+                        return __builtin_bit_cast(halfx8, v);
+                    };
+                    const uint32_t npair = nplanar >> 1;
+#endif
+#if defined(SS_ABL_TP) && SS_ABL_TP == 1
+                    if (false)
+#endif
+#if SS_TP_K32
+                    if (npair) {
+                        halfx8 bA = ld8(p32a, p32b, 0), bB = ld8(p32a, p32b, 256);
+                        halfx4 cA = ld4(p16, 0), cB = ld4(p16, 256);
+                        for (uint32_t it = 0; it < npair; it++) {
+                            // next pair's operands first (the last iteration re-reads its own: nothing is read past the planes)
+                            const uint32_t adv = (it + 1 < npair) ? 512u : 0u;
+                            p32a += adv; p32b += adv; p16 += adv;
+                            const halfx8 nA = ld8(p32a, p32b, 0), nB = ld8(p32a, p32b, 256);
+                            const halfx4 ncA = ld4(p16, 0), ncB = ld4(p16, 256);
+                            floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32, bA, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32, bB, acc1, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_lo, cA, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_lo, cB, acc1, 0, 0, 0);
+                            m16 = fmaxf(fmaxf(m16, fmaxf(fabsf(acc0[0]), fabsf(acc0[1]))), fmaxf(fabsf(acc0[2]), fabsf(acc0[3])));
+                            m16 = fmaxf(fmaxf(m16, fmaxf(fabsf(acc1[0]), fabsf(acc1[1]))), fmaxf(fabsf(acc1[2]), fabsf(acc1[3])));
+                            bA = nA; bB = nB; cA = ncA; cB = ncB;
+                        }
+                        p32a += 512; p32b += 512; p16 += 512;
+                    }
+                    if (nplanar & 1u) {                                    // the odd last group
+                        const halfx8 bA = ld8(p32a, p32b, 0);
+                        const halfx4 cA = ld4(p16, 0);
+                        floatx4 acc0 = {0.f, 0.f, 0.f, 0.f};
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32, bA, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_lo, cA, acc0, 0, 0, 0);
+                        m16 = fmaxf(fmaxf(m16, fmaxf(fabsf(acc0[0]), fabsf(acc0[1]))), fmaxf(fabsf(acc0[2]), fabsf(acc0[3])));
+                    }
+#else
+                    {
+                        // three K = 16 products per group (hi and lo planes at halves 4 kq .. + 4), four groups per iteration:
+                        // four independent accumulator chains, and the next iteration's operands are read before this one's MFMAs
+                        const char *ph = plane_addr(jb + 4u * (uint32_t)kq, 0);          // lo plane: + 128 bytes; next group: + 256
+                        auto absmax4 = [](float m, const floatx4 &a) {
+                            return fmaxf(fmaxf(fmaxf(m, fabsf(a[0])), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3])));
+                        };
+                        const uint32_t nquad = nplanar >> 2;
+#if defined(SS_ABL_TP) && SS_ABL_TP == 1
+                        if (false)
+#endif
+                        if (nquad) {
+                            halfx4 h[4], l[4];
+#pragma unroll
+                            for (int g = 0; g < 4; g++) { h[g] = ld4(ph, 256 * g); l[g] = ld4(ph, 256 * g + 128); }
+                            for (uint32_t it = 0; it < nquad; it++) {
+                                ph += (it + 1 < nquad) ? 1024 : 0;         // the last iteration re-reads its own operands: nothing past the planes
+                                halfx4 hn[4], ln[4];
+#pragma unroll
+                                for (int g = 0; g < 4; g++) { hn[g] = ld4(ph, 256 * g); ln[g] = ld4(ph, 256 * g + 128); }
+                                floatx4 acc[4];
+#pragma unroll
+                                for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_hi, h[g], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                                for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_hi, l[g], acc[g], 0, 0, 0);
+#pragma unroll
+                                for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_lo, h[g], acc[g], 0, 0, 0);
+#pragma unroll
+                                for (int g = 0; g < 4; g++) { m16 = absmax4(m16, acc[g]); h[g] = hn[g]; l[g] = ln[g]; }
+                            }
+                            ph += 1024;
+                        }
+                        for (uint32_t g = nquad << 2; g < nplanar; g++, ph += 256) {      // up to three groups left
+                            const halfx4 h0 = ld4(ph, 0), l0 = ld4(ph, 128);
+                            floatx4 acc0 = {0.f, 0.f, 0.f, 0.f};
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_hi, h0, acc0, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_hi, l0, acc0, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_lo, h0, acc0, 0, 0, 0);
+                            m16 = absmax4(m16, acc0);
+                        }
+                    }
+#endif
+                    tp_run = fmaxf(tp_run, m16 * __uint_as_float(inv_bits));
                 }
             } else {
                 // channel counts that do not divide 16 (5.1 = 6 channels, 3, 5, 7 ...): channel-major groups — the 16
                 // columns of a group are 16 consecutive blocks of ONE channel, so a lane's running maximum belongs to
                 // that channel and one LDS atomic per channel and tile closes it (it was one per group)
+                const uint32_t nblk = (seg + Cfg::BLK - 1) / Cfg::BLK;
                 const uint32_t gpc = (nblk + 15) >> 4;                  // groups per channel
                 for (uint32_t c = 0; c < C; c++) {
                     float m = 0.0f;
@@ -587,6 +807,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
                 }
             }
         }
+        if (kTpPlanar) tp_prev_bits = seg >= 12u ? tp_now_bits : (tp_now_bits > tp_prev_bits ? tp_now_bits : tp_prev_bits);
 
         // carry-out: exact state after the last valid sample, broadcast to every lane of the channel
         {
@@ -610,7 +831,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
         // ---- new halo: the halo_frames frames before the tile end (a contiguous copy; when the tile
         // is shorter than the halo the source reaches into the old halo).  Ascending order is safe:
         // the source of element j sits seg*C floats above its destination, beyond anything written so far.
-        {
+        if (!halo_done) {
             const uint32_t hn = halo_frames * C;
             float *dst = tile - hn;
             const float *srcp = dst + (size_t)seg * C;
@@ -639,7 +860,6 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
         const float o = __shfl_down(sp_run, d * C, 64);
         if (lane + d * C < 64u) sp_run = fmaxf(sp_run, o);
     }
-    if (kTpF16) tp_run = fmaxf(tp_run, tp_run16 * (1.0f / 256.0f));
     if (FACTOR != 0 && tp_fixed) atomicMax(&tpk[tp_c], __float_as_uint(tp_run));
     if (lane < C) {
         if (FACTOR != 0) atomicMax(reinterpret_cast<unsigned *>(&st.true_peak[lane]), tpk[lane]);
@@ -686,7 +906,7 @@ uint32_t td_resident_waves_per_cu(uint32_t C, uint32_t s100, uint32_t halo_frame
     uint32_t tile_len = (s100 + pieces - 1) / pieces;
     if (tile_len > cap) tile_len = cap;
     const uint32_t halo = halo_frames ? halo_frames : (uint32_t)kTdHaloFrames;
-    uint32_t wave_floats = (halo + tile_len + kTdTailFrames) * C + kMaxChannels;
+    uint32_t wave_floats = (halo + tile_len) * C + td_slack_floats(C) + kMaxChannels;
     wave_floats = (wave_floats + 3u) & ~3u;
     const size_t lds = (size_t)wave_floats * 4 * kTdWavesPerBlock;
     uint32_t blocks = lds ? (uint32_t)((160u * 1024u) / lds) : 4u;
@@ -709,7 +929,7 @@ static hipError_t td_launch(const TdParams &p, hipStream_t s)
     if (tile_len > cap) tile_len = cap;
     // per-wave LDS: halo + tile + slack + 64 peak slots
     const uint32_t halo = WAVE ? p.halo_frames : (uint32_t)kTdHaloFrames;
-    uint32_t wave_floats = (halo + tile_len + kTdTailFrames) * C + kMaxChannels;
+    uint32_t wave_floats = (halo + tile_len) * C + td_slack_floats(C) + kMaxChannels;
     wave_floats = (wave_floats + 3u) & ~3u;
     const size_t lds = (size_t)wave_floats * 4 * kTdWavesPerBlock;
     auto fn = k_time_domain<FACTOR, RING, CT, WAVE>;

@@ -1,0 +1,241 @@
+"""Parity at the shapes bench.py times (BASELINE configs 3 and 5) — the exact launch geometry the benchmark runs,
+not a reduced one — plus the low-level and special-value behaviour of the f16-split true peak.
+
+Everything goes through the C ABI; the oracle (oracle/ss_oracle.c) is the checker.  Bars: decimation bit-exact,
+spectrum / LUFS / LRA within 0.01 dB, true peak within 1e-4 relative (BASELINE.json north_star).
+"""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import soundscope_amd as ssa
+from soundscope_amd import _lib as L
+from conftest import db_close, make_stereo
+
+pytestmark = pytest.mark.gpu
+
+TOL_DB = 0.01
+
+
+def lufs_close(a, b, tol=TOL_DB):
+    if np.isinf(a) or np.isinf(b):
+        return a == b
+    return abs(a - b) <= tol
+
+
+def rel_close(a, b, rel=1e-4):
+    return abs(a - b) <= rel * max(abs(b), 1e-30)
+
+
+def _threads():
+    return max(1, min(64, len(os.sched_getaffinity(0))))
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_config3_bench_geometry_matches_oracle(oracle, overlap):
+    """BASELINE config 3 exactly as bench.py runs it: 1024 synthetic streams x 10 s x 48 kHz stereo, N = 4096,
+    hop 1024.  The geometry the shape selects (116 windows per spectrum workgroup, 4 time segments per stream with a
+    run-in) is asserted, then eight streams — first, last and the ones either side of every quarter — are compared in
+    full with the oracle (every window of both rows, LUFS, LRA, both peaks, every decimation bin), and the corpus
+    histograms with the sum of all 1024 per-stream oracle histograms."""
+    rate, frames, ns = 48000, 480000, 1024
+    b = ssa.Batch(rate, 2, ns, frames, 4096, 1024, flags=L.SS_BATCH_ALL)
+    b.synthesize(0x5EED0000, 0)
+    b.set_overlap(overlap)
+    b.run(); b.sync()
+    g, lay = b.geometry, b.layout
+    assert (lay.n_windows, lay.n_bins) == (464, 1705)
+    assert g.fft_windows_per_block == 116 and g.fft_blocks == 4096
+    assert g.td_segments == 4 and g.td_segment_subblocks == 25 and g.td_warm_subblocks == 2
+    assert g.waveform_fused == 1 and g.td_true_peak_factor == 4 and g.overlap == int(overlap)
+    res = b.results()
+    picks = [0, 1, 255, 256, 511, 512, 1022, 1023]
+    xs = {i: b.download_input(i) for i in picks}
+    with ThreadPoolExecutor(_threads()) as ex:
+        refs = dict(zip(picks, ex.map(lambda i: oracle.analyze_stream(rate, xs[i], 4096, 1024), picks)))
+    for i in picks:
+        ref = refs[i]
+        assert ref["n_windows"] == 464
+        fft = b.fft(i)
+        for w in range(464):
+            for c in range(2):
+                assert db_close(fft[w, c], ref["fft"][w, c], TOL_DB), (i, w, c)
+        assert lufs_close(res[i].integrated_lufs, ref["integrated"]), (i, res[i].integrated_lufs, ref["integrated"])
+        assert abs(res[i].loudness_range - ref["lra"]) <= TOL_DB
+        tp, sp = b.peaks(i)
+        for c in range(2):
+            assert rel_close(res[i].true_peak[c], ref["true_peak"][c]), (i, c)
+            assert res[i].sample_peak[c] == ref["sample_peak"][c]
+            assert tp[c] == res[i].true_peak[c] and sp[c] == res[i].sample_peak[c]
+        assert np.array_equal(b.waveform(i).reshape(-1), ref["wave"][:, 1].astype(np.float32)), i
+
+    # corpus gate input: the device's summed histograms == the sum of every stream's oracle histograms, exactly
+    ids = list(range(ns))
+    inputs = [b.download_input(i) for i in ids]                      # downloads stay on this thread (one handle, one thread)
+
+    def hist_of_x(x):
+        m = oracle.Meter(2, rate)
+        m.add_frames(x)
+        return m.block_hist(), m.st_hist(), m.integrated()
+    with ThreadPoolExecutor(_threads()) as ex:
+        hs = list(ex.map(hist_of_x, inputs))
+    hb, hst = b.histograms()
+    assert np.array_equal(hb, sum(h[0] for h in hs))
+    assert np.array_equal(hst, sum(h[1] for h in hs))
+    assert ssa.corpus_integrated_lufs(hb) == oracle.gated_loudness_hist(hb)
+    # and every stream's integrated loudness
+    for i in ids:
+        assert lufs_close(res[i].integrated_lufs, hs[i][2]), i
+
+
+@pytest.mark.parametrize("tp_factor", [4, 0])
+def test_config5_bench_shape_all_channels(oracle, tp_factor):
+    """BASELINE config 5 as bench.py times it: 64 streams x 10 s x 96 kHz x 8 channels, N = 16384 per channel at hop
+    1024, true peak forced to 4x (the benchmark) and at the crate's rule (2x at 96 kHz).  Four streams are checked in
+    full on the meter side (LUFS, LRA, all EIGHT channels' true and sample peaks through ss_batch_peaks) and on a
+    strided sample of windows on all eight channels."""
+    rate, ch, frames, ns = 96000, 8, 960000, 64
+    b = ssa.Batch(rate, ch, ns, frames, 16384, 1024, flags=L.SS_BATCH_ALL, true_peak_factor=tp_factor)
+    b.synthesize(0x5EED0000, 0)
+    b.run(); b.sync()
+    g, lay = b.geometry, b.layout
+    assert (lay.n_windows, lay.fft_channels, lay.n_bins) == (921, 8, 3410)
+    assert g.td_true_peak_factor == (4 if tp_factor == 4 else 2)
+    assert g.td_segments > 1                                    # the segmented (run-in) path is what the bench times
+    res = b.results()
+    picks = [0, 21, 42, 63]
+    xs = {i: b.download_input(i) for i in picks}
+
+    def meter_of(i):
+        m = oracle.Meter(ch, rate, force_tp_factor=tp_factor)
+        m.add_frames(xs[i])
+        return (m.integrated(), m.loudness_range(), [m.true_peak(c) for c in range(ch)], [m.sample_peak(c) for c in range(ch)])
+    with ThreadPoolExecutor(4) as ex:
+        ms = dict(zip(picks, ex.map(meter_of, picks)))
+    for i in picks:
+        integ, lra, tps, sps = ms[i]
+        assert lufs_close(res[i].integrated_lufs, integ), (i, res[i].integrated_lufs, integ)
+        assert abs(res[i].loudness_range - lra) <= TOL_DB
+        tp, sp = b.peaks(i)
+        for c in range(ch):
+            assert rel_close(tp[c], max(tps[c], sps[c])), (i, c, tp[c], tps[c])
+            assert sp[c] == sps[c], (i, c)
+        fft = b.fft(i)
+        xm = xs[i].reshape(frames, ch)
+        for w in list(range(0, lay.n_windows, 97)) + [lay.n_windows - 1]:
+            start = (w + 1) * 1024
+            for c in range(ch):
+                ref = oracle.get_fft(rate, xm[start:start + 16384, c])
+                assert db_close(fft[w, c], ref[:, 1], TOL_DB), (i, w, c)
+
+
+def test_batch_peaks_api(oracle):
+    from conftest import make_multich
+    rate, ch, frames = 48000, 6, 48000 * 2
+    x = make_multich(77, frames, ch, rate)
+    b = ssa.Batch(rate, ch, 2, frames, 4096, 1024, flags=L.SS_BATCH_LUFS | L.SS_BATCH_TRUE_PEAK)
+    b.upload(0, np.concatenate([x, (x * np.float32(0.5)).astype(np.float32)]))
+    b.run(); b.sync()
+    for s, scale in ((0, 1.0), (1, 0.5)):
+        m = oracle.Meter(ch, rate); m.add_frames((x * np.float32(scale)).astype(np.float32))
+        tp, sp = b.peaks(s)
+        assert tp.shape == (ch,)
+        for c in range(ch):
+            assert rel_close(tp[c], max(m.true_peak(c), m.sample_peak(c))) and sp[c] == m.sample_peak(c)
+    # capacity and argument errors
+    buf = (np.empty(3, np.float64)).ctypes.data_as(L.C.POINTER(L.C.c_double))
+    assert L.lib().ss_batch_peaks(b._h, 0, buf, None, 3) == L.SS_ERR_CAPACITY
+    assert L.lib().ss_batch_peaks(b._h, 2, buf, None, 8) == L.SS_ERR_INVALID_ARG
+    b2 = ssa.Batch(rate, 2, 1, frames, 4096, 1024, flags=L.SS_BATCH_FFT)
+    assert L.lib().ss_batch_peaks(b2._h, 0, buf, None, 8) == L.SS_ERR_INVALID_MODE
+
+
+@pytest.mark.parametrize("peak", [1e-5, 1e-6, 1e-7, 2.0 ** -23, 3e-9, 0.0])
+def test_true_peak_quiet_streams(oracle, peak):
+    """The f16-split true-peak product scales every tile by a power of two taken from its own sample peak, so its
+    relative accuracy does not depend on level: streams peaking at -100, -120, -140 dBFS, at one LSB of 24-bit PCM,
+    far below that, and digital silence all stay within 1e-4 of the oracle (a fixed x256 scale lost this below
+    about -120 dBFS, where the low f16 halves went sub-normal)."""
+    rate, frames = 48000, 48000 * 3
+    base = make_stereo(123, frames, rate, level=1.0)
+    x = (base * np.float32(peak / max(np.abs(base).max(), 1e-30))).astype(np.float32) if peak else np.zeros_like(base)
+    b = ssa.Batch(rate, 2, 2, frames, 4096, 1024, flags=L.SS_BATCH_LUFS | L.SS_BATCH_TRUE_PEAK)
+    # second stream: the same quiet programme with one loud burst, so tiles of very different scale sit side by side
+    y = x.copy()
+    y[2 * 20000:2 * 20400] = base[2 * 20000:2 * 20400] * np.float32(0.9)
+    b.upload(0, np.concatenate([x, y])); b.run(); b.sync()
+    res = b.results()
+    for i, s in enumerate((x, y)):
+        m = oracle.Meter(2, rate); m.add_frames(s)
+        for c in range(2):
+            ref = max(m.true_peak(c), m.sample_peak(c))
+            assert rel_close(res[i].true_peak[c], ref) or (ref == 0.0 and res[i].true_peak[c] == 0.0), (i, c, res[i].true_peak[c], ref)
+            assert res[i].sample_peak[c] == m.sample_peak(c)
+    # streaming handle, 16384-sample slices (the tick driver's feed)
+    an = ssa.Analyzer(); an.create_loudness_meter(2, rate)
+    m = oracle.Meter(2, rate)
+    for off in range(0, y.size - 16384, 16384):
+        an.add_samples(y[off:off + 16384]); m.add_frames(y[off:off + 16384])
+    l, r = an.get_true_peak()
+    assert rel_close(l, max(m.true_peak(0), m.sample_peak(0))) and rel_close(r, max(m.true_peak(1), m.sample_peak(1)))
+
+
+def test_documented_deviations_are_pinned(oracle):
+    """DESIGN section 6 lists two deliberate deviations; this pins what the device actually returns for them.
+    (1) NaN samples: the oracle's interpolator loses the 12 outputs per phase that touch a NaN; the device's matrix
+        form loses the outputs of the whole 16-sample window.  Both ignore NaN in every maximum (IEEE maxNum /
+        Rust's `>`), so results stay finite and, when the programme's peak is not next to the NaN, equal.
+    (2) Sub-normal flush: ebur128 flushes a sub-normal filter state to zero after each call; the device lets it decay
+        (e^-240 per second) through the sub-normal range.  Both report -inf momentary loudness once y^2 underflows."""
+    rate, frames = 48000, 48000 * 4
+    x = make_stereo(321, frames, rate, level=0.4)
+    # the loudest inter-sample region sits somewhere in the programme; put NaNs far away from the global sample peak
+    pk = int(np.argmax(np.abs(x[0::2])))
+    holes = [f for f in (1000, 50001, 123456, 150000) if abs(f - pk) > 64]
+    xn = x.copy()
+    for f in holes:
+        xn[2 * f] = np.nan
+    b = ssa.Batch(rate, 2, 2, frames, 4096, 1024, flags=L.SS_BATCH_TRUE_PEAK | L.SS_BATCH_LUFS)
+    b.upload(0, np.concatenate([x, xn])); b.run(); b.sync()
+    res = b.results()
+    m = oracle.Meter(2, rate); m.add_frames(xn)
+    assert np.isfinite(res[1].true_peak[0]) and np.isfinite(res[1].sample_peak[0])
+    assert res[1].sample_peak[0] == m.sample_peak(0) and res[1].sample_peak[1] == m.sample_peak(1)
+    assert rel_close(res[1].true_peak[1], max(m.true_peak(1), m.sample_peak(1)))        # the channel without NaN
+    assert res[1].true_peak[0] <= res[0].true_peak[0] * (1 + 1e-6)                       # a NaN can only hide outputs
+    assert res[1].true_peak[0] >= res[1].sample_peak[0]
+    # (2) an impulse and then silence: the state decays through the sub-normal range on the device
+    an = ssa.Analyzer(); an.create_loudness_meter(2, rate)
+    mm = oracle.Meter(2, rate)
+    imp = np.zeros(2 * rate * 5, np.float32); imp[0] = 1.0; imp[1] = -1.0
+    for off in range(0, imp.size, 16384):
+        an.add_samples(imp[off:off + 16384]); mm.add_frames(imp[off:off + 16384])
+    assert an.get_momentary_lufs() == mm.momentary() == -np.inf
+    assert lufs_close(an.get_integrated_lufs(), mm.integrated())
+    assert lufs_close(an.get_shortterm_lufs(), mm.shortterm())
+
+
+def test_segmented_run_in_on_dc_offset_material(oracle):
+    """Time segments > 0 start their filter two sub-blocks early from a zero state (the high-pass section's
+    near-double pole makes the residual decay like n r^n; DC-offset material is its worst case).  The segmented batch
+    path and the single-segment streaming path must land every gating block in the same 0.1 LU histogram bin."""
+    rate, frames = 48000, 48000 * 10
+    rng = np.random.default_rng(5)
+    x = np.empty(2 * frames, np.float32)
+    x[0::2] = (0.5 + 0.01 * rng.standard_normal(frames)).astype(np.float32)      # large DC offset
+    x[1::2] = (-0.3 + 0.2 * np.sin(2 * np.pi * 100 * np.arange(frames) / rate)).astype(np.float32)
+    ns = 600                                                                       # enough streams that segments are used
+    b = ssa.Batch(rate, 2, ns, frames, 4096, 1024, flags=L.SS_BATCH_LUFS)
+    for i in range(0, ns, 100):
+        b.upload(i, np.tile(x, 100))
+    b.run(); b.sync()
+    assert b.geometry.td_segments > 1
+    m = oracle.Meter(2, rate); m.add_frames(x)
+    hb, hst = b.histograms()
+    assert np.array_equal(hb, m.block_hist() * np.uint64(ns))
+    assert np.array_equal(hst, m.st_hist() * np.uint64(ns))
+    an = ssa.Analyzer(); an.create_loudness_meter(2, rate); an.add_samples(x)       # one segment, true carried state
+    assert lufs_close(an.get_integrated_lufs(), m.integrated())
+    assert lufs_close(b.results()[ns // 2].integrated_lufs, m.integrated())
