@@ -73,6 +73,9 @@ __device__ __forceinline__ void mat4_apply_add(const double *__restrict__ M, con
 #ifndef SS_TP_F16
 #define SS_TP_F16 1
 #endif
+#ifndef SS_TD_ROWSCAN
+#define SS_TD_ROWSCAN 1
+#endif
 #ifndef SS_TP_K32
 #define SS_TP_K32 0      // 1: v_mfma_f32_16x16x32_f16 for A_hi (B_hi + B_lo).  Measured no faster than three K = 16 products, and with
                          // it the spectrum kernel running BESIDE this one (overlap mode) returned isolated wrong windows (tools/probe_overlap_race.py);
@@ -179,8 +182,18 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
     const uint32_t C = CT ? (uint32_t)CT : p.channels;
     const uint32_t S = p.s100;
     const uint32_t nch = 64u / C;                       // chunks per tile (C <= 64)
-    const uint32_t chunk = lane / C, ch = lane - chunk * C;
+    // Lane -> (chunk, channel).  Natural: chunk = lane / C.  Channel counts that divide 16 (compile-time) deal the chunks
+    // round-robin to the four DPP rows of the wave instead: row r = lane / 16 holds chunks r, r + 4, r + 8, ..., so the scan
+    // steps of distance 4, 8, 16 ... are shifts INSIDE a row (v_mov_dpp row_shr, VALU rate) and only the distances 1 and 2
+    // cross rows (ds_bpermute: 22 cycles of the LDS crossbar each, and a dependent latency per step).  The walk through the
+    // interleaved tile stays bank-conflict free: (r + 4 q) L C + c covers 64 distinct banks for L = 33.
+    constexpr bool kRowScan = (CT != 0) && (16 % (CT ? CT : 1) == 0) && (SS_TD_ROWSCAN != 0);
+    const uint32_t lane_q = (lane & 15u) / C;           // position of this lane's chunk inside its row
+    const uint32_t chunk = kRowScan ? (lane >> 4) + 4u * lane_q : lane / C;
+    const uint32_t ch = kRowScan ? (lane & 15u) - lane_q * C : lane - chunk * C;
     const bool lane_ok = chunk < nch;
+    // lane holding chunk c of this lane's channel
+    auto lane_of_chunk = [&](uint32_t c) -> uint32_t { return kRowScan ? ((c & 3u) << 4) + (c >> 2) * C + ch : c * C + ch; };
     float *tile = tilebuf + halo_frames * C;            // tile[f*C + c]; tile[-q*C + c] = x[-q]
     unsigned *tpk = reinterpret_cast<unsigned *>(tilebuf + wave_lds_floats - kMaxChannels);   // per-channel peak slots
     TdState &st = p.state[stream];
@@ -499,16 +512,49 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
             z[0] = v1; z[1] = v2; z[2] = v3; z[3] = v4;
             if (active && chunk == 0) mat4_apply_add(mpow, cv, z);
         }
-        // ---- in-wave scan over chunks: z_i += (A^L)^(2^k) z_{i - 2^k}
-        for (int kstep = 0; (1u << kstep) < nchunks; kstep++) {
-            const uint32_t d = (1u << kstep) * C;
-            const double xin[4] = {__shfl_up(z[0], d, 64), __shfl_up(z[1], d, 64), __shfl_up(z[2], d, 64), __shfl_up(z[3], d, 64)};
-            if (active && lane >= d) mat4_apply_add(mpow + 16 * kstep, xin, z);
+        // ---- in-wave scan over chunks: z_i += (A^L)^(2^k) z_{i - 2^k}  (the steps commute: powers of one matrix)
+#ifndef SS_ABL_SCAN_FROM
+#define SS_ABL_SCAN_FROM 0
+#define SS_ABL_SCAN_TO 32
+#endif
+        if (kRowScan) {
+            // distances 1 and 2: the source chunk sits in another row
+#pragma unroll
+            for (int kstep = 0; kstep < 2; kstep++) {
+                const uint32_t d = 1u << kstep;
+                if (d >= nchunks) break;                // wave-uniform
+                const int src = (int)lane_of_chunk(chunk >= d ? chunk - d : 0u);
+                const double xin[4] = {__shfl(z[0], src, 64), __shfl(z[1], src, 64), __shfl(z[2], src, 64), __shfl(z[3], src, 64)};
+                if (active && chunk >= d) mat4_apply_add(mpow + 16 * kstep, xin, z);
+            }
+            // distances 4, 8, 16, 32: q - 1, q - 2, q - 4, q - 8 inside the row; lanes without a source read zeros (bound_ctrl)
+#define SS_DPP_SHR64(v, N)                                                                                              \
+    __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + (N), 0xF, 0xF, true),                      \
+                     __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + (N), 0xF, 0xF, true))
+#define SS_ROW_STEP(N, KSTEP)                                                                                           \
+    if ((4u << ((KSTEP) - 2)) < nchunks) {                                                                                 \
+        const double xin[4] = {SS_DPP_SHR64(z[0], N), SS_DPP_SHR64(z[1], N), SS_DPP_SHR64(z[2], N), SS_DPP_SHR64(z[3], N)}; \
+        mat4_apply_add(mpow + 16 * (KSTEP), xin, z);                                                                    \
+    }
+            constexpr int CC = CT ? CT : 1;
+            if (CC * 1 <= 8) { SS_ROW_STEP(CC * 1 <= 8 ? CC * 1 : 1, 2) }
+            if (CC * 2 <= 8) { SS_ROW_STEP(CC * 2 <= 8 ? CC * 2 : 1, 3) }
+            if (CC * 4 <= 8) { SS_ROW_STEP(CC * 4 <= 8 ? CC * 4 : 1, 4) }
+            if (CC * 8 <= 8) { SS_ROW_STEP(CC * 8 <= 8 ? CC * 8 : 1, 5) }
+#undef SS_ROW_STEP
+#undef SS_DPP_SHR64
+        } else {
+            for (int kstep = SS_ABL_SCAN_FROM; kstep < SS_ABL_SCAN_TO && (1u << kstep) < nchunks; kstep++) {
+                const uint32_t d = (1u << kstep) * C;
+                const double xin[4] = {__shfl_up(z[0], d, 64), __shfl_up(z[1], d, 64), __shfl_up(z[2], d, 64), __shfl_up(z[3], d, 64)};
+                if (active && lane >= d) mat4_apply_add(mpow + 16 * kstep, xin, z);
+            }
         }
         // z = state after this lane's chunk (valid for full chunks); initial state = previous chunk's
         double v1, v2, v3, v4;
         {
-            const double p0 = __shfl_up(z[0], C, 64), p1 = __shfl_up(z[1], C, 64), p2 = __shfl_up(z[2], C, 64), p3 = __shfl_up(z[3], C, 64);
+            const int src = (int)lane_of_chunk(chunk ? chunk - 1u : 0u);
+            const double p0 = __shfl(z[0], src, 64), p1 = __shfl(z[1], src, 64), p2 = __shfl(z[2], src, 64), p3 = __shfl(z[3], src, 64);
             const bool first = chunk == 0;
             v1 = first ? cv[0] : p0; v2 = first ? cv[1] : p1; v3 = first ? cv[2] : p2; v4 = first ? cv[3] : p3;
         }
@@ -809,9 +855,22 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
         }
         if (kTpPlanar) tp_prev_bits = seg >= 12u ? tp_now_bits : (tp_now_bits > tp_prev_bits ? tp_now_bits : tp_prev_bits);
 
-        // carry-out: exact state after the last valid sample, broadcast to every lane of the channel
-        {
-            const uint32_t src_lane = (nchunks - 1) * C + ch;
+        // carry-out: exact state after the last valid sample, to the lanes of the channel (chunk 0's lane consumes it)
+        if (kRowScan && CT <= 2) {
+            // the source lanes are wave-uniform: v_readlane per channel instead of eight trips through the LDS crossbar
+            const uint32_t lastc = nchunks - 1u;
+            const uint32_t l0 = ((lastc & 3u) << 4) + (lastc >> 2) * C;     // lane of (last chunk, channel 0)
+            auto rl64 = [](double v, uint32_t src) -> double {
+                return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), (int)src), __builtin_amdgcn_readlane(__double2loint(v), (int)src));
+            };
+            const double vv[4] = {v1, v2, v3, v4};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const double a = rl64(vv[q], l0);
+                cv[q] = (CT == 2 && ch == 1u) ? rl64(vv[q], l0 + 1u) : a;
+            }
+        } else {
+            const uint32_t src_lane = lane_of_chunk(nchunks - 1);
             cv[0] = __shfl(v1, src_lane, 64); cv[1] = __shfl(v2, src_lane, 64);
             cv[2] = __shfl(v3, src_lane, 64); cv[3] = __shfl(v4, src_lane, 64);
         }
