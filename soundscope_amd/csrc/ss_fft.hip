@@ -71,6 +71,27 @@ __device__ __forceinline__ v2f pk_mul_mi(v2f a)
     return r;
 }
 
+// (v.x + v.y, v.x - v.y): the raw mid/side sums of one stereo frame in one instruction
+__device__ __forceinline__ v2f pk_sum_diff(v2f v)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(v));
+    return r;
+}
+// a * w.x / a * w.y for both halves of a (window weights are kept two to a register pair)
+__device__ __forceinline__ v2f pk_scale_lo(v2f a, v2f w)
+{
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(w));
+    return r;
+}
+__device__ __forceinline__ v2f pk_scale_hi(v2f a, v2f w)
+{
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(w));
+    return r;
+}
+
 // forward radix-4 butterfly on (a0,a1,a2,a3) in place: A_k = sum_j a_j (-i)^(jk)  — 8 packed adds
 __device__ __forceinline__ void radix4(v2f &a0, v2f &a1, v2f &a2, v2f &a3)
 {
@@ -160,8 +181,9 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
                                                  float *o_mid, float *o_side, bool store_side = true)
 {
     const uint32_t ngroups = (n_bins + 3) >> 2;
-    // dB = 10 log10(2) * log2(q) + (db_offset + pink[bin]); an exact zero reads -150 (+ pink): feed the
-    // fma the log value that lands on -150 instead of selecting afterwards (one instruction less per bin)
+    // dB = 10 log10(2) * log2(q) + (db_offset + pink[bin]); an exact zero reads -150 (+ pink): the log operand is
+    // replaced by the value that lands on -150.  Exact zeros are rare (digital silence), so the wave first asks whether
+    // any of its squared magnitudes is zero (a min tree and one compare) and only then pays the per-value selects.
     constexpr float kDb = 3.01029995663981195f;
     const float lg0 = (-150.0f - db_offset) / kDb;
 #pragma unroll
@@ -171,7 +193,7 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
             const uint32_t k0 = first_bin + 4 * g;
             const float4 op = *reinterpret_cast<const float4 *>(offpink + 4 * g);   // table padded to the row stride
             const float opv[4] = {op.x, op.y, op.z, op.w};
-            float rm[4], rs[4];
+            float qm[4], qs[4], rm[4], rs[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const uint32_t k = k0 + e;                       // k <= 2051 < 4096: the mirror index stays positive
@@ -180,10 +202,22 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
                 v2f m2, s2;                                      // 2*M = (zk.x+zm.x, zk.y-zm.y); 2*S ~ (zk.y+zm.y, zk.x-zm.x)
                 asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,0] neg_hi:[0,1]" : "=v"(m2) : "v"(zk), "v"(zm));
                 asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(s2) : "v"(zk), "v"(zm));
-                const float qm = fmaf(m2.x, m2.x, m2.y * m2.y);
-                const float qs = fmaf(s2.x, s2.x, s2.y * s2.y);
-                rm[e] = fmaf(qm == 0.0f ? lg0 : __log2f(qm), kDb, opv[e]);
-                rs[e] = fmaf(qs == 0.0f ? lg0 : __log2f(qs), kDb, opv[e]);
+                qm[e] = fmaf(m2.x, m2.x, m2.y * m2.y);
+                qs[e] = fmaf(s2.x, s2.x, s2.y * s2.y);
+            }
+            const float qmin = fminf(fminf(fminf(qm[0], qm[1]), fminf(qm[2], qm[3])), fminf(fminf(qs[0], qs[1]), fminf(qs[2], qs[3])));
+            if (__builtin_expect(__ballot(qmin == 0.0f) == 0ull, 1)) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    rm[e] = fmaf(__log2f(qm[e]), kDb, opv[e]);
+                    rs[e] = fmaf(__log2f(qs[e]), kDb, opv[e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    rm[e] = fmaf(qm[e] == 0.0f ? lg0 : __log2f(qm[e]), kDb, opv[e]);
+                    rs[e] = fmaf(qs[e] == 0.0f ? lg0 : __log2f(qs[e]), kDb, opv[e]);
+                }
             }
 #if defined(SS_ABL) && SS_ABL == 1      /* ablation: no output stores */
             asm volatile("" ::"v"(rm[0]), "v"(rm[1]), "v"(rm[2]), "v"(rm[3]), "v"(rs[0]), "v"(rs[1]), "v"(rs[2]), "v"(rs[3]));
@@ -385,9 +419,9 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
     const float2 *src = reinterpret_cast<const float2 *>(p.pcm) + (size_t)stream * p.frames_per_stream +
                         p.first_start + (size_t)w_begin * p.hop;
     const v2f *twn = reinterpret_cast<const v2f *>(p.tw_n);
-    float hw[16];
+    v2f hw[8];                                                            // (w[t + 512 i], w[t + 512 i + 256])
 #pragma unroll
-    for (int j = 0; j < 16; j++) hw[j] = p.half_window[t + 256 * j];
+    for (int j = 0; j < 8; j++) hw[j] = v2f{p.half_window[t + 512 * j], p.half_window[t + 512 * j + 256]};
     v2f tw1[16];
     if (TW6) {
         tw1[1] = twn[t]; tw1[2] = twn[2 * t]; tw1[3] = twn[3 * t];
@@ -401,25 +435,21 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
     const int tsw = SPEC_POS(t);
     const size_t out_win_stride = (size_t)2 * p.bin_stride;
     float *outp = p.out + ((size_t)stream * p.n_windows + w_begin) * out_win_stride;
-    float sm[16], df[16];
+    v2f sd[16];                                                           // raw (l + r, l - r) of frame t + 256 j
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const float2 v = src[t + 256 * j];
-        sm[j] = v.x + v.y;
-        df[j] = v.x - v.y;
-    }
+    for (int j = 0; j < 16; j++) sd[j] = pk_sum_diff(reinterpret_cast<const v2f *>(src)[t + 256 * j]);
     __syncthreads();
     for (uint32_t w = w_begin; w < w_end; ++w) {
-        float2 nx[HS];
+        v2f nx[HS];
         const bool more = (w + 1 < w_end);
 #pragma unroll
         for (int q = 0; q < HS; q++) {
-            nx[q] = make_float2(0.f, 0.f);
-            if (more) nx[q] = src[(size_t)(w + 1 - w_begin) * p.hop + t + 256 * (16 - HS + q)];
+            nx[q] = v2f{0.f, 0.f};
+            if (more) nx[q] = reinterpret_cast<const v2f *>(src)[(size_t)(w + 1 - w_begin) * p.hop + t + 256 * (16 - HS + q)];
         }
         v2f z[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) z[j] = v2f{sm[j] * hw[j], df[j] * hw[j]};
+        for (int j = 0; j < 16; j++) z[j] = (j & 1) ? pk_scale_hi(sd[j], hw[j >> 1]) : pk_scale_lo(sd[j], hw[j >> 1]);
         SS_PRIO_LO();
         fft16(z);
         SS_PRIO_HI();
@@ -461,9 +491,9 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
         fft4096_epilogue(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride);
         if (more) {
 #pragma unroll
-            for (int j = 0; j < 16 - HS; j++) { sm[j] = sm[j + HS]; df[j] = df[j + HS]; }
+            for (int j = 0; j < 16 - HS; j++) sd[j] = sd[j + HS];
 #pragma unroll
-            for (int q = 0; q < HS; q++) { sm[16 - HS + q] = nx[q].x + nx[q].y; df[16 - HS + q] = nx[q].x - nx[q].y; }
+            for (int q = 0; q < HS; q++) sd[16 - HS + q] = pk_sum_diff(nx[q]);
         }
         __syncthreads();
     }
