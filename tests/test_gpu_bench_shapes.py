@@ -239,3 +239,31 @@ def test_segmented_run_in_on_dc_offset_material(oracle):
     an = ssa.Analyzer(); an.create_loudness_meter(2, rate); an.add_samples(x)       # one segment, true carried state
     assert lufs_close(an.get_integrated_lufs(), m.integrated())
     assert lufs_close(b.results()[ns // 2].integrated_lufs, m.integrated())
+
+
+def test_rccl_communicator_single_rank_on_device(oracle):
+    """The library's own RCCL binding on real hardware: librccl is opened, a one-rank communicator is created
+    (ncclGetUniqueId + ncclCommInitRank), ncclCommCount answers, and the corpus all-reduce runs as a real
+    ncclAllReduce(…, 2000, ncclUint64, ncclSum) on the batch's stream — with one rank the sum is the batch's own
+    histograms.  (Two ranks need two GPUs: RCCL refuses duplicate devices; the N > 1 rank logic is covered on CPU by
+    tests/test_distributed_comm.py and on 8 GPUs by the driver's scaling run.)"""
+    from soundscope_amd.distributed import Comm, corpus_gate
+    comm = Comm(0, 1, None, transport="rccl")
+    assert comm.transport == "rccl" and comm.size == 1 and comm.rank == 0
+    comm.barrier()
+    assert list(comm.allreduce_sum_u64(np.array([3, 2 ** 40 + 1], np.uint64))) == [3, 2 ** 40 + 1]
+    assert list(comm.allreduce_max_f64(np.array([1.5, -2.0]))) == [1.5, -2.0]
+    rate, frames = 48000, 48000 * 4
+    xs = [make_stereo(40 + i, frames, rate, level=0.1 + 0.2 * i, gap=(i == 1)) for i in range(3)]
+    b = ssa.Batch(rate, 2, 3, frames, 4096, 1024, flags=L.SS_BATCH_LUFS)
+    b.upload(0, np.concatenate(xs)); b.run()
+    hb, hs = b.allreduce_histograms(comm)                   # queued behind the run on the batch's stream
+    hb2, hs2 = b.histograms()
+    assert np.array_equal(hb, hb2) and np.array_equal(hs, hs2)
+    ms = []
+    for x in xs:
+        m = oracle.Meter(2, rate); m.add_frames(x); ms.append(m)
+    assert np.array_equal(hb, sum(m.block_hist() for m in ms))
+    gi, _ = corpus_gate(np.concatenate([hb, hs]))
+    assert gi == oracle.gated_loudness_hist(hb)
+    comm.close()

@@ -194,6 +194,13 @@ def test_meter_errors_and_reinit(oracle):
             an.create_loudness_meter(ch, rate)
         assert e.value.code == L.SS_ERR_NOMEM
         assert an.sample_rate() == rate                      # rate sticks even on error (analyzer.rs:50)
+    # `self.loudness_meter = EbuR128::new(..)?` assigns only on success (analyzer.rs:51): after the failed calls the
+    # previous 6-channel / 96 kHz meter is still the handle's meter and keeps working
+    x = make_multich(3, 9600, 6, 96000)
+    m = oracle.Meter(6, 96000)
+    an.add_samples(x); m.add_frames(x)
+    assert an.get_true_peak_channel(5) == pytest.approx(max(m.true_peak(5), m.sample_peak(5)), rel=1e-4)
+    assert lufs_close(an.get_momentary_lufs(), m.momentary())
 
 
 @pytest.mark.parametrize("channels,rate", [(1, 48000), (6, 48000), (8, 96000), (5, 44100), (3, 22050)])
@@ -217,6 +224,25 @@ def test_forced_true_peak_factor(oracle):
         an.add_samples(x); m.add_frames(x)
         l, r = an.get_true_peak()
         assert rel_close(l, m.true_peak(0)) and rel_close(r, m.true_peak(1))
+
+
+def test_true_peak_factor_takes_effect_at_reset(oracle):
+    """ss_analyzer_set_true_peak_factor applies at the next configure OR reset (the header's contract)."""
+    rate = 96000
+    x = make_stereo(19, rate, rate, level=1.2)
+    an = ssa.Analyzer(); an.create_loudness_meter(2, rate)          # crate rule at 96 kHz: 2x
+    an.set_true_peak_factor(4)
+    an.reset()                                                       # now 4x
+    m = oracle.Meter(2, rate, force_tp_factor=4)
+    an.add_samples(x); m.add_frames(x)
+    l, r = an.get_true_peak()
+    assert rel_close(l, m.true_peak(0)) and rel_close(r, m.true_peak(1))
+    an.set_true_peak_factor(0)
+    an.reset()                                                       # back to the rule
+    m2 = oracle.Meter(2, rate)
+    an.add_samples(x); m2.add_frames(x)
+    l, r = an.get_true_peak()
+    assert rel_close(l, m2.true_peak(0)) and rel_close(r, m2.true_peak(1))
 
 
 def test_true_peak_ebu3341_intersample(oracle):
