@@ -159,6 +159,7 @@ template <int FACTOR, bool RING, int CT, int WAVE>
 __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_domain(TdParams p, uint32_t L, uint32_t tile_len,
                                                                                       uint32_t wave_lds_floats, uint32_t halo_frames)
 {
+    const uint32_t inv_L = 0xFFFFFFFFu / L + 1u;        // ceil(2^32 / L): x / L == (x * inv_L) >> 32 for x < 2^16 (L <= 65)
     using Cfg = TpCfg<FACTOR>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u;
@@ -322,11 +323,12 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
 
     // tile geometry: a tile never crosses a sub-block boundary of the absolute grid; a sub-block is
     // cut into equal pieces of at most tile_len frames
-#define SS_TILE_FRAMES(at, off_in, out)                                     \
+    // (toff = off % tile_len is carried along instead of being divided out for every tile)
+#define SS_TILE_FRAMES(at, off_in, toff_in, out)                            \
     do {                                                                    \
         uint64_t n_ = 0;                                                    \
         if ((at) < seg_end) {                                               \
-            n_ = tile_len - ((off_in) % tile_len);                          \
+            n_ = tile_len - (toff_in);                                      \
             if (n_ > S - (off_in)) n_ = S - (off_in);                       \
             if (n_ > seg_end - (at)) n_ = seg_end - (at);                   \
         }                                                                   \
@@ -351,7 +353,9 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
 #pragma unroll
     for (int q = 0; q < kTdPrefetch; q++) pf[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t seg;
-    SS_TILE_FRAMES(pos, off, seg);
+    uint32_t toff = off % tile_len;                     // position inside the current piece of the sub-block
+    uint32_t slot = (uint32_t)(sb % p.sub_cap);         // where the current sub-block's energies go (ring of sub_cap)
+    SS_TILE_FRAMES(pos, off, toff, seg);
     SS_PREFETCH(pos, seg);
 
     while (seg != 0) {
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
         const double *mpow = &K.m_pow[0][0];
         asm volatile("" : "+s"(mpow));
         const bool warm = pos < seg_begin;              // run-in tile: filter only
-        const uint32_t nchunks = (seg + L - 1) / L;
+        const uint32_t nchunks = (uint32_t)(((uint64_t)(seg + L - 1) * inv_L) >> 32);     // (seg + L - 1) / L, exact for seg < 2^16
 
         // ---- stage the tile from the prefetch registers (remainder / unaligned: direct)
         {
@@ -384,11 +388,12 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
         }
         // next tile's loads fly while this one is processed
         const uint64_t npos = pos + seg;
-        uint32_t noff = off + seg;
+        uint32_t noff = off + seg, ntoff = toff + seg;
         const bool sub_done = (noff == S);
         if (sub_done) noff = 0;
+        if (sub_done || ntoff >= tile_len) ntoff = 0;
         uint32_t nseg_frames;
-        SS_TILE_FRAMES(npos, noff, nseg_frames);
+        SS_TILE_FRAMES(npos, noff, ntoff, nseg_frames);
         SS_PREFETCH(npos, nseg_frames);
         __builtin_amdgcn_wave_barrier();               // LDS is in-order per wave: only ordering is needed
 
@@ -882,10 +887,11 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
                     const double o = __shfl_down(e, d * C, 64);
                     if (lane + d * C < 64u) e += o;
                 }
-                if (lane < C) p.subblocks[(size_t)stream * p.sub_stride + (size_t)(sb % p.sub_cap) * C + lane] = e;
+                if (lane < C) p.subblocks[(size_t)stream * p.sub_stride + (size_t)slot * C + lane] = e;
             }
             e_run = 0.0;
             sb++;
+            slot = slot + 1u == p.sub_cap ? 0u : slot + 1u;
         }
         // ---- new halo: the halo_frames frames before the tile end (a contiguous copy; when the tile
         // is shorter than the halo the source reaches into the old halo).  Ascending order is safe:
@@ -902,6 +908,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
         }
         pos = npos;
         off = noff;
+        toff = ntoff;
         seg = nseg_frames;
     }
 
