@@ -73,6 +73,9 @@ __device__ __forceinline__ void mat4_apply_add(const double *__restrict__ M, con
 #ifndef SS_TP_F16
 #define SS_TP_F16 1
 #endif
+#ifndef SS_TD_LATE_PREFETCH
+#define SS_TD_LATE_PREFETCH 0     // 1: issue the next tile's loads behind the K-weighting passes (measured: no gain, -0.5 %)
+#endif
 #ifndef SS_TD_ROWSCAN
 #define SS_TD_ROWSCAN 1
 #endif
@@ -159,7 +162,6 @@ template <int FACTOR, bool RING, int CT, int WAVE>
 __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_domain(TdParams p, uint32_t L, uint32_t tile_len,
                                                                                       uint32_t wave_lds_floats, uint32_t halo_frames)
 {
-    const uint32_t inv_L = 0xFFFFFFFFu / L + 1u;        // ceil(2^32 / L): x / L == (x * inv_L) >> 32 for x < 2^16 (L <= 65)
     using Cfg = TpCfg<FACTOR>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u;
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
         const double *mpow = &K.m_pow[0][0];
         asm volatile("" : "+s"(mpow));
         const bool warm = pos < seg_begin;              // run-in tile: filter only
-        const uint32_t nchunks = (uint32_t)(((uint64_t)(seg + L - 1) * inv_L) >> 32);     // (seg + L - 1) / L, exact for seg < 2^16
+        const uint32_t nchunks = (seg + L - 1) / L;
 
         // ---- stage the tile from the prefetch registers (remainder / unaligned: direct)
         {
@@ -394,7 +396,9 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
         if (sub_done || ntoff >= tile_len) ntoff = 0;
         uint32_t nseg_frames;
         SS_TILE_FRAMES(npos, noff, ntoff, nseg_frames);
+#if !SS_TD_LATE_PREFETCH
         SS_PREFETCH(npos, nseg_frames);
+#endif
         __builtin_amdgcn_wave_barrier();               // LDS is in-order per wave: only ordering is needed
 
         // ---- min-max decimation of the bins that END inside this tile (analyzer.rs:107-137): bin i =
@@ -608,6 +612,12 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
             }
             if (!warm) { e_run += e; sp_run = fmaxf(sp_run, sp); }
         }
+#if SS_TD_LATE_PREFETCH
+        // The next tile's loads are issued here, behind the K-weighting passes: the 32 registers they land in are then
+        // not live through the passes (the kernel's register peak), and the true-peak phase that follows (microseconds)
+        // still covers their latency.
+        SS_PREFETCH(npos, nseg_frames);
+#endif
         // ---- true peak on the matrix pipe (not during the run-in)
         bool halo_done = false;
         const uint32_t tp_now_bits = kTpPlanar ? wave_max_nonneg_bits(sp) : 0u;      // this tile's sample peak, wave-uniform
