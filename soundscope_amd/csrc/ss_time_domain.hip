@@ -24,17 +24,21 @@ namespace ssk {
 //
 //  * Segments.  A stream is cut into `nseg` runs of whole sub-blocks so that a
 //    batch of a few hundred streams still fills 4096 wave slots.  Segment k > 0
-//    starts its filter `warm` sub-blocks (0.3 s) early from a zero state and
-//    discards that run-in: the K-weighting poles (|z| <= 0.99502 at 48 kHz,
-//    i.e. e^-240 per second at any rate) shrink the influence of the unknown
-//    initial state by e^-72 ~ 5e-32 — sixteen orders below f64 rounding — so the
-//    result equals the sequential recurrence to the last bit that f64 carries.
-//    Segment 0 (and every streaming call, nseg = 1) starts from the true state.
+//    starts its filter `warm` sub-blocks (2 = 0.2 s) early from a zero state and
+//    discards that run-in: the slowest K-weighting pole (|z| = 0.99502 at 48 kHz,
+//    e^-240 per second at any rate) leaves e^-48 ~ 1.6e-21 of the unknown initial
+//    state.  The high-pass section's poles are a near-double pair (Q ~ 0.5), so the
+//    residual decays like n r^n and its DC gain is large: on DC-offset material the
+//    state at the segment start is off by ~1e-13 relative — far below anything the
+//    0.01 dB bar or a 0.1 LU histogram bin can see (tests pin the latter), but not
+//    "to the last bit".  Segment 0 (and every streaming call, nseg = 1) starts from
+//    the true carried state.
 //  * K-weighting on the f64 VALU.  Each lane owns one (chunk of L frames,
 //    channel); the recurrence is cut by  state_out = A^L state_in + zero_state:
 //      pass 1: per chunk, run the state recurrence from zero              (4 FMA)
-//      scan  : in-wave Hillis-Steele over chunks (ds_bpermute shuffles) with the
-//              constant matrices (A^L)^(2^k)
+//      scan  : in-wave Hillis-Steele over chunks with the constant matrices
+//              (A^L)^(2^k); chunks are dealt round-robin to the four DPP rows so that
+//              the long distances are in-row v_mov_dpp shifts, the short ones ds_bpermute
 //      pass 2: rerun each chunk from its true initial state, accumulate y^2.
 //    L is chosen with (L-1)*C = 0 (mod 32) so the per-lane walk through the
 //    interleaved tile is bank-conflict free without padding.
