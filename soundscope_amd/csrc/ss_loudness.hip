@@ -85,36 +85,49 @@ __device__ void eval_hist(const unsigned long long *hb, const unsigned long long
     if (lane == 0) { if (out_i) *out_i = integrated; if (out_lra) *out_lra = lra; }
 }
 
-__global__ __launch_bounds__(64) void k_finalize(FinalizeParams p)
+// slot of sub-block (j - q) in a ring of `cap` slots, given jm = j % cap and q <= 29 (no division per term)
+__device__ __forceinline__ uint32_t ring_back(uint32_t jm, uint32_t q, uint32_t cap)
+{
+    uint32_t s = jm + cap * 30u - q;          // cap >= 1: the bias keeps it positive for q <= 29 < 30 cap
+    return s % cap;
+}
+
+// One workgroup per stream; the gating blocks of a stream are independent (histogram increments are LDS atomics), so a
+// long stream (config 2's 600 s: 6000 sub-blocks) is spread over 256 threads; wave 0 then evaluates gate and LRA.
+__global__ __launch_bounds__(256) void k_finalize(FinalizeParams p)
 {
     __shared__ unsigned long long hb[kHistBins];
     __shared__ unsigned long long hs[kHistBins];
     __shared__ unsigned int counts[2];
     const uint32_t stream = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x, nthr = (int)blockDim.x;
     unsigned long long *gh = reinterpret_cast<unsigned long long *>(p.hist) + (size_t)stream * 2 * kHistBins;
     unsigned long long *corpus = reinterpret_cast<unsigned long long *>(p.corpus_hist);
-    for (int i = lane; i < kHistBins; i += 64) { hb[i] = gh[i]; hs[i] = gh[kHistBins + i]; }
+    for (int i = lane; i < kHistBins; i += nthr) { hb[i] = gh[i]; hs[i] = gh[kHistBins + i]; }
     if (lane < 2) counts[lane] = 0;
     __syncthreads();
 
     const uint32_t C = p.channels;
     const double S = (double)p.k->s100;
     const double *P = p.subblocks + (size_t)stream * p.sub_stride;
+    const uint32_t cap = p.sub_cap;
+    const bool direct = p.sub_end <= (uint64_t)cap && p.sub_begin == 0;               // batches: slot == sub-block index
     // gating block ending with sub-block j: j-3..j ; short-term block: j-29..j when (j-29) % 10 == 0
     const uint64_t sub_end = p.sub_end_of ? p.sub_end_of[stream] : p.sub_end;          // ragged batches
-    for (uint64_t j = p.sub_begin + lane; j < sub_end; j += 64) {
+    uint32_t nb = 0, ns = 0;
+    for (uint64_t j = p.sub_begin + lane; j < sub_end; j += nthr) {
+        const uint32_t jm = direct ? (uint32_t)j : (uint32_t)(j % cap);
         if (j >= 3) {
             double sum = 0.0;
             for (uint32_t c = 0; c < C; c++) {
                 const double w = p.weights[c];
                 if (w == 0.0) continue;
                 double cs = 0.0;
-                for (int q = 3; q >= 0; q--) cs += P[(size_t)((j - q) % p.sub_cap) * C + c];
+                for (int q = 3; q >= 0; q--) cs += P[(size_t)(direct ? jm - (uint32_t)q : ring_back(jm, (uint32_t)q, cap)) * C + c];
                 sum += w * cs;
             }
             sum /= 4.0 * S;
-            atomicAdd(&counts[0], 1u);
+            nb++;
             if (sum >= p.hist_bounds[0]) atomicAdd(&hb[hist_index(p.hist_bounds, sum)], 1ull);
         }
         if (j >= 29 && (j - 29) % 10 == 0) {
@@ -123,17 +136,19 @@ __global__ __launch_bounds__(64) void k_finalize(FinalizeParams p)
                 const double w = p.weights[c];
                 if (w == 0.0) continue;
                 double cs = 0.0;
-                for (int q = 29; q >= 0; q--) cs += P[(size_t)((j - q) % p.sub_cap) * C + c];
+                for (int q = 29; q >= 0; q--) cs += P[(size_t)(direct ? jm - (uint32_t)q : ring_back(jm, (uint32_t)q, cap)) * C + c];
                 sum += w * cs;
             }
             sum /= 30.0 * S;
-            atomicAdd(&counts[1], 1u);
+            ns++;
             if (sum >= p.hist_bounds[0]) atomicAdd(&hs[hist_index(p.hist_bounds, sum)], 1ull);
         }
     }
+    if (nb) atomicAdd(&counts[0], nb);
+    if (ns) atomicAdd(&counts[1], ns);
     __syncthreads();
     // corpus contribution = what this call added
-    for (int i = lane; i < kHistBins; i += 64) {
+    for (int i = lane; i < kHistBins; i += nthr) {
         const unsigned long long db = hb[i] - gh[i], ds = hs[i] - gh[kHistBins + i];
         if (corpus) {
             if (db) atomicAdd(&corpus[i], db);
@@ -143,9 +158,10 @@ __global__ __launch_bounds__(64) void k_finalize(FinalizeParams p)
         gh[kHistBins + i] = hs[i];
     }
     if (p.out_counts && lane < 2) p.out_counts[stream * 2 + lane] += counts[lane];
-    eval_hist(hb, hs, p.hist_energies, p.hist_bounds,
-              p.out_integrated ? &p.out_integrated[stream] : nullptr,
-              p.out_lra ? &p.out_lra[stream] : nullptr);
+    if (lane < 64)          // (wave 0; the histograms in LDS are complete: the barrier above)
+        eval_hist(hb, hs, p.hist_energies, p.hist_bounds,
+                  p.out_integrated ? &p.out_integrated[stream] : nullptr,
+                  p.out_lra ? &p.out_lra[stream] : nullptr);
 }
 
 // Streaming form (one handle, a few new sub-blocks per call, no per-call read-out): the same gating rules
@@ -197,7 +213,12 @@ hipError_t launch_finalize(const FinalizeParams &p, hipStream_t s)
     if (p.n_streams == 0) return hipSuccess;
     const bool streaming = p.n_streams == 1 && !p.corpus_hist && !p.out_integrated && !p.out_lra && p.sub_stride == 0;
     if (streaming) hipLaunchKernelGGL(k_finalize_stream, dim3(1), dim3(64), 0, s, p);
-    else hipLaunchKernelGGL(k_finalize, dim3(p.n_streams), dim3(64), 0, s, p);
+    else {
+        // a wave per stream when there are many streams or little to do per stream; four waves for a long stream
+        const uint64_t nsub = p.sub_end - p.sub_begin;
+        const uint32_t threads = (nsub > 512 && p.n_streams < 4096) ? 256u : 64u;
+        hipLaunchKernelGGL(k_finalize, dim3(p.n_streams), dim3(threads), 0, s, p);
+    }
     return hipGetLastError();
 }
 
