@@ -206,6 +206,14 @@ def main():
     lay = b.layout
     b.set_overlap(not args.sequential)
     hist = [None]
+    # the memory system's floor for the spectrum kernel's access pattern on THIS box: its loads and stores alone, same
+    # grid / occupancy / addresses, no arithmetic (overwrites the spectra, so it runs before anything is computed)
+    io_floor_ms = None
+    if rank == 0:
+        try:
+            io_floor_ms = b.traffic_floor(5)
+        except Exception:
+            io_floor_ms = None
 
     def step():
         b.run()
@@ -296,7 +304,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": lib.ss_batch_kernel_name(b._h, L.SS_KERNEL_FFT).decode(),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         # context, measured in this run: the same loads and stores with no arithmetic in between
+                         "io_floor": ({"ms": io_floor_ms, "GBps": alg_bytes / (io_floor_ms * 1e-3) / 1e9,
+                                       "kernel_over_floor": (fft_ms / max(fft_n_launch, 1)) / io_floor_ms,
+                                       "what": "k_fft4096_traffic: this kernel's grid, occupancy and addresses, loads + stores only"}
+                                      if io_floor_ms else None)},
         }
         # PCIe-inclusive rate (informational, never `value`): host f32 -> HBM upload of a slice + its share of a pass
         try:

@@ -241,6 +241,12 @@ void *ss_batch_input_device_ptr(ss_batch *b);
 /* fill the corpus with the documented synthetic signal: utility
  * for benchmarks, not part of the measured path */
 int ss_batch_synthesize(ss_batch *b, uint64_t seed, uint32_t first_stream_id);
+/* measurement utility (like ss_batch_synthesize, not part of the measured path): run ONLY the HBM traffic of this batch's
+ * spectrum kernel — same grid, workgroup size, LDS footprint (occupancy) and addresses, loads and stores, no arithmetic —
+ * `reps` times and return the average milliseconds per launch: the floor the memory system sets for that access pattern
+ * on this device, next to which the kernel's time can be read.  Overwrites the batch's spectrum buffer.
+ * SS_ERR_UNSUPPORTED unless the batch takes the N = 4096 stereo kernel at hop 1024. */
+int ss_batch_traffic_floor(ss_batch *b, uint32_t reps, double *ms_per_launch);
 /* enqueue one pass of the hot path over the whole batch; asynchronous */
 int ss_batch_run(ss_batch *b);
 int ss_batch_sync(ss_batch *b);

@@ -38,7 +38,7 @@ SYMBOLS = [
     "ss_device_synchronize", "ss_batch_peaks", "ss_batch_geometry_get", "ss_batch_set_overlap",
     "ss_comm_init", "ss_comm_init_from_env", "ss_comm_destroy", "ss_comm_rank", "ss_comm_size",
     "ss_comm_transport_name", "ss_comm_barrier", "ss_comm_allreduce_u64_sum", "ss_comm_allreduce_f64_max",
-    "ss_batch_allreduce_histograms",
+    "ss_batch_allreduce_histograms", "ss_batch_traffic_floor",
 ]
 
 SS_OK = 0
@@ -195,6 +195,7 @@ def _bind(lib):
         "ss_comm_allreduce_u64_sum": (C.c_int, [vp, u64p, C.c_size_t]),
         "ss_comm_allreduce_f64_max": (C.c_int, [vp, f64p, C.c_size_t]),
         "ss_batch_allreduce_histograms": (C.c_int, [vp, vp, u64p]),
+        "ss_batch_traffic_floor": (C.c_int, [vp, C.c_uint32, f64p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -108,6 +108,12 @@ class Batch:
         _check(L.lib().ss_batch_allreduce_histograms(self._h, comm._h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
         return out[:1000].copy(), out[1000:].copy()
 
+    def traffic_floor(self, reps=5):
+        """ms per launch of the spectrum kernel's loads and stores alone (measurement utility; clobbers the spectra)."""
+        ms = C.c_double()
+        _check(L.lib().ss_batch_traffic_floor(self._h, reps, C.byref(ms)))
+        return ms.value
+
     def fft(self, stream):
         lay = self.layout
         out = np.empty((lay.n_windows, lay.fft_channels, lay.n_bins), np.float32)

@@ -1047,7 +1047,13 @@ int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
 #ifdef SS_TUNING
         if (const char *e = std::getenv("SS_FFT_WPB")) { int v = std::atoi(e); if (v >= 2 && v <= 4096) b->windows_per_block = (uint32_t)(v & ~1); }
 #endif
-        L.fft_bin_stride = (L.n_bins + 3u) & ~3u;        // rows start 16-B aligned: 16-byte stores
+        // Rows start 16-byte aligned (16-byte stores).  Padding them to whole 128-byte lines lifts a pure streaming-store
+        // kernel with this row pattern from 3.7 to 4.4 TB/s (tools/ubench_fftio.hip) but does nothing for the real kernel
+        // (A/B in one process: 3.14 vs 3.12 ms), so the rows stay compact.  -DSS_FFT_ROW_ALIGN=32u rebuilds the padded form.
+#ifndef SS_FFT_ROW_ALIGN
+#define SS_FFT_ROW_ALIGN 4u
+#endif
+        L.fft_bin_stride = (L.n_bins + (SS_FFT_ROW_ALIGN - 1u)) & ~(SS_FFT_ROW_ALIGN - 1u);
         L.fft_bytes = (uint64_t)cfg->n_streams * L.n_windows * L.fft_channels * L.fft_bin_stride * sizeof(float);
         HIPCHK(b->fft.alloc((size_t)(L.fft_bytes / sizeof(float))));
     }
@@ -1447,6 +1453,37 @@ int ss_batch_run(ss_batch *b)
         HIPCHK(hipStreamWaitEvent(b->stream, b->ev_join, 0));
     }
     b->pending_events = tm;
+    return SS_OK;
+}
+
+// measurement utility: the spectrum kernel's loads and stores alone (see the header)
+int ss_batch_traffic_floor(ss_batch *b, uint32_t reps, double *ms_per_launch)
+{
+    SS_ON_DEVICE(b);
+    if (!b || !ms_per_launch || reps == 0) return SS_ERR_INVALID_ARG;
+    const ss_batch_config &c = b->cfg;
+    const ss_batch_layout &L = b->lay;
+    if (!(c.flags & SS_BATCH_FFT) || !b->fft_fast || c.hop_frames != 1024 || !L.n_windows || b->ragged) return SS_ERR_UNSUPPORTED;
+    ssk::FftBatchParams p{};
+    p.pcm = b->pcm.p; p.out = b->fft.p;
+    p.frames_per_stream = c.frames_per_stream; p.first_start = b->first_start;
+    p.n_streams = c.n_streams; p.channels = c.channels; p.n_windows = L.n_windows; p.hop = c.hop_frames;
+    p.n = c.fft_n; p.first_bin = L.first_bin; p.n_bins = L.n_bins; p.bin_stride = L.fft_bin_stride;
+    p.windows_per_block = b->windows_per_block;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(hipEventCreate(&e0));
+    hipError_t err = hipEventCreate(&e1);
+    if (err == hipSuccess) err = ssk::launch_fft4096_traffic(p, b->stream);            // warm
+    if (err == hipSuccess) err = hipEventRecord(e0, b->stream);
+    for (uint32_t r = 0; r < reps && err == hipSuccess; r++) err = ssk::launch_fft4096_traffic(p, b->stream);
+    if (err == hipSuccess) err = hipEventRecord(e1, b->stream);
+    if (err == hipSuccess) err = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    HIPCHK(err);
+    *ms_per_launch = (double)ms / reps;
     return SS_OK;
 }
 

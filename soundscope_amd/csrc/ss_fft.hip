@@ -5,6 +5,9 @@
 // Nothing here is translated from the reference: the reference has no GPU code.
 #include "ss_kernels.h"
 
+#ifndef SS_FFT_NT_STORE
+#define SS_FFT_NT_STORE 0
+#endif
 #ifndef SS_FFT_WAVES
 #define SS_FFT_WAVES 2   // min waves per SIMD the N=4096 pair kernel is register-allocated for
 #endif
@@ -223,8 +226,14 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
             asm volatile("" ::"v"(rm[0]), "v"(rm[1]), "v"(rm[2]), "v"(rm[3]), "v"(rs[0]), "v"(rs[1]), "v"(rs[2]), "v"(rs[3]));
             (void)o_mid; (void)o_side;
 #else
+#if SS_FFT_NT_STORE
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(f4v{rm[0], rm[1], rm[2], rm[3]}, reinterpret_cast<f4v *>(o_mid) + g);
+            if (store_side) __builtin_nontemporal_store(f4v{rs[0], rs[1], rs[2], rs[3]}, reinterpret_cast<f4v *>(o_side) + g);
+#else
             reinterpret_cast<float4 *>(o_mid)[g] = make_float4(rm[0], rm[1], rm[2], rm[3]);
             if (store_side) reinterpret_cast<float4 *>(o_side)[g] = make_float4(rs[0], rs[1], rs[2], rs[3]);
+#endif
 #endif
         }
     }

@@ -158,6 +158,8 @@ hipError_t launch_render_spectrum(const float *rows, uint32_t bin_stride, uint32
 hipError_t launch_render_waveform(const float *wave, uint64_t wave_stride, uint32_t n_points, uint32_t n_streams,
                                   uint32_t x_min, uint32_t x_max, uint32_t cols, float *out, hipStream_t s);
 hipError_t launch_mid_side(const float *interleaved, size_t frames, float *mid, float *side, hipStream_t s);
+// measurement utility: k_fft4096_ms1's loads and stores with no arithmetic (same grid, occupancy and addresses)
+hipError_t launch_fft4096_traffic(const FftBatchParams &p, hipStream_t s);
 hipError_t launch_synth(float *pcm, uint32_t n_streams, uint64_t frames, uint32_t channels,
                         uint32_t rate, uint64_t seed, uint32_t first_id, hipStream_t s);
 

@@ -235,4 +235,52 @@ hipError_t launch_synth(float *pcm, uint32_t n_streams, uint64_t frames, uint32_
     return hipGetLastError();
 }
 
+// ---- measurement utility: the spectrum kernel's HBM traffic with no arithmetic -----------------------------------------
+// Same grid, same workgroup size, same LDS footprint (so the same three workgroups per CU), same addresses: every
+// workgroup walks its run of windows, loads the four new 256-frame slots of each window (8-byte loads) and stores the two
+// output rows as 16-byte stores.  What this takes is the floor the memory system sets for k_fft4096_ms1's access pattern
+// on this chip — a copy-shaped ceiling next to which the kernel's own time can be read (bench.py: roofline.io_floor).
+__global__ __launch_bounds__(256, 3) void k_fft4096_traffic(FftBatchParams p)
+{
+    __shared__ float pad[9728];                                           // 38 912 B: the spectrum kernel's footprint
+    const int t = threadIdx.x;
+    const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
+    const uint32_t stream = blockIdx.x / groups;
+    const uint32_t grp = blockIdx.x - stream * groups;
+    const uint32_t w_begin = grp * p.windows_per_block;
+    uint32_t w_end = w_begin + p.windows_per_block;
+    if (w_begin >= p.n_windows) return;
+    if (w_end > p.n_windows) w_end = p.n_windows;
+    const float2 *src = reinterpret_cast<const float2 *>(p.pcm) + (size_t)stream * p.frames_per_stream + p.first_start + (size_t)w_begin * p.hop;
+    float *outp = p.out + ((size_t)stream * p.n_windows + w_begin) * 2 * p.bin_stride;
+    const uint32_t ngroups = (p.n_bins + 3) >> 2;
+    float acc = 0.0f;
+    pad[t] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 12; j++) { const float2 v = src[t + 256 * j]; acc += v.x + v.y; }       // the run's first window: all 16 slots
+    for (uint32_t w = w_begin; w < w_end; ++w) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const float2 v = src[(size_t)(w - w_begin) * p.hop + t + 256 * (12 + q)]; acc += v.x + v.y; }
+        float *o = outp + (size_t)(w - w_begin) * 2 * p.bin_stride;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint32_t g = (uint32_t)t + 256u * i;
+            if (g < ngroups) {
+                const float4 v = make_float4(acc, acc, acc, acc);
+                reinterpret_cast<float4 *>(o)[g] = v;
+                reinterpret_cast<float4 *>(o + p.bin_stride)[g] = v;
+            }
+        }
+    }
+    if (acc == 1.2345e33f) pad[t] = acc;
+}
+
+hipError_t launch_fft4096_traffic(const FftBatchParams &p, hipStream_t s)
+{
+    if (p.n_windows == 0 || p.n_streams == 0) return hipSuccess;
+    const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
+    hipLaunchKernelGGL(k_fft4096_traffic, dim3(groups * p.n_streams), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 }  // namespace ssk
