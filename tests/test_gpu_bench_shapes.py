@@ -267,3 +267,23 @@ def test_rccl_communicator_single_rank_on_device(oracle):
     gi, _ = corpus_gate(np.concatenate([hb, hs]))
     assert gi == oracle.gated_loudness_hist(hb)
     comm.close()
+
+
+def test_traffic_floor_utility(oracle):
+    """ss_batch_traffic_floor times the spectrum kernel's loads and stores alone; it clobbers the spectra (documented)
+    and the next pass recomputes them; shapes that do not take the N = 4096 stereo kernel are refused."""
+    rate, frames = 48000, 48000 * 2
+    xs = [make_stereo(70 + i, frames, rate) for i in range(4)]
+    b = ssa.Batch(rate, 2, 4, frames, 4096, 1024)
+    b.upload(0, np.concatenate(xs))
+    b.run(); b.sync()
+    ref = b.fft(2).copy()
+    ms = b.traffic_floor(3)
+    assert 0.0 < ms < 50.0
+    assert not np.array_equal(b.fft(2), ref)                  # overwritten by the utility
+    b.run(); b.sync()
+    assert np.array_equal(b.fft(2), ref)                      # and recomputed, bit for bit
+    b16 = ssa.Batch(rate, 2, 1, frames, 16384, 1024)
+    out = L.C.c_double()
+    assert L.lib().ss_batch_traffic_floor(b16._h, 1, L.C.byref(out)) == L.SS_ERR_UNSUPPORTED
+    assert L.lib().ss_batch_traffic_floor(b._h, 0, L.C.byref(out)) == L.SS_ERR_INVALID_ARG
