@@ -192,8 +192,18 @@ def main():
         raise SystemExit("ss_set_device failed: " + lib.ss_last_device_error().decode())
     comm = None
     if world > 1:
-        comm = Comm.from_env(transport)           # RCCL: ncclCommInitRank inside the library
-        comm.barrier()                            # proves the communicator before anything is timed
+        try:
+            comm = Comm.from_env(transport)       # RCCL: ncclCommInitRank inside the library
+            comm.barrier()                        # proves the communicator before anything is timed
+        except Exception as e:
+            # a broken RCCL setup must not cost the whole line: the 16 kB exchange can be staged through host memory
+            # (every rank takes this branch together when the bootstrap itself fails; the JSON says which transport ran)
+            print(f"[bench] rank {rank}: {transport} communicator failed ({e}); falling back to host-tcp", file=sys.stderr, flush=True)
+            if transport == "host-tcp":
+                raise
+            os.environ["SS_COMM_FILE"] = f"/tmp/ss_comm_fallback_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}.rdzv"
+            comm = Comm.from_env("host-tcp")
+            comm.barrier()
         if comm.size != world:
             raise SystemExit(f"communicator reports {comm.size} ranks, expected {world}")
 
