@@ -171,6 +171,12 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the config 2 / config 5 lines")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON): native libraries print to file descriptor 1 on their own (RCCL's
+    # version banner at communicator creation), so everything but the final line is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -355,7 +361,8 @@ def main():
             except Exception as ex:
                 extra.append({"error": repr(ex)})
             out["config"]["extra"] = extra
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:
         comm.barrier()
         comm.close()
