@@ -66,6 +66,23 @@ int ss_device_synchronize(void);
 const char *ss_last_device_error(void);
 
 /* ------------------------------------------------------------------------ *
+ *  Inspection of the constant tables the kernels consume, exactly as the library designs them on the host (no device
+ *  needed).  They exist so that the PRODUCT's tables can be checked against published numbers (BS.1770-4 coefficient
+ *  table, EBU histogram definition, SURVEY's bin counts) independently of the test oracle.  Any pointer may be NULL.
+ * ------------------------------------------------------------------------ */
+/* K-weighting of ebur128 0.1.10 at `rate` (one 4th-order section: b[0..4], a[0..4], a[0] = 1) */
+int ss_inspect_kweight(uint32_t rate, double b5[5], double a5[5]);
+/* true-peak interpolator (49-tap Hann-windowed sinc, `factor` 2 or 4): taps[(f - 1) * len + t] = coefficient of x[n - t] in
+ * polyphase branch f = 1 .. factor - 1 (branch 0 is the identity tap); *len = taps per branch (12 or 24) */
+int ss_inspect_true_peak(int factor, float *taps, uint32_t cap, uint32_t *len);
+/* spectrum-analyzer's periodic Hann window in f32 (n values) */
+int ss_inspect_hann(uint32_t n, float *w);
+/* retained bins of FrequencyLimit::Range(20, 20000) for (rate, n): FFT index of the first one and their number */
+int ss_inspect_bins(uint32_t rate, uint32_t n, uint32_t *first_bin, uint32_t *n_bins);
+/* ebur128 histogram: 1000 representative energies and 1001 bin boundaries */
+int ss_inspect_histogram(double energies1000[1000], double bounds1001[1001]);
+
+/* ------------------------------------------------------------------------ *
  *  Analyzer mirror (one entry point per Rust method)
  * ------------------------------------------------------------------------ */
 typedef struct ss_analyzer ss_analyzer;

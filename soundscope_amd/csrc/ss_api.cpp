@@ -448,6 +448,59 @@ int ss_device_synchronize(void)
 }
 const char *ss_last_device_error(void) { return g_last_err.c_str(); }
 
+// ---- inspection of the host-designed tables (no device involved) -------------------------------------------------
+int ss_inspect_kweight(uint32_t rate, double b5[5], double a5[5])
+{
+    if (rate < 16 || rate > 2822400) return SS_ERR_INVALID_ARG;
+    double b[5], a[5];
+    sst::kweight_design((double)rate, b, a);
+    if (b5) std::memcpy(b5, b, sizeof b);
+    if (a5) std::memcpy(a5, a, sizeof a);
+    return SS_OK;
+}
+
+int ss_inspect_true_peak(int factor, float *taps, uint32_t cap, uint32_t *len)
+{
+    if (factor != 2 && factor != 4) return SS_ERR_INVALID_ARG;
+    std::vector<std::vector<sst::PolyTap>> ph; int delay = 0;
+    sst::true_peak_design(factor, ph, &delay);
+    const uint32_t n = factor == 4 ? 12u : 24u;            // taps per branch as the kernels hold them (TdConst::tp)
+    if (len) *len = n;
+    if (taps) {
+        if (cap < (uint32_t)(factor - 1) * n) return SS_ERR_CAPACITY;
+        std::memset(taps, 0, sizeof(float) * (size_t)(factor - 1) * n);
+        for (int f = 1; f < factor; f++)
+            for (const auto &tap : ph[f]) if ((uint32_t)tap.delay < n) taps[(size_t)(f - 1) * n + tap.delay] = tap.coeff;
+    }
+    return SS_OK;
+}
+
+int ss_inspect_hann(uint32_t n, float *w)
+{
+    if (!w) return SS_ERR_INVALID_ARG;
+    const std::vector<float> h = sst::hann_window(n);
+    if (n) std::memcpy(w, h.data(), sizeof(float) * n);
+    return SS_OK;
+}
+
+int ss_inspect_bins(uint32_t rate, uint32_t n, uint32_t *first_bin, uint32_t *n_bins)
+{
+    size_t first = 0;
+    const size_t cnt = sst::fft_bins(rate, n, &first);
+    if (first_bin) *first_bin = (uint32_t)first;
+    if (n_bins) *n_bins = (uint32_t)cnt;
+    return SS_OK;
+}
+
+int ss_inspect_histogram(double energies1000[1000], double bounds1001[1001])
+{
+    double e[sst::kHistBins], b[sst::kHistBins + 1];
+    sst::histogram_tables(e, b);
+    if (energies1000) std::memcpy(energies1000, e, sizeof e);
+    if (bounds1001) std::memcpy(bounds1001, b, sizeof b);
+    return SS_OK;
+}
+
 int ss_analyzer_create(uint32_t channels, uint32_t rate, ss_analyzer **out)
 {
     if (!out) return SS_ERR_INVALID_ARG;
