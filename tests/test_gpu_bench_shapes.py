@@ -287,3 +287,21 @@ def test_traffic_floor_utility(oracle):
     out = L.C.c_double()
     assert L.lib().ss_batch_traffic_floor(b16._h, 1, L.C.byref(out)) == L.SS_ERR_UNSUPPORTED
     assert L.lib().ss_batch_traffic_floor(b._h, 0, L.C.byref(out)) == L.SS_ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("channels,rate,frames", [(4, 48000, 48000 * 3 + 77), (8, 44100, 44100 * 2), (16, 48000, 48000), (1, 44100, 44100 * 3)])
+def test_batch_true_peak_other_channel_counts(oracle, channels, rate, frames):
+    """The planar f16 true peak for every channel count that takes it in a batch (1, 2, 4, 8: blocks of 64 / C frames) and
+    the f32 product for 16; rates whose tiles are not whole column groups (44.1 kHz) mix both inside a tile."""
+    from conftest import make_multich
+    xs = [make_multich(300 + i, frames, channels, rate, level=0.2 + 0.5 * i) for i in range(2)]
+    b = ssa.Batch(rate, channels, 2, frames, 4096, 1024, flags=L.SS_BATCH_LUFS | L.SS_BATCH_TRUE_PEAK)
+    b.upload(0, np.concatenate(xs)); b.run(); b.sync()
+    res = b.results()
+    for i, x in enumerate(xs):
+        m = oracle.Meter(channels, rate); m.add_frames(x)
+        tp, sp = b.peaks(i)
+        for c in range(channels):
+            assert rel_close(tp[c], max(m.true_peak(c), m.sample_peak(c))), (i, c, tp[c], m.true_peak(c))
+            assert sp[c] == m.sample_peak(c)
+        assert lufs_close(res[i].integrated_lufs, m.integrated())

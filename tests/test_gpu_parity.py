@@ -203,7 +203,8 @@ def test_meter_errors_and_reinit(oracle):
     assert lufs_close(an.get_momentary_lufs(), m.momentary())
 
 
-@pytest.mark.parametrize("channels,rate", [(1, 48000), (6, 48000), (8, 96000), (5, 44100), (3, 22050)])
+@pytest.mark.parametrize("channels,rate", [(1, 48000), (6, 48000), (8, 96000), (5, 44100), (3, 22050), (4, 48000), (8, 48000), (16, 44100),
+                                           (2, 32000), (64, 16000)])
 def test_multichannel_meter(oracle, channels, rate):
     x = make_multich(channels * 31 + rate, rate * 5, channels, rate)
     an = ssa.Analyzer(); an.create_loudness_meter(channels, rate)
