@@ -232,11 +232,10 @@ def main():
             io_floor_ms = None
 
     def step():
+        # one pass + the corpus gate, all queued on the device: [ncclAllReduce of the 2 x 1000 u64 histograms in place on
+        # the batch's stream when N > 1] + gate / LRA of the summed histograms.  No host synchronisation per step.
         b.run()
-        if comm is not None:
-            hist[0] = np.concatenate(b.allreduce_histograms(comm))     # ncclAllReduce in place on the batch's stream, then D2H + sync
-        else:
-            hist[0] = np.concatenate(b.histograms())                   # D2H + sync
+        b.corpus_gate_enqueue(comm)
 
     def fence():
         lib.ss_device_synchronize()
@@ -258,7 +257,11 @@ def main():
 
     samples_per_step = total_streams * frames * 2
     value = samples_per_step * args.steps / dt
-    corpus_i, corpus_lra = corpus_gate(hist[0])
+    corpus_i, corpus_lra = b.corpus_gate_read()                 # what the last step left on the device
+    hist[0] = np.concatenate(b.histograms())                    # (all-reduced in place when N > 1)
+    host_i, host_lra = corpus_gate(hist[0])                     # the same gate on the host copy of the histograms
+    if abs(corpus_i - host_i) > 1e-9 or abs(corpus_lra - host_lra) > 1e-9:
+        raise SystemExit(f"device corpus gate {corpus_i, corpus_lra} != host {host_i, host_lra}")
 
     # per-kernel times: a separate SEQUENTIAL pass (with two kernels sharing the chip a per-kernel HIP-event time
     # would not describe either of them); HIP events on the batch's own stream

@@ -341,6 +341,12 @@ int ss_comm_allreduce_f64_max(ss_comm *c, double *inout, size_t n);
  * the reduced histograms after the stream has drained.  Afterwards ss_batch_histograms returns the corpus-wide
  * histograms on every rank, and ss_corpus_integrated_lufs / ss_corpus_loudness_range evaluate the gate. */
 int ss_batch_allreduce_histograms(ss_batch *b, ss_comm *c, uint64_t *out2000);
+/* the whole corpus gate on the device, asynchronously: [ss_batch_allreduce_histograms over `c` when c != NULL] + A7 / A8
+ * (loudness_global_multiple, loudness_range_multiple) of the summed histograms into a device pair, queued on the batch's
+ * stream behind ss_batch_run — no copy, no wait, so a loop of passes needs no host synchronisation per pass.
+ * ss_batch_corpus_gate_read waits for the stream and returns the pair of the last pass. */
+int ss_batch_corpus_gate_enqueue(ss_batch *b, ss_comm *c);
+int ss_batch_corpus_gate_read(ss_batch *b, double *integrated_lufs, double *loudness_range);
 
 /* ------------------------------------------------------------------------- *
  *  Render-side reductions: the step after the path.

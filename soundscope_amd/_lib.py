@@ -39,6 +39,7 @@ SYMBOLS = [
     "ss_comm_init", "ss_comm_init_from_env", "ss_comm_destroy", "ss_comm_rank", "ss_comm_size",
     "ss_comm_transport_name", "ss_comm_barrier", "ss_comm_allreduce_u64_sum", "ss_comm_allreduce_f64_max",
     "ss_batch_allreduce_histograms", "ss_batch_traffic_floor",
+    "ss_batch_corpus_gate_enqueue", "ss_batch_corpus_gate_read",
     "ss_inspect_kweight", "ss_inspect_true_peak", "ss_inspect_hann", "ss_inspect_bins", "ss_inspect_histogram",
 ]
 
@@ -197,6 +198,8 @@ def _bind(lib):
         "ss_comm_allreduce_f64_max": (C.c_int, [vp, f64p, C.c_size_t]),
         "ss_batch_allreduce_histograms": (C.c_int, [vp, vp, u64p]),
         "ss_batch_traffic_floor": (C.c_int, [vp, C.c_uint32, f64p]),
+        "ss_batch_corpus_gate_enqueue": (C.c_int, [vp, vp]),
+        "ss_batch_corpus_gate_read": (C.c_int, [vp, f64p, f64p]),
         "ss_inspect_kweight": (C.c_int, [C.c_uint32, f64p, f64p]),
         "ss_inspect_true_peak": (C.c_int, [C.c_int, f32p, C.c_uint32, C.POINTER(C.c_uint32)]),
         "ss_inspect_hann": (C.c_int, [C.c_uint32, f32p]),

@@ -108,6 +108,16 @@ class Batch:
         _check(L.lib().ss_batch_allreduce_histograms(self._h, comm._h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
         return out[:1000].copy(), out[1000:].copy()
 
+    def corpus_gate_enqueue(self, comm=None):
+        """Queue the corpus gate on the device behind run(): all-reduce over `comm` (if any) + gate + LRA; no wait."""
+        _check(L.lib().ss_batch_corpus_gate_enqueue(self._h, comm._h if comm is not None else None))
+
+    def corpus_gate_read(self):
+        """(integrated LUFS, LRA) of the last queued corpus gate (waits for the batch's stream)."""
+        i, r = C.c_double(), C.c_double()
+        _check(L.lib().ss_batch_corpus_gate_read(self._h, C.byref(i), C.byref(r)))
+        return i.value, r.value
+
     def traffic_floor(self, reps=5):
         """ms per launch of the spectrum kernel's loads and stores alone (measurement utility; clobbers the spectra)."""
         ms = C.c_double()

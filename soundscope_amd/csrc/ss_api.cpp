@@ -1717,6 +1717,38 @@ int ss_batch_histograms_device(ss_batch *b, void *dst)
     return SS_OK;
 }
 
+// The corpus gate without leaving the device: [sum over the ranks] + loudness_global / loudness_range of the corpus
+// histograms, queued on the batch's stream behind ss_batch_run.  Nothing is copied or waited for, so a loop of passes
+// needs no host synchronisation per pass; ss_batch_corpus_gate_read fetches the pair.
+int ss_batch_corpus_gate_enqueue(ss_batch *b, ss_comm *comm)
+{
+    SS_ON_DEVICE(b);
+    if (!b) return SS_ERR_INVALID_ARG;
+    if (!b->corpus.p) return SS_ERR_INVALID_MODE;
+    if (comm) {
+        int rc = ss_batch_allreduce_histograms(b, comm, nullptr);
+        if (rc) return rc;
+    }
+    const double *he, *hb;
+    int rc = get_hist_tables(&he, &hb);
+    if (rc) return rc;
+    HIPCHK(ssk::launch_hist_eval(b->corpus.p, he, hb, b->out2.p, b->stream));
+    return SS_OK;
+}
+
+int ss_batch_corpus_gate_read(ss_batch *b, double *integrated, double *lra)
+{
+    SS_ON_DEVICE(b);
+    if (!b) return SS_ERR_INVALID_ARG;
+    if (!b->corpus.p) return SS_ERR_INVALID_MODE;
+    double r[2];
+    HIPCHK(hipMemcpyAsync(r, b->out2.p, sizeof r, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (integrated) *integrated = r[0];
+    if (lra) *lra = r[1];
+    return SS_OK;
+}
+
 double ss_corpus_integrated_lufs(const uint64_t *h) { return h ? sst::gated_loudness(h) : NAN; }
 double ss_corpus_loudness_range(const uint64_t *h) { return h ? sst::loudness_range(h) : NAN; }
 

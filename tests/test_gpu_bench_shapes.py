@@ -264,8 +264,13 @@ def test_rccl_communicator_single_rank_on_device(oracle):
     for x in xs:
         m = oracle.Meter(2, rate); m.add_frames(x); ms.append(m)
     assert np.array_equal(hb, sum(m.block_hist() for m in ms))
-    gi, _ = corpus_gate(np.concatenate([hb, hs]))
+    gi, gr = corpus_gate(np.concatenate([hb, hs]))
     assert gi == oracle.gated_loudness_hist(hb)
+    # the same gate queued on the device (what bench.py's step does: run + all-reduce + gate, no host sync in between)
+    for c in (None, comm):
+        b.run(); b.corpus_gate_enqueue(c)
+        di, dr = b.corpus_gate_read()
+        assert abs(di - gi) < 1e-9 and abs(dr - gr) < 1e-9, (di, gi, dr, gr)
     comm.close()
 
 
