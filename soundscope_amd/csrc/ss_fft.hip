@@ -74,27 +74,6 @@ __device__ __forceinline__ v2f pk_mul_mi(v2f a)
     return r;
 }
 
-// (v.x + v.y, v.x - v.y): the raw mid/side sums of one stereo frame in one instruction
-__device__ __forceinline__ v2f pk_sum_diff(v2f v)
-{
-    v2f r;
-    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(v));
-    return r;
-}
-// a * w.x / a * w.y for both halves of a (window weights are kept two to a register pair)
-__device__ __forceinline__ v2f pk_scale_lo(v2f a, v2f w)
-{
-    v2f r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(w));
-    return r;
-}
-__device__ __forceinline__ v2f pk_scale_hi(v2f a, v2f w)
-{
-    v2f r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(w));
-    return r;
-}
-
 // forward radix-4 butterfly on (a0,a1,a2,a3) in place: A_k = sum_j a_j (-i)^(jk)  — 8 packed adds
 __device__ __forceinline__ void radix4(v2f &a0, v2f &a1, v2f &a2, v2f &a3)
 {
@@ -428,9 +407,9 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
     const float2 *src = reinterpret_cast<const float2 *>(p.pcm) + (size_t)stream * p.frames_per_stream +
                         p.first_start + (size_t)w_begin * p.hop;
     const v2f *twn = reinterpret_cast<const v2f *>(p.tw_n);
-    v2f hw[8];                                                            // (w[t + 512 i], w[t + 512 i + 256])
+    float hw[16];
 #pragma unroll
-    for (int j = 0; j < 8; j++) hw[j] = v2f{p.half_window[t + 512 * j], p.half_window[t + 512 * j + 256]};
+    for (int j = 0; j < 16; j++) hw[j] = p.half_window[t + 256 * j];
     v2f tw1[16];
     if (TW6) {
         tw1[1] = twn[t]; tw1[2] = twn[2 * t]; tw1[3] = twn[3 * t];
@@ -444,21 +423,25 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
     const int tsw = SPEC_POS(t);
     const size_t out_win_stride = (size_t)2 * p.bin_stride;
     float *outp = p.out + ((size_t)stream * p.n_windows + w_begin) * out_win_stride;
-    v2f sd[16];                                                           // raw (l + r, l - r) of frame t + 256 j
+    float sm[16], df[16];
 #pragma unroll
-    for (int j = 0; j < 16; j++) sd[j] = pk_sum_diff(reinterpret_cast<const v2f *>(src)[t + 256 * j]);
+    for (int j = 0; j < 16; j++) {
+        const float2 v = src[t + 256 * j];
+        sm[j] = v.x + v.y;
+        df[j] = v.x - v.y;
+    }
     __syncthreads();
     for (uint32_t w = w_begin; w < w_end; ++w) {
-        v2f nx[HS];
+        float2 nx[HS];
         const bool more = (w + 1 < w_end);
 #pragma unroll
         for (int q = 0; q < HS; q++) {
-            nx[q] = v2f{0.f, 0.f};
-            if (more) nx[q] = reinterpret_cast<const v2f *>(src)[(size_t)(w + 1 - w_begin) * p.hop + t + 256 * (16 - HS + q)];
+            nx[q] = make_float2(0.f, 0.f);
+            if (more) nx[q] = src[(size_t)(w + 1 - w_begin) * p.hop + t + 256 * (16 - HS + q)];
         }
         v2f z[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) z[j] = (j & 1) ? pk_scale_hi(sd[j], hw[j >> 1]) : pk_scale_lo(sd[j], hw[j >> 1]);
+        for (int j = 0; j < 16; j++) z[j] = v2f{sm[j] * hw[j], df[j] * hw[j]};
         SS_PRIO_LO();
         fft16(z);
         SS_PRIO_HI();
@@ -500,9 +483,9 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
         fft4096_epilogue(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride);
         if (more) {
 #pragma unroll
-            for (int j = 0; j < 16 - HS; j++) sd[j] = sd[j + HS];
+            for (int j = 0; j < 16 - HS; j++) { sm[j] = sm[j + HS]; df[j] = df[j + HS]; }
 #pragma unroll
-            for (int q = 0; q < HS; q++) sd[16 - HS + q] = pk_sum_diff(nx[q]);
+            for (int q = 0; q < HS; q++) { sm[16 - HS + q] = nx[q].x + nx[q].y; df[16 - HS + q] = nx[q].x - nx[q].y; }
         }
         __syncthreads();
     }
@@ -945,6 +928,9 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
         // that lane l stores bins +4l..+4l+3 with one 16-byte store.  From one iteration to the next the bin
         // index grows by 1024: positions move by +-1024 (SPEC_POS only looks at bits 1 and 6), twiddles turn by W_16^1.
         float *o = p.out + (((size_t)stream * p.n_windows + w) * fft_ch + ch) * p.bin_stride;
+#if defined(SS_ABL16) && SS_ABL16 == 1      /* ablation (timing only): no epilogue at all */
+        if (t == 0) o[0] = xbuf2[0][w & 4095u].x + xbuf2[1][w & 4095u].y;
+#else
         {
             const uint32_t lane = (uint32_t)t & 63u, wv = (uint32_t)t >> 6;
             float *stg = stage[wv];
@@ -988,13 +974,19 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
                 const float4 v = reinterpret_cast<const float4 *>(stg)[lane];
                 __builtin_amdgcn_wave_barrier();
                 const uint32_t g = 256u * it + 64u * wv + lane;        // group of four bins this lane stores
+#if defined(SS_ABL16) && SS_ABL16 == 2      /* ablation (timing only): no output stores */
+                asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                (void)g; (void)o;
+#else
                 if (g < ngroups) {
                     float4 pk = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (p.pink) pk = *reinterpret_cast<const float4 *>(p.pink + 4u * g);
                     reinterpret_cast<float4 *>(o)[g] = make_float4(v.x + pk.x, v.y + pk.y, v.z + pk.z, v.w + pk.w);
                 }
+#endif
             }
         }
+#endif
         if (more) {
 #pragma unroll
             for (int j = 0; j < 15; j++) { raw0[j] = raw0[j + 1]; raw1[j] = raw1[j + 1]; }
