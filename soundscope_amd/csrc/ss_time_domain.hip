@@ -58,6 +58,19 @@ typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
 typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
 
 
+// Development build (-DSS_TD_PROF): per-phase shader-clock totals of k_time_domain, summed over all waves
+// (s_memtime at the phase boundaries of the tile loop; read back with ss_debug_td_prof).  Not in release builds.
+#ifdef SS_TD_PROF
+__device__ unsigned long long g_td_prof[16];
+#define SS_PROF_DECL uint64_t pt_ = __builtin_amdgcn_s_memtime(); uint64_t pacc_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define SS_PROF_MARK(i) do { const uint64_t n_ = __builtin_amdgcn_s_memtime(); pacc_[i] += n_ - pt_; pt_ = n_; } while (0)
+#define SS_PROF_END do { if (lane == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 9; i_++) atomicAdd(&g_td_prof[i_], (unsigned long long)pacc_[i_]); atomicAdd(&g_td_prof[15], 1ull); } } while (0)
+#else
+#define SS_PROF_DECL
+#define SS_PROF_MARK(i)
+#define SS_PROF_END
+#endif
+
 template <int FACTOR>
 struct TpCfg {
     static constexpr int HIST = (FACTOR == 2) ? 24 : 12;     // taps per polyphase branch
@@ -67,7 +80,10 @@ struct TpCfg {
     static constexpr int KSTEPS = (BLK + HIST - 1 + 3) / 4;  // 4 or 10
 };
 
-__device__ __forceinline__ void mat4_apply_add(const double *__restrict__ M, const double (&x)[4], double (&z)[4])
+// (the matrix pointer is in the CONSTANT address space: the tables are written once by the host before any launch, and a
+// uniform constant-space address makes the sixteen loads scalar (s_load into SGPRs, K$) instead of per-lane flat loads)
+typedef const __attribute__((address_space(4))) double *const_f64_ptr;
+__device__ __forceinline__ void mat4_apply_add(const_f64_ptr M, const double (&x)[4], double (&z)[4])
 {
 #pragma unroll
     for (int r = 0; r < 4; r++)
@@ -363,11 +379,12 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
     uint32_t slot = (uint32_t)(sb % p.sub_cap);         // where the current sub-block's energies go (ring of sub_cap)
     SS_TILE_FRAMES(pos, off, toff, seg);
     SS_PREFETCH(pos, seg);
+    SS_PROF_DECL
 
     while (seg != 0) {
         // keep the scan matrices in memory (scalar loads at the point of use): hoisting all of them
         // out of the tile loop would cost 224 SGPRs
-        const double *mpow = &K.m_pow[0][0];
+        const_f64_ptr mpow = (const_f64_ptr)(uintptr_t)&K.m_pow[0][0];
         asm volatile("" : "+s"(mpow));
         const bool warm = pos < seg_begin;              // run-in tile: filter only
         const uint32_t nchunks = (seg + L - 1) / L;
@@ -404,6 +421,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
         SS_PREFETCH(npos, nseg_frames);
 #endif
         __builtin_amdgcn_wave_barrier();               // LDS is in-order per wave: only ordering is needed
+        SS_PROF_MARK(0);
 
         // ---- min-max decimation of the bins that END inside this tile (analyzer.rs:107-137): bin i =
         // [floor(i*spp), min(ceil((i+1)*spp), len)), the same f64 expressions as the reference; 16 lanes
@@ -498,6 +516,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
             }
         }
 
+        SS_PROF_MARK(1);
         const bool active = lane_ok && chunk < nchunks;
         const uint32_t len = active ? ((seg - chunk * L) < L ? (seg - chunk * L) : L) : 0u;
         const float *xs = tile + (size_t)chunk * L * C + ch;
@@ -525,6 +544,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
             z[0] = v1; z[1] = v2; z[2] = v3; z[3] = v4;
             if (active && chunk == 0) mat4_apply_add(mpow, cv, z);
         }
+        SS_PROF_MARK(2);
         // ---- in-wave scan over chunks: z_i += (A^L)^(2^k) z_{i - 2^k}  (the steps commute: powers of one matrix)
 #ifndef SS_ABL_SCAN_FROM
 #define SS_ABL_SCAN_FROM 0
@@ -572,6 +592,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
             v1 = first ? cv[0] : p0; v2 = first ? cv[1] : p1; v3 = first ? cv[2] : p2; v4 = first ? cv[3] : p3;
         }
 
+        SS_PROF_MARK(3);
         // ---- pass 2: true-state rerun + energy + sample peak
         float sp = 0.0f;                                // this lane's max |x| over its chunk (also steers the true-peak path)
         {
@@ -622,6 +643,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
         // still covers their latency.
         SS_PREFETCH(npos, nseg_frames);
 #endif
+        SS_PROF_MARK(4);
         // ---- true peak on the matrix pipe (not during the run-in)
         bool halo_done = false;
         const uint32_t tp_now_bits = kTpPlanar ? wave_max_nonneg_bits(sp) : 0u;      // this tile's sample peak, wave-uniform
@@ -756,6 +778,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
                     };
                     const uint32_t jb = 4u * ((uint32_t)mrow / C);
                     auto ld4 = [](const char *q, int off) -> halfx4 { return __builtin_bit_cast(halfx4, *reinterpret_cast<const uint2 *>(q + off)); };
+                    SS_PROF_MARK(5);
                     float m16 = 0.0f;
 #if SS_TP_K32
                     const uint32_t j32 = jb + 8u * ((uint32_t)kq & 1u);
@@ -872,6 +895,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
                 }
             }
         }
+        SS_PROF_MARK(6);
         if (kTpPlanar) tp_prev_bits = seg >= 12u ? tp_now_bits : (tp_now_bits > tp_prev_bits ? tp_now_bits : tp_prev_bits);
 
         // carry-out: exact state after the last valid sample, to the lanes of the channel (chunk 0's lane consumes it)
@@ -924,7 +948,9 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
         off = noff;
         toff = ntoff;
         seg = nseg_frames;
+        SS_PROF_MARK(7);
     }
+    SS_PROF_END;
 
     // ---- fold this wave's results into the stream state
     // energy of the trailing incomplete sub-block: reduce the lanes' shares (streaming calls carry it over)
@@ -1079,3 +1105,17 @@ hipError_t launch_time_domain(const TdParams &p, hipStream_t s)
 }
 
 }  // namespace ssk
+
+#ifdef SS_TD_PROF
+// development builds only: [0..7] phase clocks (stage, decimate, pass 1, scan, pass 2, tp convert (+ f32 remainder), tp product,
+// tile tail), [15] waves counted; reset != 0 clears the totals after reading
+extern "C" int ss_debug_td_prof(unsigned long long *out16, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(ssk::g_td_prof), 16 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        const unsigned long long z[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(ssk::g_td_prof), z, sizeof z);
+    }
+    return e == hipSuccess ? 0 : -1;
+}
+#endif
