@@ -743,30 +743,48 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
                     const float *rbase = tile + ((int)(half * FB + 2u * fpl) - 12) * (int)C + (int)cc;    // round 0; + 128 floats per round
                     uint32_t *wbase = reinterpret_cast<uint32_t *>(tile) + half * 64u + cc * (FB >> 1) + fpl;   // hi pair; lo: + 32
                     const bool saver = half * FB + 2u * fpl < 12u;         // this lane saved its round-0 pair from the old halo (lane < 6 C)
-                    for (int top = nround; top > 0; top -= 4) {
+                    // (hi, hi) = f16(s x0), f16(s x1);  (lo, lo) = f16(s x - hi): four v_fma_mix
+                    auto split2 = [&](float xa, float xb, uint32_t &hh, uint32_t &ll) {
+                        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hh) : "v"(xa), "s"(scale));
+                        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hh) : "v"(xb), "s"(scale));
+                        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ll) : "v"(xa), "s"(scale), "v"(hh));
+                        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ll) : "v"(xb), "s"(scale), "v"(hh));
+                    };
+                    // The top round (its upper block may not exist) and round 0 (whose first pairs come from the saved halo)
+                    // are peeled off, so the rounds in between run without predicates or selects.
+                    int rd = nround - 1;
+                    const float *rp = rbase + rd * 128;
+                    uint32_t *wp = wbase + rd * 128;
+                    if (rd > 0) {
+                        uint32_t hh, ll;
+                        split2(rp[0], rp[(int)C], hh, ll);
+                        if (top_ok) { wp[0] = hh; wp[32] = ll; }
+                        rd--; rp -= 128; wp -= 128;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    for (; rd >= 4; rd -= 4, rp -= 512, wp -= 512) {        // rounds rd .. rd - 3, all >= 1
                         float x0[4], x1[4];
 #pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            int rd = top - 1 - u;
-                            rd = rd < 0 ? 0 : rd;                          // wave-uniform; a repeated round 0 rewrites the same values
-                            x0[u] = rbase[rd * 128]; x1[u] = rbase[rd * 128 + (int)C];
-                            if (rd == 0) { x0[u] = saver ? s0 : x0[u]; x1[u] = saver ? s1 : x1[u]; }
-                        }
+                        for (int u = 0; u < 4; u++) { x0[u] = rp[-128 * u]; x1[u] = rp[-128 * u + (int)C]; }
 #pragma unroll
                         for (int u = 0; u < 4; u++) {
-                            int rd = top - 1 - u;
-                            rd = rd < 0 ? 0 : rd;
-                            // (hi, hi) = f16(s x0), f16(s x1);  (lo, lo) = f16(s x - hi): four v_fma_mix
                             uint32_t hh, ll;
-                            asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hh) : "v"(x0[u]), "s"(scale));
-                            asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hh) : "v"(x1[u]), "s"(scale));
-                            asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ll) : "v"(x0[u]), "s"(scale), "v"(hh));
-                            asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ll) : "v"(x1[u]), "s"(scale), "v"(hh));
-                            if (rd != nround - 1 || top_ok) {
-                                wbase[rd * 128] = hh;
-                                wbase[rd * 128 + 32] = ll;
-                            }
+                            split2(x0[u], x1[u], hh, ll);
+                            wp[-128 * u] = hh;
+                            wp[-128 * u + 32] = ll;
                         }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    for (; rd >= 1; rd--, rp -= 128, wp -= 128) {           // up to three rounds left above round 0
+                        uint32_t hh, ll;
+                        split2(rp[0], rp[(int)C], hh, ll);
+                        wp[0] = hh; wp[32] = ll;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    {                                                       // round 0
+                        uint32_t hh, ll;
+                        split2(saver ? s0 : rbase[0], saver ? s1 : rbase[(int)C], hh, ll);
+                        if (nround > 1 || top_ok) { wbase[0] = hh; wbase[32] = ll; }
                         __builtin_amdgcn_wave_barrier();
                     }
                     // (4) column (channel tp_c, block of outputs b = 16/C g + mrow / C) reads its window [4 b, 4 b + 16) of
