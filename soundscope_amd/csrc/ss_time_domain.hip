@@ -443,27 +443,49 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
                     float mn = __builtin_nanf(""), mx = __builtin_nanf("");
                     if (valid) {
                         const float4 *bp4 = reinterpret_cast<const float4 *>(tile + ((int)bs - (int)t0));   // may reach into the halo
+                        // three reads cover spp <= 96 (48 kHz stereo), a fourth spp <= 128; clamped indices repeat an element,
+                        // which cannot change a min / max.  All reads are issued before the arithmetic.
+                        float4 v[3];
 #pragma unroll
-                        for (int it = 0; it < 4; it++) {                              // spp <= 128: four clamped reads cover a bin
+                        for (int it = 0; it < 3; it++) {
                             uint32_t j = lane8 + 8u * it;
                             j = j < n4 ? j : n4 - 1;
-                            const float4 v = bp4[j];
-                            mn = fminf(fminf(mn, v.x), fminf(fminf(v.y, v.z), v.w));
-                            mx = fmaxf(fmaxf(mx, v.x), fmaxf(fmaxf(v.y, v.z), v.w));
+                            v[it] = bp4[j];
+                        }
+#if defined(__HIP_DEVICE_COMPILE__)
+                        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+                        for (int it = 0; it < 3; it++) {
+                            mn = fminf(fminf(mn, v[it].x), fminf(fminf(v[it].y, v[it].z), v[it].w));
+                            mx = fmaxf(fmaxf(mx, v[it].x), fmaxf(fmaxf(v[it].y, v[it].z), v[it].w));
+                        }
+                        if (n4 > 24u) {                                                // wave-uniform
+                            const float4 w = bp4[lane8 + 24u < n4 ? lane8 + 24u : n4 - 1];
+                            mn = fminf(fminf(mn, w.x), fminf(fminf(w.y, w.z), w.w));
+                            mx = fmaxf(fmaxf(mx, w.x), fmaxf(fmaxf(w.y, w.z), w.w));
                         }
                         if (WAVE == 3)                                                 // longer bins (192 at 96 kHz stereo)
                             for (uint32_t j = lane8 + 32u; j < n4; j += 8u) {
-                                const float4 v = bp4[j];
-                                mn = fminf(fminf(mn, v.x), fminf(fminf(v.y, v.z), v.w));
-                                mx = fmaxf(fmaxf(mx, v.x), fmaxf(fmaxf(v.y, v.z), v.w));
+                                const float4 w = bp4[j];
+                                mn = fminf(fminf(mn, w.x), fminf(fminf(w.y, w.z), w.w));
+                                mx = fmaxf(fmaxf(mx, w.x), fmaxf(fmaxf(w.y, w.z), w.w));
                             }
                     }
-                    // 8-lane all-reduce: xor 1, xor 2 (quad_perm), then the mirror inside each half row
-#define SS_DPP(x, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), (ctrl), 0xF, 0xF, false))
-                    mn = fminf(mn, SS_DPP(mn, 0xB1)); mx = fmaxf(mx, SS_DPP(mx, 0xB1));
-                    mn = fminf(mn, SS_DPP(mn, 0x4E)); mx = fmaxf(mx, SS_DPP(mx, 0x4E));
-                    mn = fminf(mn, SS_DPP(mn, 0x141)); mx = fmaxf(mx, SS_DPP(mx, 0x141));
-#undef SS_DPP
+                    // 8-lane all-reduce: xor 1, xor 2 (quad_perm), then the mirror inside each half row.  DPP on the
+                    // operand of v_min / v_max itself (IEEE minNum / maxNum: a NaN partner is ignored, an all-NaN bin stays NaN);
+                    // written out because the builtin route costs four instructions per step and value.  The s_nop keep the
+                    // two wait states a DPP read needs after a VALU write of the same register.
+                    asm volatile("s_nop 1\n\t"
+                                 "v_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                                 "s_nop 0\n\t"
+                                 "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                                 "s_nop 0\n\t"
+                                 "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf"
+                                 : "+v"(mn), "+v"(mx));
                     if (valid && lane8 == 0) {
                         float2 *o = reinterpret_cast<float2 *>(p.wave_out + (size_t)stream * p.wave_stride) + i;
                         *o = make_float2(mn, mx);
