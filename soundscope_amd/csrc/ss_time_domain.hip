@@ -397,10 +397,13 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
             if ((reinterpret_cast<uintptr_t>(g) & 15u) == 0) {
                 const uint32_t nv = total >> 2;
                 float4 *t4 = reinterpret_cast<float4 *>(tile);
+                // no predicate: a lane past the tile's end holds a copy of the last float4 (clamped prefetch index) and writes
+                // it where it belongs — the same value to the same place, without exec-mask branches
+                const uint32_t last = nv ? nv - 1u : 0u;
 #pragma unroll
                 for (int q = 0; q < kTdPrefetch; q++) {
                     const uint32_t i = lane + 64u * q;
-                    if (i < nv) t4[i] = pf[q];
+                    if (nv) t4[i < last ? i : last] = pf[q];               // (nv is wave-uniform)
                 }
                 const float4 *g4 = reinterpret_cast<const float4 *>(g);
                 for (uint32_t i = lane + 64u * kTdPrefetch; i < nv; i += 64u) t4[i] = g4[i];

@@ -310,3 +310,33 @@ def test_batch_true_peak_other_channel_counts(oracle, channels, rate, frames):
             assert rel_close(tp[c], max(m.true_peak(c), m.sample_peak(c))), (i, c, tp[c], m.true_peak(c))
             assert sp[c] == m.sample_peak(c)
         assert lufs_close(res[i].integrated_lufs, m.integrated())
+
+
+@pytest.mark.parametrize("rate,channels", [(48000, 2), (96000, 2), (44100, 2), (48000, 1)])
+def test_fused_decimation_nan_semantics(oracle, rate, channels):
+    """Min-max decimation fused into the time-domain kernel (the batch path; integer samples-per-bin fast paths at
+    48 / 96 kHz stereo, the general path otherwise) keeps f32::min / f32::max semantics (analyzer.rs:107-137): NaN
+    samples are ignored, a bin of nothing but NaN stays NaN, +-inf and signed zeros pass through — bit for bit."""
+    frames = rate * 2
+    rng = np.random.default_rng(77)
+    xs = []
+    for i in range(3):
+        x = (rng.standard_normal(frames * channels) * 0.1).astype(np.float32)
+        spp = frames * channels // 2000
+        x[spp * 10: spp * 11] = np.nan                    # exactly bin 10 when spp is an integer
+        x[spp * 50 + 3: spp * 53 + 1] = np.nan            # a run across three bins
+        x[spp * 100 + 1] = np.nan
+        x[spp * 200] = np.inf
+        x[spp * 300 + 5] = -np.inf
+        x[spp * 400: spp * 401] = -0.0
+        x[-5:] = np.nan                                   # the tail of the last bin
+        xs.append(x)
+    b = ssa.Batch(rate, channels, 3, frames, 4096, 1024, flags=L.SS_BATCH_WAVEFORM | L.SS_BATCH_LUFS)
+    b.upload(0, np.concatenate(xs)); b.run(); b.sync()
+    for i, x in enumerate(xs):
+        ref = oracle.get_waveform(x, frames / rate)[:, 1].astype(np.float32)
+        got = b.waveform(i).reshape(-1)
+        assert got.shape == ref.shape
+        assert np.array_equal(got.view(np.uint32)[~np.isnan(ref)], ref.view(np.uint32)[~np.isnan(ref)]), i
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), i
+        assert np.isnan(ref).any()
