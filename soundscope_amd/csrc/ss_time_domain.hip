@@ -894,8 +894,25 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
                                 for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_hi, l[g], acc[g], 0, 0, 0);
 #pragma unroll
                                 for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_lo, h[g], acc[g], 0, 0, 0);
+                                // max |.| of the sixteen results: v_max3 with |abs| source modifiers, eight instructions (through the
+                                // fmaxf / fabsf builtins the compiler quiets every operand first: seventeen).  The s_nop are the six
+                                // wait states a VALU read needs behind a four-pass MFMA write, which inline asm hides from the compiler.
+                                asm volatile("s_nop 5\n\t"
+                                             "v_max3_f32 %0, %0, |%1|, |%2|\n\t"
+                                             "v_max3_f32 %0, %0, |%3|, |%4|\n\t"
+                                             "v_max3_f32 %0, %0, |%5|, |%6|\n\t"
+                                             "v_max3_f32 %0, %0, |%7|, |%8|\n\t"
+                                             "v_max3_f32 %0, %0, |%9|, |%10|\n\t"
+                                             "v_max3_f32 %0, %0, |%11|, |%12|\n\t"
+                                             "v_max3_f32 %0, %0, |%13|, |%14|\n\t"
+                                             "v_max3_f32 %0, %0, |%15|, |%16|"
+                                             : "+v"(m16)
+                                             : "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[0][2]), "v"(acc[0][3]),
+                                               "v"(acc[1][0]), "v"(acc[1][1]), "v"(acc[1][2]), "v"(acc[1][3]),
+                                               "v"(acc[2][0]), "v"(acc[2][1]), "v"(acc[2][2]), "v"(acc[2][3]),
+                                               "v"(acc[3][0]), "v"(acc[3][1]), "v"(acc[3][2]), "v"(acc[3][3]));
 #pragma unroll
-                                for (int g = 0; g < 4; g++) { m16 = absmax4(m16, acc[g]); h[g] = hn[g]; l[g] = ln[g]; }
+                                for (int g = 0; g < 4; g++) { h[g] = hn[g]; l[g] = ln[g]; }
                             }
                             ph += 1024;
                         }
