@@ -166,16 +166,28 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
     // dB = 10 log10(2) * log2(q) + (db_offset + pink[bin]); an exact zero reads -150 (+ pink): the log operand is
     // replaced by the value that lands on -150.  Exact zeros are rare (digital silence), so the wave first asks whether
     // any of its squared magnitudes is zero (a min tree and one compare) and only then pays the per-value selects.
+    //
+    // Memory order: every load of the window (both groups' table rows here; the caller's prefetched samples before the
+    // call) is consumed before the first store is issued.  Loads and stores share vmcnt and may complete out of order
+    // with each other, so a load waited for behind a store costs s_waitcnt vmcnt(0), i.e. the stores' completion.  In the
+    // per-phase clock profile (-DSS_FFT_PROF) this order takes a fifth off the epilogue's wave time; the kernel time does
+    // not move (the other two workgroups of the CU cover the wait), it is kept because it also frees two spilled registers.
     constexpr float kDb = 3.01029995663981195f;
     const float lg0 = (-150.0f - db_offset) / kDb;
+    float4 op[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const uint32_t g = (uint32_t)t + 256u * i;
+        op[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g < ngroups) op[i] = *reinterpret_cast<const float4 *>(offpink + 4 * g);   // table padded to the row stride
+    }
+    float rm[2][4], rs[2][4];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         const uint32_t g = (uint32_t)t + 256u * i;
         if (g < ngroups) {
             const uint32_t k0 = first_bin + 4 * g;
-            const float4 op = *reinterpret_cast<const float4 *>(offpink + 4 * g);   // table padded to the row stride
-            const float opv[4] = {op.x, op.y, op.z, op.w};
-            float qm[4], qs[4], rm[4], rs[4];
+            float qm[4], qs[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const uint32_t k = k0 + e;                       // k <= 2051 < 4096: the mirror index stays positive
@@ -187,31 +199,44 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
                 qm[e] = fmaf(m2.x, m2.x, m2.y * m2.y);
                 qs[e] = fmaf(s2.x, s2.x, s2.y * s2.y);
             }
+            const float opv[4] = {op[i].x, op[i].y, op[i].z, op[i].w};
             const float qmin = fminf(fminf(fminf(qm[0], qm[1]), fminf(qm[2], qm[3])), fminf(fminf(qs[0], qs[1]), fminf(qs[2], qs[3])));
             if (__builtin_expect(__ballot(qmin == 0.0f) == 0ull, 1)) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    rm[e] = fmaf(__log2f(qm[e]), kDb, opv[e]);
-                    rs[e] = fmaf(__log2f(qs[e]), kDb, opv[e]);
+                    rm[i][e] = fmaf(__log2f(qm[e]), kDb, opv[e]);
+                    rs[i][e] = fmaf(__log2f(qs[e]), kDb, opv[e]);
                 }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    rm[e] = fmaf(qm[e] == 0.0f ? lg0 : __log2f(qm[e]), kDb, opv[e]);
-                    rs[e] = fmaf(qs[e] == 0.0f ? lg0 : __log2f(qs[e]), kDb, opv[e]);
+                    rm[i][e] = fmaf(qm[e] == 0.0f ? lg0 : __log2f(qm[e]), kDb, opv[e]);
+                    rs[i][e] = fmaf(qs[e] == 0.0f ? lg0 : __log2f(qs[e]), kDb, opv[e]);
                 }
             }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) { rm[i][e] = 0.0f; rs[i][e] = 0.0f; }
+        }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);          // the stores stay behind everything above
+#endif
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const uint32_t g = (uint32_t)t + 256u * i;
+        if (g < ngroups) {
 #if defined(SS_ABL) && SS_ABL == 1      /* ablation: no output stores */
-            asm volatile("" ::"v"(rm[0]), "v"(rm[1]), "v"(rm[2]), "v"(rm[3]), "v"(rs[0]), "v"(rs[1]), "v"(rs[2]), "v"(rs[3]));
+            asm volatile("" ::"v"(rm[i][0]), "v"(rm[i][1]), "v"(rm[i][2]), "v"(rm[i][3]), "v"(rs[i][0]), "v"(rs[i][1]), "v"(rs[i][2]), "v"(rs[i][3]));
             (void)o_mid; (void)o_side;
 #else
 #if SS_FFT_NT_STORE
             typedef float f4v __attribute__((ext_vector_type(4)));
-            __builtin_nontemporal_store(f4v{rm[0], rm[1], rm[2], rm[3]}, reinterpret_cast<f4v *>(o_mid) + g);
-            if (store_side) __builtin_nontemporal_store(f4v{rs[0], rs[1], rs[2], rs[3]}, reinterpret_cast<f4v *>(o_side) + g);
+            __builtin_nontemporal_store(f4v{rm[i][0], rm[i][1], rm[i][2], rm[i][3]}, reinterpret_cast<f4v *>(o_mid) + g);
+            if (store_side) __builtin_nontemporal_store(f4v{rs[i][0], rs[i][1], rs[i][2], rs[i][3]}, reinterpret_cast<f4v *>(o_side) + g);
 #else
-            reinterpret_cast<float4 *>(o_mid)[g] = make_float4(rm[0], rm[1], rm[2], rm[3]);
-            if (store_side) reinterpret_cast<float4 *>(o_side)[g] = make_float4(rs[0], rs[1], rs[2], rs[3]);
+            reinterpret_cast<float4 *>(o_mid)[g] = make_float4(rm[i][0], rm[i][1], rm[i][2], rm[i][3]);
+            if (store_side) reinterpret_cast<float4 *>(o_side)[g] = make_float4(rs[i][0], rs[i][1], rs[i][2], rs[i][3]);
 #endif
 #endif
         }
@@ -388,6 +413,17 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
 #else
 #define SS_PRIO_EPI() SS_PRIO_LO()
 #endif
+// Development build (-DSS_FFT_PROF): per-phase shader-clock totals of k_fft4096_ms1 over all waves (tools/probe_fft_phases.py)
+#ifdef SS_FFT_PROF
+__device__ unsigned long long g_fft_prof[16];
+#define SS_FPROF_DECL uint64_t pt_ = __builtin_amdgcn_s_memtime(); uint64_t pacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define SS_FPROF_MARK(i) do { const uint64_t n_ = __builtin_amdgcn_s_memtime(); pacc_[i] += n_ - pt_; pt_ = n_; } while (0)
+#define SS_FPROF_END do { if ((threadIdx.x & 63) == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 12; i_++) atomicAdd(&g_fft_prof[i_], (unsigned long long)pacc_[i_]); atomicAdd(&g_fft_prof[15], 1ull); } } while (0)
+#else
+#define SS_FPROF_DECL
+#define SS_FPROF_MARK(i)
+#define SS_FPROF_END
+#endif
 template <int HS, bool TW6>
 __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchParams p)
 {
@@ -431,6 +467,7 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
         df[j] = v.x - v.y;
     }
     __syncthreads();
+    SS_FPROF_DECL
     for (uint32_t w = w_begin; w < w_end; ++w) {
         float2 nx[HS];
         const bool more = (w + 1 < w_end);
@@ -457,38 +494,52 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
             }
             xbuf[X1W(ka, tb, hi)] = v;
         }
+        SS_FPROF_MARK(0);
         __syncthreads();
+        SS_FPROF_MARK(1);
 #pragma unroll
         for (int ta = 0; ta < 16; ta++) z[ta] = xbuf[X1W(hi, tb, ta)];
+        SS_FPROF_MARK(2);
         __syncthreads();
+        SS_FPROF_MARK(3);
         SS_PRIO_LO();
         fft16(z);
         SS_PRIO_HI();
         xbuf[X2W(0, hi, tb)] = z[R16(0)];
 #pragma unroll
         for (int kb = 1; kb < 16; kb++) xbuf[X2W(kb, hi, tb)] = pk_cmul(z[R16(kb)], tw2s[tb * kb]);
+        SS_FPROF_MARK(4);
         __syncthreads();
+        SS_FPROF_MARK(5);
 #pragma unroll
         for (int q = 0; q < 16; q++) z[q] = xbuf[X2W(hi, tb, q)];
+        SS_FPROF_MARK(6);
         __syncthreads();
+        SS_FPROF_MARK(7);
         SS_PRIO_LO();
         fft16(z);
         SS_PRIO_HI();
 #pragma unroll
         for (int kc = 0; kc < 16; kc++)
             if ((p.publish_mask >> kc) & 1u) xbuf[kc * 256 + tsw] = z[R16(kc)];   // blocks with no retained bin or mirror are skipped
+        SS_FPROF_MARK(8);
         __syncthreads();
+        SS_FPROF_MARK(9);
         SS_PRIO_EPI();
-        float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
-        fft4096_epilogue(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride);
+        // the sliding registers take the prefetched hop before the epilogue's stores (see fft4096_epilogue)
         if (more) {
 #pragma unroll
             for (int j = 0; j < 16 - HS; j++) { sm[j] = sm[j + HS]; df[j] = df[j + HS]; }
 #pragma unroll
             for (int q = 0; q < HS; q++) { sm[16 - HS + q] = nx[q].x + nx[q].y; df[16 - HS + q] = nx[q].x - nx[q].y; }
         }
+        float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
+        fft4096_epilogue(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride);
+        SS_FPROF_MARK(10);
         __syncthreads();
+        SS_FPROF_MARK(11);
     }
+    SS_FPROF_END;
 #undef X1W
 #undef X2W
 }
@@ -1147,3 +1198,16 @@ hipError_t launch_fft_generic(const FftBatchParams &p, int mode, hipStream_t s)
 }
 
 }  // namespace ssk
+
+#ifdef SS_FFT_PROF
+// development builds only: [0..11] phase clocks of k_fft4096_ms1 (compute / barrier alternating), [15] waves counted
+extern "C" int ss_debug_fft_prof(unsigned long long *out16, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(ssk::g_fft_prof), 16 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        const unsigned long long z[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(ssk::g_fft_prof), z, sizeof z);
+    }
+    return e == hipSuccess ? 0 : -1;
+}
+#endif
