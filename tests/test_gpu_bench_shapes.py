@@ -340,3 +340,68 @@ def test_fused_decimation_nan_semantics(oracle, rate, channels):
         assert np.array_equal(got.view(np.uint32)[~np.isnan(ref)], ref.view(np.uint32)[~np.isnan(ref)]), i
         assert np.array_equal(np.isnan(got), np.isnan(ref)), i
         assert np.isnan(ref).any()
+
+
+def test_config4_full_size_equals_its_eight_shards(oracle):
+    """BASELINE config 4 at its full size on ONE GPU (8192 synthetic streams x 10 s x 48 kHz stereo: 31.5 GB of input,
+    52 GB of spectra) against the way eight ranks would compute it: eight 1024-stream shards with the stream ids of
+    `shard_streams(8192, r, 8)`.  Size-independent properties of the sharding: the corpus histograms of the big batch
+    are exactly the sum of the shards' histograms (the all-reduce's result), so the corpus gate and LRA agree exactly;
+    every stream's loudness, range and peaks are the same in either batch although the launch geometry differs
+    (spectrum workgroups per stream, time segments per stream: asserted to differ); three streams of the big batch
+    — first, one in the middle of a shard, last — are checked against the oracle in full."""
+    from soundscope_amd.distributed import shard_streams, corpus_gate
+    rate, frames, total, world = 48000, 480000, 8192, 8
+    try:
+        big = ssa.Batch(rate, 2, total, frames, 4096, 1024, flags=L.SS_BATCH_ALL)
+    except Exception as e:                              # a GPU with less free memory than the 85 GB this shape needs
+        pytest.skip(f"config 4 does not fit this device: {e}")
+    big.synthesize(0x5EED0000, 0)
+    big.run(); big.sync()
+    gb = big.geometry
+    rb = big.results()
+    big_res = [(r.integrated_lufs, r.loudness_range, r.true_peak[0], r.true_peak[1], r.sample_peak[0], r.sample_peak[1]) for r in rb]
+    hb_big, hs_big = big.histograms()
+    picks = [0, 4097, total - 1]
+    xs = {i: big.download_input(i) for i in picks}
+    ffts = {i: big.fft(i) for i in picks}
+    waves = {i: big.waveform(i).reshape(-1).copy() for i in picks}
+    big.close()
+
+    hb_sum, hs_sum = np.zeros(1000, np.uint64), np.zeros(1000, np.uint64)
+    shard_geo = None
+    for r in range(world):
+        first, count = shard_streams(total, r, world)
+        assert (first, count) == (1024 * r, 1024)
+        b = ssa.Batch(rate, 2, count, frames, 4096, 1024, flags=L.SS_BATCH_ALL)
+        b.synthesize(0x5EED0000, first)
+        b.run(); b.sync()
+        shard_geo = b.geometry
+        hb, hs = b.histograms()
+        hb_sum += hb; hs_sum += hs
+        res = b.results()
+        for i in range(count):
+            got = (res[i].integrated_lufs, res[i].loudness_range, res[i].true_peak[0], res[i].true_peak[1],
+                   res[i].sample_peak[0], res[i].sample_peak[1])
+            want = big_res[first + i]
+            assert lufs_close(got[0], want[0], 1e-9) and abs(got[1] - want[1]) <= 1e-9, (r, i, got, want)
+            assert got[4:] == want[4:] and rel_close(got[2], want[2], 1e-6) and rel_close(got[3], want[3], 1e-6), (r, i, got, want)
+        if r == 0:
+            assert np.array_equal(b.download_input(0), xs[0])           # same stream ids -> same synthetic samples
+        b.close()
+    assert (gb.td_segments, gb.fft_windows_per_block) != (shard_geo.td_segments, shard_geo.fft_windows_per_block)
+    assert np.array_equal(hb_big, hb_sum) and np.array_equal(hs_big, hs_sum)
+    assert corpus_gate(np.concatenate([hb_big, hs_big])) == corpus_gate(np.concatenate([hb_sum, hs_sum]))
+    assert int(hb_big.sum()) > 0
+
+    with ThreadPoolExecutor(_threads()) as ex:
+        refs = dict(zip(picks, ex.map(lambda i: oracle.analyze_stream(rate, xs[i], 4096, 1024), picks)))
+    for i in picks:
+        ref = refs[i]
+        for w in range(464):
+            for c in range(2):
+                assert db_close(ffts[i][w, c], ref["fft"][w, c], TOL_DB), (i, w, c)
+        assert lufs_close(big_res[i][0], ref["integrated"]) and abs(big_res[i][1] - ref["lra"]) <= TOL_DB
+        for c in range(2):
+            assert rel_close(big_res[i][2 + c], ref["true_peak"][c]) and big_res[i][4 + c] == ref["sample_peak"][c]
+        assert np.array_equal(waves[i], ref["wave"][:, 1].astype(np.float32)), i
