@@ -67,20 +67,43 @@ __device__ void eval_hist(const unsigned long long *hb, const unsigned long long
         uint32_t index;
         if (integ < bd[0]) index = 0;
         else { index = hist_index(bd, integ); if (integ > en[index]) index++; }
-        unsigned long long above = 0;
-        for (int i = lane; i < kHistBins; i += 64) if ((uint32_t)i >= index) above += hs[i];
-        above = wave_sum_u64(above);
-        if (above != 0 && lane == 0) {
+        // Percentile bins without a serial walk over the histogram: lane l owns bins [16 l, 16 l + 16), an inclusive scan
+        // over the lanes' gated counts tells which lane holds an entry of a given rank, and that lane walks its own 16
+        // bins.  (ebur128 walks all bins from the gate: `while acc <= rank { acc += hist[j]; j += 1 }`, entry = bin j - 1,
+        // i.e. the first bin at which the cumulative gated count exceeds the rank.)
+        const int b0 = lane * 16;
+        unsigned long long own = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int i = b0 + ((q + lane) & 15);                    // rotated start: spreads the lanes over the LDS banks
+            if (i < kHistBins && (uint32_t)i >= index) own += hs[i];
+        }
+        unsigned long long incl = own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        const unsigned long long above = __shfl(incl, 63, 64);
+        if (above != 0) {
             const unsigned long long plow = (unsigned long long)((double)(above - 1) * 0.1 + 0.5);
             const unsigned long long phigh = (unsigned long long)((double)(above - 1) * 0.95 + 0.5);
-            unsigned long long acc = 0; uint32_t j = index;
-            while (acc <= plow) acc += hs[j++];
-            const double l_en = en[j - 1];
-            while (acc <= phigh) acc += hs[j++];
-            const double h_en = en[j - 1];
+            const unsigned long long excl = incl - own;
+            auto energy_of_rank = [&](unsigned long long r) -> double {
+                const bool mine = excl <= r && r < incl;             // exactly one lane (ranks are < above)
+                double e = 0.0;
+                if (mine) {
+                    unsigned long long acc = excl;
+                    int j = b0 > (int)index ? b0 : (int)index;
+                    for (;;) { acc += hs[j]; if (acc > r) break; j++; }
+                    e = en[j];
+                }
+                const int src = __ffsll((long long)__ballot(mine)) - 1;
+                return __shfl(e, src, 64);
+            };
+            const double l_en = energy_of_rank(plow), h_en = energy_of_rank(phigh);
             lra = (10.0 * log10(h_en) - 0.691) - (10.0 * log10(l_en) - 0.691);
         }
-        lra = __shfl(lra, 0, 64);
     }
     if (lane == 0) { if (out_i) *out_i = integrated; if (out_lra) *out_lra = lra; }
 }
