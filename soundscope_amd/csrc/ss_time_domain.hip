@@ -1063,13 +1063,16 @@ uint32_t td_chunk_frames(uint32_t C, uint32_t s100)
     return best;
 }
 
+#ifndef SS_TD_FULL_TILES
+#define SS_TD_FULL_TILES 0      // 1: tiles of the full scan width and a short last one per sub-block instead of equal pieces (experiment)
+#endif
 // waves of k_time_domain one CU holds at once (LDS per wave grows with the channel count and the decimation halo)
 uint32_t td_resident_waves_per_cu(uint32_t C, uint32_t s100, uint32_t halo_frames)
 {
     const uint32_t L = td_chunk_frames(C, s100);
     const uint32_t cap = (64u / C) * L;
     const uint32_t pieces = (s100 + cap - 1) / cap;
-    uint32_t tile_len = (s100 + pieces - 1) / pieces;
+    uint32_t tile_len = SS_TD_FULL_TILES ? cap : (s100 + pieces - 1) / pieces;
     if (tile_len > cap) tile_len = cap;
     const uint32_t halo = halo_frames ? halo_frames : (uint32_t)kTdHaloFrames;
     uint32_t wave_floats = (halo + tile_len) * C + td_slack_floats(C) + kMaxChannels;
@@ -1091,7 +1094,7 @@ static hipError_t td_launch(const TdParams &p, hipStream_t s)
     const uint32_t nch = 64u / C;
     const uint32_t cap = nch * L;                                   // frames one wave can scan at once
     const uint32_t pieces = (S + cap - 1) / cap;                    // equal tiles per sub-block
-    uint32_t tile_len = (S + pieces - 1) / pieces;
+    uint32_t tile_len = SS_TD_FULL_TILES ? cap : (S + pieces - 1) / pieces;
     if (tile_len > cap) tile_len = cap;
     // per-wave LDS: halo + tile + slack + 64 peak slots
     const uint32_t halo = WAVE ? p.halo_frames : (uint32_t)kTdHaloFrames;
@@ -1124,7 +1127,7 @@ static int td_wave_int4(const TdParams &p)
     const uint32_t L = td_chunk_frames(C, S);
     const uint32_t cap = (64u / C) * L;
     const uint32_t pieces = (S + cap - 1) / cap;
-    uint32_t tile_len = (S + pieces - 1) / pieces;
+    uint32_t tile_len = SS_TD_FULL_TILES ? cap : (S + pieces - 1) / pieces;
     if (tile_len > cap) tile_len = cap;
     if (!(((uint64_t)S * C) % 4u == 0 && ((uint64_t)tile_len * C) % 4u == 0 && (p.halo_frames * C) % 4u == 0)) return 0;
     return spp <= 128 ? 2 : 3;
