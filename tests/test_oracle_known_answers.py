@@ -146,6 +146,22 @@ def test_ebu3341_cases_10_and_13_burst_maxima(oracle):
         assert max(v[1] for v in r) == pytest.approx(-23.0, abs=0.1)
 
 
+def test_ebu3341_cases_11_and_14_stepped_burst_maxima(oracle):
+    """Case 11 / 14 shape: the bursts of cases 10 / 13 at levels stepped 1 dB apart from -38 to -19 dBFS -> the maximum
+    short-term (3 s bursts) resp. momentary (0.4 s bursts) reading of segment k is its level +-0.1 (every third level
+    here; the whole ladder takes a minute of oracle time)."""
+    rate = 48000
+    z = lambda sec: np.zeros(int(rate * sec))
+    for k in range(0, 20, 3):
+        level = -38.0 + k
+        x = np.concatenate([z(0.15 * k + 0.1), sine(rate, 3.0, 1000, level), z(1.0)])
+        r = _readings(oracle, interleave(x, x), rate, 0.05)
+        assert max(v[2] for v in r) == pytest.approx(level, abs=0.1), level
+        x = np.concatenate([z(0.02 * k + 0.1), sine(rate, 0.4, 1000, level), z(1.0)])
+        r = _readings(oracle, interleave(x, x), rate, 0.01)
+        assert max(v[1] for v in r) == pytest.approx(level, abs=0.1), level
+
+
 # ------------------------------------------------------------------ EBU Tech 3342 (LRA)
 @pytest.mark.parametrize("lo,hi,expect", [(-20, -30, 10), (-20, -15, 5), (-40, -20, 20)])
 def test_ebu3342_lra(oracle, lo, hi, expect):
