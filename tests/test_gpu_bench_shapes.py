@@ -90,8 +90,8 @@ def test_config3_bench_geometry_matches_oracle(oracle, overlap):
         assert lufs_close(res[i].integrated_lufs, hs[i][2]), i
 
 
-@pytest.mark.parametrize("tp_factor", [4, 0])
-def test_config5_bench_shape_all_channels(oracle, tp_factor):
+@pytest.mark.parametrize("tp_factor,overlap", [(4, False), (0, False), (4, True)])
+def test_config5_bench_shape_all_channels(oracle, tp_factor, overlap):
     """BASELINE config 5 as bench.py times it: 64 streams x 10 s x 96 kHz x 8 channels, N = 16384 per channel at hop
     1024, true peak forced to 4x (the benchmark) and at the crate's rule (2x at 96 kHz).  Four streams are checked in
     full on the meter side (LUFS, LRA, all EIGHT channels' true and sample peaks through ss_batch_peaks) and on a
@@ -99,6 +99,7 @@ def test_config5_bench_shape_all_channels(oracle, tp_factor):
     rate, ch, frames, ns = 96000, 8, 960000, 64
     b = ssa.Batch(rate, ch, ns, frames, 16384, 1024, flags=L.SS_BATCH_ALL, true_peak_factor=tp_factor)
     b.synthesize(0x5EED0000, 0)
+    b.set_overlap(overlap)                                      # the 16384-point run kernel beside the 8-channel time-domain kernel
     b.run(); b.sync()
     g, lay = b.geometry, b.layout
     assert (lay.n_windows, lay.fft_channels, lay.n_bins) == (921, 8, 3410)
