@@ -115,7 +115,10 @@ constexpr int kTdWavesPerBlock = 4;
 #define SS_TD_PREFETCH 8
 #endif
 constexpr int kTdPrefetch = SS_TD_PREFETCH;        // float4 per lane held in flight for the next tile
-constexpr int kTdBatch = 11;          // LDS reads issued together in the sequential passes
+#ifndef SS_TD_BATCH
+#define SS_TD_BATCH 10
+#endif
+constexpr int kTdBatch = SS_TD_BATCH;          // LDS reads issued together in the sequential passes
 
 // one K-weighting state step (DF-II, zero-based state v1..v4); the critical path is one FMA
 #define SS_KW_STATE(xd)                         \
@@ -1046,18 +1049,65 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
 #undef SS_PREFETCH
 }
 
-// Chunk length L: (L-1)*C = 0 (mod 32) makes the per-lane walk through the interleaved tile touch
-// lane-linear banks; among the candidates pick the one with the fewest sequential steps per
-// sub-block (pieces * L, pieces = tiles a sub-block is cut into).
+// Chunk length L (frames one lane filters per tile; a tile is 64 / C chunks).  Candidates are rated by a model of the
+// sequential work per 100 ms sub-block, in units of one batched K-weighting step of a lane, calibrated on chunk-length
+// sweeps of four shapes (tools/sweep_td_chunk.py: 48 / 96 / 44.1 kHz stereo, 96 kHz 8 channels):
+//   pieces x (F + steps(L) + 1.2 x frames of the incomplete last chunk)  x  occupancy(workgroups per CU)  x  exposure
+//   F        ~ 80   what a tile costs whatever its length (staging, scan, conversion set-up, decimation, tile tail),
+//   steps(L) = L, a step outside whole batches of kTdBatch (a look-ahead single) counting 1.5, plus 3 % per extra way of
+//              LDS bank conflict of the per-lane walk (lane (chunk, channel) reads tile[chunk L C + channel]),
+//   an incomplete last chunk runs the plain recurrence on one lane per channel, both passes: ~1.2 steps per frame,
+//   occupancy: three workgroups per CU cost 1.25x, two 1.6x their step count (longer tiles need more LDS),
+//   exposure : a tile beyond the 2048 floats the prefetch registers hold loads the rest at the point of use; tiles that
+//              do not start on 16-byte boundaries are staged with scalar loads (x 1.6).
+// A length that cuts the sub-block into whole tiles of whole chunks keeps every lane busy and has no incomplete chunk:
+// 48 kHz stereo 4800 = 5 x 32 x 30 — k_time_domain 2.14 -> 1.98 ms against L = 33 (5 tiles of 29 chunks + 3 frames)
+// although the walk of an even L is 2-way bank conflicted; 96 kHz stereo 2.91 -> 2.17 ms (was L = 65); BASELINE
+// config 5 (96 kHz, 8 channels) 3.02 -> 2.08 ms (was L = 65: 19 tiles of 7 chunks + 51 frames; now 40 tiles of 8 x 30).
+static uint32_t td_lds_blocks(uint32_t C, uint32_t tile_len)
+{
+    uint32_t wave_floats = ((uint32_t)kTdHaloFrames + tile_len) * C + td_slack_floats(C) + kMaxChannels;
+    wave_floats = (wave_floats + 3u) & ~3u;
+    const size_t lds = (size_t)wave_floats * 4 * kTdWavesPerBlock;
+    uint32_t blocks = (uint32_t)((160u * 1024u) / lds);
+    const uint32_t max_blocks = (4u * SS_TD_WAVES) / kTdWavesPerBlock;
+    return blocks > max_blocks ? max_blocks : blocks;
+}
+
 uint32_t td_chunk_frames(uint32_t C, uint32_t s100)
 {
+#ifdef SS_TUNING        // development builds only: force a chunk length (tools/sweep_td_chunk.py)
+    if (const char *e = std::getenv("SS_TD_L")) { const int v = std::atoi(e); if (v >= 8 && v <= 128) return (uint32_t)v; }
+#endif
     const uint32_t nch = 64u / C;
-    uint32_t best = 33, best_cost = 0xFFFFFFFFu;
-    for (uint32_t L : {33u, 49u, 65u}) {
-        if (((L - 1) * C) % 32u) continue;
+    const bool rowscan = C == 1 || C == 2 || C == 8;          // the compile-time channel counts whose chunks are dealt to the DPP rows
+    static const double occupancy[5] = {8.0, 3.0, 1.6, 1.25, 1.0};
+    uint32_t best = 33; double best_cost = 1e300;
+    for (uint32_t L : {20u, 25u, 30u, 33u, 35u, 40u, 45u, 49u, 50u, 55u, 60u, 65u}) {
         const uint32_t cap = nch * L;
         const uint32_t pieces = (s100 + cap - 1) / cap;
-        const uint32_t cost = pieces * L + 8 * pieces;       // per-tile fixed work ~ 8 steps
+        uint32_t tile_len = (s100 + pieces - 1) / pieces;
+        if (tile_len > cap) tile_len = cap;
+        const uint32_t blocks = td_lds_blocks(C, tile_len);
+        if (blocks == 0) continue;
+        const uint32_t rem = tile_len % L;
+        uint32_t ways = 1;                                    // bank conflicts of one pass read, per half wave
+        for (uint32_t half = 0; half < 2; half++) {
+            uint32_t hits[64] = {0};
+            for (uint32_t l = 32 * half; l < 32 * half + 32; l++) {
+                uint32_t chunk, ch;
+                if (rowscan) { const uint32_t q = (l & 15u) / C; chunk = (l >> 4) + 4u * q; ch = (l & 15u) - q * C; }
+                else { chunk = l / C; ch = l - chunk * C; }
+                if (chunk >= nch) continue;
+                const uint32_t n = ++hits[(chunk * L * C + ch) & 63u];
+                if (n > ways) ways = n;
+            }
+        }
+        const double steps = ((double)(kTdBatch * (L / kTdBatch)) + 1.5 * (double)(L % kTdBatch)) * (1.0 + 0.03 * (double)(ways - 1));
+        const uint32_t tile_floats = tile_len * C;
+        const double exposure = 1.0 + (tile_floats > 2048u ? 0.35 * (double)(tile_floats - 2048u) / 2048.0 : 0.0);
+        double cost = (double)pieces * (80.0 + steps + 1.2 * (double)rem) * occupancy[blocks > 4 ? 4 : blocks] * exposure;
+        if ((tile_floats & 3u) != 0u) cost *= 1.6;           // tiles that do not start on 16 bytes are staged with scalar loads
         if (cost < best_cost) { best_cost = cost; best = L; }
     }
     return best;
