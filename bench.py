@@ -166,7 +166,9 @@ def main():
     ap.add_argument("--rate", type=int, default=48000)
     ap.add_argument("--fft-n", type=int, default=4096)
     ap.add_argument("--hop", type=int, default=1024)
-    ap.add_argument("--sequential", action="store_true", help="spectrum and time-domain kernels back to back instead of overlapped")
+    ap.add_argument("--sequential", action="store_true", help="spectrum kernel, then the time-domain chain, on one stream")
+    ap.add_argument("--overlap", type=int, default=2, choices=[0, 1, 2],
+                    help="ss_batch_set_overlap mode: 1 = spectrum kernel beside the whole time-domain chain, 2 (default) = beside its tail only")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg (and its parity check)")
     ap.add_argument("--no-extra", action="store_true", help="skip the config 2 / config 5 lines")
     args = ap.parse_args()
@@ -220,7 +222,8 @@ def main():
     b = ssa.Batch(args.rate, 2, count, frames, args.fft_n, args.hop, flags=L.SS_BATCH_ALL)
     b.synthesize(0x5EED0000, first)
     lay = b.layout
-    b.set_overlap(not args.sequential)
+    ov_mode = 0 if args.sequential else args.overlap
+    b.set_overlap(ov_mode)
     hist = [None]
     # the memory system's floor for the spectrum kernel's access pattern on THIS box: its loads and stores alone, same
     # grid / occupancy / addresses, no arithmetic (overwrites the spectra, so it runs before anything is computed)
@@ -311,7 +314,9 @@ def main():
                        "streams_total": total_streams, "streams_this_rank": count, "windows_per_stream": lay.n_windows, "bins": lay.n_bins,
                        "sharding": f"streams, {world} rank(s)",
                        "collective": ({"lib": "none", "nranks": 1} if comm is None else {"lib": comm.transport, "nranks": comm.size, "call": "ncclAllReduce(2000, ncclUint64, ncclSum) per step" if comm.transport == "rccl" else "host-staged sum over loopback TCP"}),
-                       "mode": "sequential" if args.sequential else "overlap (spectrum kernel on a second HIP stream beside the time-domain chain)",
+                       "mode": ["sequential (spectrum kernel, then the time-domain chain)",
+                                "overlap (spectrum kernel on a second HIP stream beside the time-domain chain)",
+                                "time-domain kernel, then the spectrum kernel on a second HIP stream beside the chain's tail (gating / histograms)"][ov_mode],
                        "geometry": {"fft_windows_per_block": geo.fft_windows_per_block, "fft_blocks": geo.fft_blocks,
                                     "td_segments": geo.td_segments, "td_segment_subblocks": geo.td_segment_subblocks,
                                     "waveform_fused": geo.waveform_fused},

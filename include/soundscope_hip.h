@@ -283,13 +283,17 @@ typedef struct ss_batch_geometry {
     uint32_t td_warm_subblocks;      /* filter run-in of segments > 0                                 */
     uint32_t td_true_peak_factor;    /* 0, 2, 4                                                       */
     uint32_t waveform_fused;         /* 1: decimation runs inside the time-domain kernel              */
-    uint32_t overlap;                /* 1: spectrum kernel runs beside the time-domain chain          */
+    uint32_t overlap;                /* ss_batch_set_overlap mode: 0, 1 or 2                          */
 } ss_batch_geometry;                 /* 32 bytes */
 int ss_batch_geometry_get(const ss_batch *b, ss_batch_geometry *out);
-/* run the spectrum kernel on a second HIP stream beside the time-domain chain (they use different pipes: packed
- * f32 VALU + LDS vs f64 VALU + matrix cores); results are identical either way.  Per-kernel event timing
- * (ss_batch_timing_enable) always runs sequentially. */
-int ss_batch_set_overlap(ss_batch *b, int enable);
+/* how a pass is laid over the batch's two HIP streams; results are identical in every mode.
+ *   0  sequential: spectrum kernel, then the time-domain chain (default);
+ *   1  the spectrum kernel on a second stream beside the whole time-domain chain (they use different pipes: packed f32
+ *      VALU + LDS vs f64 VALU + matrix cores);
+ *   2  the time-domain kernel alone first, then the spectrum kernel on the second stream beside the chain's short
+ *      latency-bound tail (per-stream gating / histograms, a standalone decimation).
+ * Per-kernel event timing (ss_batch_timing_enable) always runs sequentially. */
+int ss_batch_set_overlap(ss_batch *b, int mode);
 /* spectrum of one stream: compact [n_windows][fft_channels][n_bins] f32 dB (pink-compensated);
  * on the device the rows are fft_bin_stride floats apart */
 int ss_batch_download_fft(ss_batch *b, uint32_t stream, float *out, size_t cap_floats);

@@ -97,9 +97,10 @@ class Batch:
         _check(L.lib().ss_batch_geometry_get(self._h, C.byref(g)))
         return g
 
-    def set_overlap(self, on=True):
-        """Spectrum kernel on a second HIP stream beside the time-domain chain (same results)."""
-        _check(L.lib().ss_batch_set_overlap(self._h, 1 if on else 0))
+    def set_overlap(self, mode=True):
+        """0 / False: sequential; 1 / True: spectrum kernel on a second HIP stream beside the time-domain chain;
+        2: beside the chain's tail only (time-domain kernel first and alone).  Same results in every mode."""
+        _check(L.lib().ss_batch_set_overlap(self._h, int(mode)))
 
     def allreduce_histograms(self, comm):
         """The corpus gate's exchange: in-place SUM all-reduce of this batch's corpus histograms over `comm`

@@ -1002,7 +1002,7 @@ struct ss_batch {
     // opt-in (SS_BATCH_OVERLAP=1): the spectrum kernel on a second stream beside the time-domain chain
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool overlap = false;
+    int overlap = 0;                  // 0 sequential, 1 the spectrum kernel beside the time-domain chain, 2 beside its tail only
     bool timing = false;
     hipEvent_t ev[2 * SS_KERNEL_COUNT] = {};
     bool ev_ready = false;
@@ -1403,12 +1403,17 @@ int ss_batch_run(ss_batch *b)
     // overlap mode: fork — the spectrum kernel goes to stream2 after everything already queued on the main stream
     // (uploads, the previous pass), the time-domain chain stays on the main stream, join at the end.  Per-kernel
     // event timing is meaningless while two kernels share the chip, so timing passes stay sequential.
-    const bool ov = b->overlap && !tm;
+    // Mode 2 (tail overlap): the time-domain kernel runs first and alone; the spectrum kernel starts behind it on stream2
+    // while the short latency-bound tail of the chain (gating / histograms per stream, a standalone decimation) runs on
+    // the main stream beside it.
+    const int mode = tm ? 0 : b->overlap;
+    const bool ov = mode != 0;
     hipStream_t fft_stream = ov ? b->stream2 : b->stream;
-    if (ov) {
+    if (mode == 1) {
         HIPCHK(hipEventRecord(b->ev_fork, b->stream));
         HIPCHK(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
     }
+    auto launch_spectrum = [&]() -> int {
     HIPCHK(rec(2 * SS_KERNEL_FFT));
     if ((c.flags & SS_BATCH_FFT) && L.n_windows) {
         ssk::FftBatchParams p{};
@@ -1454,6 +1459,9 @@ int ss_batch_run(ss_batch *b)
         }
     }
     HIPCHK(rec(2 * SS_KERNEL_FFT + 1));
+    return SS_OK;
+    };
+    if (mode != 2) { rc = launch_spectrum(); if (rc) return rc; }
 
     const bool td = (c.flags & (SS_BATCH_LUFS | SS_BATCH_TRUE_PEAK)) != 0;
     HIPCHK(rec(2 * SS_KERNEL_TIME_DOMAIN));
@@ -1474,6 +1482,11 @@ int ss_batch_run(ss_batch *b)
         HIPCHK(ssk::launch_time_domain(p, b->stream));
     }
     HIPCHK(rec(2 * SS_KERNEL_TIME_DOMAIN + 1));
+    if (mode == 2) {
+        HIPCHK(hipEventRecord(b->ev_fork, b->stream));
+        HIPCHK(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
+        rc = launch_spectrum(); if (rc) return rc;
+    }
 
     HIPCHK(rec(2 * SS_KERNEL_FINALIZE));
     if (td) {
@@ -1628,7 +1641,7 @@ int ss_batch_geometry_get(const ss_batch *b, ss_batch_geometry *out)
         out->td_true_peak_factor = (uint32_t)b->tp_factor;
     }
     out->waveform_fused = (b->wave_fused && !b->ragged) ? 1u : 0u;
-    out->overlap = b->overlap ? 1u : 0u;
+    out->overlap = (uint32_t)b->overlap;
     return SS_OK;
 }
 
@@ -1642,7 +1655,7 @@ int ss_batch_set_overlap(ss_batch *b, int enable)
         HIPCHK(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
     }
     HIPCHK(hipStreamSynchronize(b->stream));
-    b->overlap = enable != 0;
+    b->overlap = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
     return SS_OK;
 }
 

@@ -33,7 +33,7 @@ def _threads():
     return max(1, min(64, len(os.sched_getaffinity(0))))
 
 
-@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("overlap", [0, 1, 2])
 def test_config3_bench_geometry_matches_oracle(oracle, overlap):
     """BASELINE config 3 exactly as bench.py runs it: 1024 synthetic streams x 10 s x 48 kHz stereo, N = 4096,
     hop 1024.  The geometry the shape selects (116 windows per spectrum workgroup, 4 time segments per stream with a
@@ -90,7 +90,7 @@ def test_config3_bench_geometry_matches_oracle(oracle, overlap):
         assert lufs_close(res[i].integrated_lufs, hs[i][2]), i
 
 
-@pytest.mark.parametrize("tp_factor,overlap", [(4, False), (0, False), (4, True)])
+@pytest.mark.parametrize("tp_factor,overlap", [(4, 0), (0, 0), (4, 1), (4, 2)])
 def test_config5_bench_shape_all_channels(oracle, tp_factor, overlap):
     """BASELINE config 5 as bench.py times it: 64 streams x 10 s x 96 kHz x 8 channels, N = 16384 per channel at hop
     1024, true peak forced to 4x (the benchmark) and at the crate's rule (2x at 96 kHz).  Four streams are checked in
