@@ -5,6 +5,9 @@
 // Nothing here is translated from the reference: the reference has no GPU code.
 #include "ss_kernels.h"
 
+#ifndef SS_FFT_E1ROW
+#define SS_FFT_E1ROW 1      // k_fft4096_ms1 and k_fft16k_run: the first exchange uses the row layout of the second (A/B: -1 % and -2 %)
+#endif
 #ifndef SS_FFT_NT_STORE
 #define SS_FFT_NT_STORE 0
 #endif
@@ -429,7 +432,11 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
 {
     __shared__ __attribute__((aligned(16))) v2f xbuf[16 * kPlane];        // 36864 B
     __shared__ __attribute__((aligned(16))) v2f tw2s[256];                //  2048 B
+#if SS_FFT_E1ROW      /* first exchange in the row layout of the second one: the reader's 16 values are contiguous (8 x ds_read_b128) */
+#define X1W(ka, tb_, ta_) ((ka) * kPlane + (tb_) * kRow + (ta_))
+#else
 #define X1W(ka, tb_, ta_) ((ka) * kX1Stride + (tb_) + 16 * (ta_))
+#endif
 #define X2W(kb, ka_, tb_) ((kb) * kPlane + (ka_) * kRow + (tb_))
     const int t = threadIdx.x;
     const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
@@ -851,7 +858,11 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
     __shared__ __attribute__((aligned(16))) v2f xbuf2[2][16 * kPlane];       // 2 x 36864 B
     __shared__ __attribute__((aligned(16))) v2f tw2s[256];                    //  2048 B
     __shared__ __attribute__((aligned(16))) float stage[4][256];              //  4096 B: 79872 B per workgroup, two per CU
+#if SS_FFT_E1ROW      /* first exchange in the row layout of the second one: the reader's 16 values are contiguous (8 x ds_read_b128) */
+#define X1W(ka, tb_, ta_) ((ka) * kPlane + (tb_) * kRow + (ta_))
+#else
 #define X1W(ka, tb_, ta_) ((ka) * kX1Stride + (tb_) + 16 * (ta_))
+#endif
 #define X2W(kb, ka_, tb_) ((kb) * kPlane + (ka_) * kRow + (tb_))
     const int t = threadIdx.x;
     const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
