@@ -4,6 +4,7 @@
 // arithmetic of ebur128 0.1.10 / spectrum-analyzer 1.7.0 / microfft 0.6.0 as restated in DESIGN.md.
 // Nothing here is translated from the reference: the reference has no GPU code.
 #include "ss_kernels.h"
+#include <cstdlib>
 
 #ifndef SS_FFT_E1ROW
 #define SS_FFT_E1ROW 1      // k_fft4096_ms1 and k_fft16k_run: the first exchange uses the row layout of the second (A/B: -1 % and -2 %)
@@ -1069,6 +1070,9 @@ void fft16k_run_geometry(uint32_t n_streams, uint32_t fft_ch, uint32_t n_windows
     const uint32_t max_groups = n_windows / 16u ? n_windows / 16u : 1u;
     if (groups > max_groups) groups = max_groups;
     if (groups < 1) groups = 1;
+#ifdef SS_TUNING        // development builds only (tools/ab_cfg5.sh with SS_FFT16K_GROUPS)
+    if (const char *e = std::getenv("SS_FFT16K_GROUPS")) { const int v = std::atoi(e); if (v >= 1 && (uint32_t)v <= n_windows) groups = (uint32_t)v; }
+#endif
     const uint32_t wpb = (n_windows + groups - 1) / groups;
     *windows_per_block = wpb;
     *groups_out = (n_windows + wpb - 1) / wpb;
