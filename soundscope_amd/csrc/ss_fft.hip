@@ -9,6 +9,12 @@
 #ifndef SS_FFT_E1ROW
 #define SS_FFT_E1ROW 1      // k_fft4096_ms1 and k_fft16k_run: the first exchange uses the row layout of the second (A/B: -1 % and -2 %)
 #endif
+#ifndef SS_FFT_LATE_HOP
+#define SS_FFT_LATE_HOP 1      // the next hop's loads are issued behind the first radix pass (A/B: -1.4 %); 2 = behind the second (worse)
+#endif
+#ifndef SS_FFT16K_LATE_HOP
+#define SS_FFT16K_LATE_HOP 1   // k_fft16k_run: the next hop's loads behind the first radix pass (A/B: -3.5 %)
+#endif
 #ifndef SS_FFT_NT_STORE
 #define SS_FFT_NT_STORE 0
 #endif
@@ -479,11 +485,13 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
     for (uint32_t w = w_begin; w < w_end; ++w) {
         float2 nx[HS];
         const bool more = (w + 1 < w_end);
+#if !SS_FFT_LATE_HOP
 #pragma unroll
         for (int q = 0; q < HS; q++) {
             nx[q] = make_float2(0.f, 0.f);
             if (more) nx[q] = src[(size_t)(w + 1 - w_begin) * p.hop + t + 256 * (16 - HS + q)];
         }
+#endif
         v2f z[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) z[j] = v2f{sm[j] * hw[j], df[j] * hw[j]};
@@ -502,6 +510,13 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
             }
             xbuf[X1W(ka, tb, hi)] = v;
         }
+#if SS_FFT_LATE_HOP == 1      /* the hop's loads behind the first radix pass: two more passes and the publish still cover them */
+#pragma unroll
+        for (int q = 0; q < HS; q++) {
+            nx[q] = make_float2(0.f, 0.f);
+            if (more) nx[q] = src[(size_t)(w + 1 - w_begin) * p.hop + t + 256 * (16 - HS + q)];
+        }
+#endif
         SS_FPROF_MARK(0);
         __syncthreads();
         SS_FPROF_MARK(1);
@@ -516,6 +531,13 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
         xbuf[X2W(0, hi, tb)] = z[R16(0)];
 #pragma unroll
         for (int kb = 1; kb < 16; kb++) xbuf[X2W(kb, hi, tb)] = pk_cmul(z[R16(kb)], tw2s[tb * kb]);
+#if SS_FFT_LATE_HOP == 2
+#pragma unroll
+        for (int q = 0; q < HS; q++) {
+            nx[q] = make_float2(0.f, 0.f);
+            if (more) nx[q] = src[(size_t)(w + 1 - w_begin) * p.hop + t + 256 * (16 - HS + q)];
+        }
+#endif
         SS_FPROF_MARK(4);
         __syncthreads();
         SS_FPROF_MARK(5);
@@ -923,7 +945,9 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
     for (uint32_t w = w_begin; w < w_end; ++w) {
         const bool more = (w + 1 < w_end);
         v2f nx0 = {0.0f, 0.0f}, nx1 = {0.0f, 0.0f};
+#if !SS_FFT16K_LATE_HOP
         if (more) ld4((size_t)(w + 1 - w_begin) * 1024u + n0 + 1024u * 15u, nx0, nx1);
+#endif
         // the two halves are independent problems: every barrier phase carries both (half the barriers
         // per transform, two instruction streams to cover LDS latency)
         v2f z0[16], z1[16];
@@ -960,6 +984,9 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
             if (ka & 12) v = pk_cmul(v, twg[ka & 12]);
             xbuf2[1][X1W(ka, tb, hi)] = v;
         }
+#if SS_FFT16K_LATE_HOP
+        if (more) ld4((size_t)(w + 1 - w_begin) * 1024u + n0 + 1024u * 15u, nx0, nx1);
+#endif
         __syncthreads();
 #pragma unroll
         for (int ta = 0; ta < 16; ta++) { z0[ta] = xbuf2[0][X1W(hi, tb, ta)]; z1[ta] = xbuf2[1][X1W(hi, tb, ta)]; }
