@@ -40,8 +40,8 @@ namespace ssk {
 //              (A^L)^(2^k); chunks are dealt round-robin to the four DPP rows so that
 //              the long distances are in-row v_mov_dpp shifts, the short ones ds_bpermute
 //      pass 2: rerun each chunk from its true initial state, accumulate y^2.
-//    L is chosen with (L-1)*C = 0 (mod 32) so the per-lane walk through the
-//    interleaved tile is bank-conflict free without padding.
+//    L is chosen by td_chunk_frames (below): whole tiles of whole chunks first (48 kHz stereo: L = 30, a
+//    sub-block = 5 tiles x 32 chunks), then occupancy and the bank conflicts of the per-lane walk.
 //  * True peak on the f32 MATRIX pipe, concurrently with other waves' f64 VALU
 //    work: the polyphase FIR  y_f[n] = sum_t c_f[t] x[n-t]  over a block of BLK
 //    consecutive outputs is a banded-Toeplitz product
@@ -212,7 +212,8 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
     // round-robin to the four DPP rows of the wave instead: row r = lane / 16 holds chunks r, r + 4, r + 8, ..., so the scan
     // steps of distance 4, 8, 16 ... are shifts INSIDE a row (v_mov_dpp row_shr, VALU rate) and only the distances 1 and 2
     // cross rows (ds_bpermute: 22 cycles of the LDS crossbar each, and a dependent latency per step).  The walk through the
-    // interleaved tile stays bank-conflict free: (r + 4 q) L C + c covers 64 distinct banks for L = 33.
+    // interleaved tile is bank-conflict free for odd L ((r + 4 q) L C + c covers 64 distinct banks) and 2-way conflicted for
+    // L = 30, which td_chunk_frames still prefers where it cuts the sub-block into whole tiles of whole chunks.
     constexpr bool kRowScan = (CT != 0) && (16 % (CT ? CT : 1) == 0) && (SS_TD_ROWSCAN != 0);
     const uint32_t lane_q = (lane & 15u) / C;           // position of this lane's chunk inside its row
     const uint32_t chunk = kRowScan ? (lane >> 4) + 4u * lane_q : lane / C;
