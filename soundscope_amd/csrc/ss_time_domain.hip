@@ -90,6 +90,23 @@ __device__ __forceinline__ void mat4_apply_add(const_f64_ptr M, const double (&x
         z[r] = fma(M[r * 4 + 0], x[0], fma(M[r * 4 + 1], x[1], fma(M[r * 4 + 2], x[2], fma(M[r * 4 + 3], x[3], z[r]))));
 }
 
+// w = D s, D = [(-1)^j C(i,j)]: the backward differences of the DF-II state (D is its own inverse).  The chunk scan
+// works on w (ss_tables.cpp, kweight_transition_pow): the subtractions are exact for the slowly varying states that make
+// the plain product A^n s cancel, and six of them replace nothing else.
+__device__ __forceinline__ void state_diff(double (&s)[4])
+{
+    const double d12 = s[0] - s[1], d23 = s[1] - s[2], d34 = s[2] - s[3];
+    const double e1 = d12 - d23, e2 = d23 - d34;
+    s[1] = d12; s[2] = e1; s[3] = e1 - e2;
+}
+__device__ __forceinline__ void state_undiff(double &v1, double &v2, double &v3, double &v4)
+{
+    // (v1, d12, e1, f) -> (v1, v2, v3, v4)
+    const double d12 = v2, e1 = v3, f = v4;
+    const double d23 = d12 - e1, e2 = e1 - f, d34 = d23 - e2;
+    v2 = v1 - d12; v3 = v2 - d23; v4 = v3 - d34;
+}
+
 #ifndef SS_TP_F16
 #define SS_TP_F16 1
 #endif
@@ -571,7 +588,12 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
             }
             for (; i < len; i++) { SS_KW_STATE((double)xs[i * C]) SS_KW_SHIFT() }
             z[0] = v1; z[1] = v2; z[2] = v3; z[3] = v4;
-            if (active && chunk == 0) mat4_apply_add(mpow, cv, z);
+            state_diff(z);                              // the scan runs in difference coordinates
+            if (active && chunk == 0) {
+                double cw[4] = {cv[0], cv[1], cv[2], cv[3]};
+                state_diff(cw);
+                mat4_apply_add(mpow, cw, z);
+            }
         }
         SS_PROF_MARK(2);
         // ---- in-wave scan over chunks: z_i += (A^L)^(2^k) z_{i - 2^k}  (the steps commute: powers of one matrix)
@@ -618,7 +640,9 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
             const int src = (int)lane_of_chunk(chunk ? chunk - 1u : 0u);
             const double p0 = __shfl(z[0], src, 64), p1 = __shfl(z[1], src, 64), p2 = __shfl(z[2], src, 64), p3 = __shfl(z[3], src, 64);
             const bool first = chunk == 0;
-            v1 = first ? cv[0] : p0; v2 = first ? cv[1] : p1; v3 = first ? cv[2] : p2; v4 = first ? cv[3] : p3;
+            double q1 = p0, q2 = p1, q3 = p2, q4 = p3;
+            state_undiff(q1, q2, q3, q4);               // back to (v1 .. v4)
+            v1 = first ? cv[0] : q1; v2 = first ? cv[1] : q2; v3 = first ? cv[2] : q3; v4 = first ? cv[3] : q4;
         }
 
         SS_PROF_MARK(3);

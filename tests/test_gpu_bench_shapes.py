@@ -406,3 +406,55 @@ def test_config4_full_size_equals_its_eight_shards(oracle):
         for c in range(2):
             assert rel_close(big_res[i][2 + c], ref["true_peak"][c]) and big_res[i][4 + c] == ref["sample_peak"][c]
         assert np.array_equal(waves[i], ref["wave"][:, 1].astype(np.float32)), i
+
+
+_SWEEP = [(r, c) for r in (8000, 16000, 22050, 32000, 44100, 48000, 88200, 96000, 192000) for c in (1, 2, 3, 4, 6, 8)]
+
+
+@pytest.mark.parametrize("rate,channels", _SWEEP)
+def test_time_domain_chunk_lengths_across_rates_and_channels(oracle, rate, channels):
+    """The time-domain kernel's tile geometry (chunk length, tiles per sub-block, lanes per chunk row, planar or f32
+    true peak, fused or standalone decimation) is chosen per (rate, channel count) by a cost model; this walks the
+    model's whole decision table — nine rates x six channel counts, chunk lengths 20 ... 65, exact and inexact tilings —
+    with a batch whose length is not a whole number of sub-blocks or segments, and holds every loudness figure, every
+    channel's peaks and every decimation bin to the oracle."""
+    from conftest import make_multich
+    frames = int(rate * 2.37) + 5
+    xs = [make_multich(900 + 7 * i + channels, frames, channels, rate, level=0.15 + 0.6 * i) for i in range(3)]
+    b = ssa.Batch(rate, channels, 3, frames, 4096, 1024, flags=L.SS_BATCH_LUFS | L.SS_BATCH_TRUE_PEAK | L.SS_BATCH_WAVEFORM)
+    b.upload(0, np.concatenate(xs)); b.run(); b.sync()
+    res = b.results()
+    for i, x in enumerate(xs):
+        m = oracle.Meter(channels, rate); m.add_frames(x)
+        tp, sp = b.peaks(i)
+        for c in range(channels):
+            assert rel_close(tp[c], max(m.true_peak(c), m.sample_peak(c))), (i, c, tp[c], m.true_peak(c))
+            assert sp[c] == m.sample_peak(c), (i, c)
+        assert lufs_close(res[i].integrated_lufs, m.integrated()), (i, res[i].integrated_lufs, m.integrated())
+        assert abs(res[i].loudness_range - m.loudness_range()) <= TOL_DB
+        ref = oracle.get_waveform(x, frames / rate)[:, 1].astype(np.float32)
+        assert np.array_equal(b.waveform(i).reshape(-1)[:ref.size], ref), i
+
+
+@pytest.mark.parametrize("rate,channels,bound", [(48000, 2, 1e-10), (96000, 2, 1e-9), (192000, 2, 2e-8), (192000, 1, 2e-8), (44100, 8, 1e-10), (384000, 2, 1e-6)])
+def test_kweighting_is_f64_accurate_at_every_rate(oracle, rate, channels, bound):
+    """The K-weighted 100 ms sub-block energies of the parallel (two-pass, in-wave scan) filter against a sequential f64
+    filter (scipy lfilter, transposed direct form) with the meter's own coefficients.  The poles move towards z = 1 with the
+    sample rate and the DF-II state grows to 1e5 ... 1e8 times the input; the chunk scan therefore runs in backward-
+    difference coordinates of the state (ss_tables.cpp kweight_transition_pow) — with plain powers of the companion
+    matrix the same comparison read 3e-8 at 48 kHz, 5e-6 at 96 kHz and 2e-3 at 192 kHz."""
+    from scipy.signal import lfilter
+    from conftest import make_multich
+    frames = int(rate * 2.37) + 5
+    xs = [make_multich(900 + 7 * i + channels, frames, channels, rate, level=0.15 + 0.6 * i) for i in range(3)]
+    b = ssa.Batch(rate, channels, 3, frames, 4096, 1024, flags=L.SS_BATCH_LUFS)
+    b.upload(0, np.concatenate(xs)); b.run(); b.sync()
+    assert b.geometry.td_segments > 1                       # segments with a run-in, like the benchmark
+    bb, aa = oracle.Meter(channels, rate).coeffs()
+    S = (rate + 5) // 10
+    n = frames // S
+    for i, x in enumerate(xs):
+        y = lfilter(bb, aa, x.reshape(-1, channels).astype(np.float64), axis=0)
+        ref = np.array([[np.sum(y[k * S:(k + 1) * S, c] ** 2) for c in range(channels)] for k in range(n)])
+        got = b.subblocks(i)[:n]
+        assert (np.abs(got - ref) / ref).max() <= bound, (i, (np.abs(got - ref) / ref).max())
