@@ -458,3 +458,29 @@ def test_kweighting_is_f64_accurate_at_every_rate(oracle, rate, channels, bound)
         ref = np.array([[np.sum(y[k * S:(k + 1) * S, c] ** 2) for c in range(channels)] for k in range(n)])
         got = b.subblocks(i)[:n]
         assert (np.abs(got - ref) / ref).max() <= bound, (i, (np.abs(got - ref) / ref).max())
+
+
+@pytest.mark.parametrize("n_streams", [1, 3, 17, 100, 257, 700])
+def test_launch_geometry_across_batch_sizes(oracle, n_streams):
+    """The launch geometry (windows per spectrum workgroup, time segments per stream and their run-in) is a function of
+    the batch size; between the handful-of-streams shapes of the parity tests and the 1024-stream benchmark shape this
+    walks the sizes in between — first, middle and last stream of each batch in full against the oracle."""
+    rate, frames = 48000, int(48000 * 3.3) + 11
+    b = ssa.Batch(rate, 2, n_streams, frames, 4096, 1024, flags=L.SS_BATCH_ALL)
+    b.synthesize(0xC0FFEE, 5)
+    b.run(); b.sync()
+    res = b.results()
+    lay = b.layout
+    picks = sorted({0, n_streams // 2, n_streams - 1})
+    for i in picks:
+        x = b.download_input(i)
+        ref = oracle.analyze_stream(rate, x, 4096, 1024)
+        assert ref["n_windows"] == lay.n_windows
+        fft = b.fft(i)
+        for w in range(lay.n_windows):
+            for c in range(2):
+                assert db_close(fft[w, c], ref["fft"][w, c], TOL_DB), (i, w, c)
+        assert lufs_close(res[i].integrated_lufs, ref["integrated"]) and abs(res[i].loudness_range - ref["lra"]) <= TOL_DB
+        for c in range(2):
+            assert rel_close(res[i].true_peak[c], ref["true_peak"][c]) and res[i].sample_peak[c] == ref["sample_peak"][c]
+        assert np.array_equal(b.waveform(i).reshape(-1), ref["wave"][:, 1].astype(np.float32)), i
