@@ -484,3 +484,31 @@ def test_launch_geometry_across_batch_sizes(oracle, n_streams):
         for c in range(2):
             assert rel_close(res[i].true_peak[c], ref["true_peak"][c]) and res[i].sample_peak[c] == ref["sample_peak"][c]
         assert np.array_equal(b.waveform(i).reshape(-1), ref["wave"][:, 1].astype(np.float32)), i
+
+
+@pytest.mark.parametrize("frames", [1, 100, 4095, 4096, 4097, 5120, 5121, 19199, 19200, 19201, 19679, 19680, 24000, 143999, 144000, 144001, 148800, 148801])
+def test_stream_length_edges(oracle, frames):
+    """Lengths at every threshold of the path at 48 kHz: no window / the first window (the reference skips the window whose
+    left edge is sample 0, so N + hop frames are needed), the first 400 ms gating block and the first 100 ms step behind
+    it, the first 3 s short-term block and its first 1 s step — five streams per batch, each against the oracle."""
+    rate = 48000
+    xs = [make_stereo(600 + i, frames, rate, level=0.1 + 0.2 * i) for i in range(5)]
+    b = ssa.Batch(rate, 2, 5, frames, 4096, 1024, flags=L.SS_BATCH_ALL)
+    b.upload(0, np.concatenate(xs)); b.run(); b.sync()
+    res = b.results()
+    lay = b.layout
+    for i, x in enumerate(xs):
+        ref = oracle.analyze_stream(rate, x, 4096, 1024)
+        assert ref["n_windows"] == lay.n_windows
+        if lay.n_windows:
+            fft = b.fft(i)
+            for w in range(lay.n_windows):
+                for c in range(2):
+                    assert db_close(fft[w, c], ref["fft"][w, c], TOL_DB), (i, w, c)
+        assert lufs_close(res[i].integrated_lufs, ref["integrated"]), (i, res[i].integrated_lufs, ref["integrated"])
+        assert abs(res[i].loudness_range - ref["lra"]) <= TOL_DB
+        for c in range(2):
+            assert rel_close(res[i].true_peak[c], ref["true_peak"][c]) and res[i].sample_peak[c] == ref["sample_peak"][c]
+        got = b.waveform(i).reshape(-1)
+        want = ref["wave"][:, 1].astype(np.float32)
+        assert np.array_equal(got[:want.size], want), i
