@@ -109,9 +109,9 @@ def self_check(batch, stream, ref):
             "true_peak_rel_err": tp_rel, "decimation_bit_exact": wave_ok, "ok": bool(ok)}
 
 
-def time_config(ssa, L, rate, channels, streams, frames, fft_n, hop, tp_factor, steps, warmup=1):
+def time_config(ssa, L, rate, channels, streams, frames, fft_n, hop, tp_factor, steps, warmup=1, flags=None):
     """Per-kernel HIP-event times of one extra BASELINE configuration (informational lines under config.extra)."""
-    b = ssa.Batch(rate, channels, streams, frames, fft_n, hop, flags=L.SS_BATCH_ALL, true_peak_factor=tp_factor)
+    b = ssa.Batch(rate, channels, streams, frames, fft_n, hop, flags=L.SS_BATCH_ALL if flags is None else flags, true_peak_factor=tp_factor)
     b.synthesize(0x5EED0000, 0)
     for _ in range(warmup):
         b.run(); b.sync()
@@ -356,7 +356,13 @@ def main():
         if world == 1 and not args.no_extra:
             b.close()
             extra = []
-            try:      # config 2: one stream (10 s and the 600 s steady-state variant)
+            try:
+                # config 3 as BASELINE.json words it ("4096-pt FFT + LUFS"): the headline step additionally carries the
+                # 4x true peak and the decimation that north_star puts on the path
+                e = time_config(ssa, L, args.rate, 2, count, frames, args.fft_n, args.hop, 0, steps=5, flags=L.SS_BATCH_FFT | L.SS_BATCH_LUFS)
+                e["workload"] = f"config 3 without true peak and decimation: {count} streams x {args.seconds:g} s, spectrum + K-weighted gated LUFS / LRA only"
+                extra.append(e)
+                # config 2: one stream (10 s and the 600 s steady-state variant)
                 for secs in (10, 600):
                     e = time_config(ssa, L, 48000, 2, 1, 48000 * secs, 4096, 1024, 0, steps=5)
                     e["workload"] = f"config 2: 1 stream x {secs} s, 48 kHz stereo, N=4096 hop 1024, full path"
