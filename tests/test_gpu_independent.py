@@ -1,0 +1,110 @@
+"""The DEVICE path against oracle-independent computations (numpy / scipy in f64 from the published definitions) — the
+second line of evidence next to the oracle comparisons, since product and oracle share an author:
+
+  * spectrum: mid / side, periodic Hann, |rfft| in f64, 20 log10(mag 4 / N), pink compensation 10 log10(f / 1000),
+    bins 20 Hz ... 20 kHz (analyzer.rs:11-27, :55-105; audio_player.rs:400-419);
+  * K-weighted loudness: BS.1770 gating on 400 ms blocks of a sequential f64 filter (coefficients from the meter);
+  * true peak: the 49-tap Hann-windowed sinc interpolator as a polyphase convolution in f64.
+"""
+import numpy as np
+import pytest
+from scipy import signal
+
+import soundscope_amd as ssa
+from soundscope_amd import _lib as L
+from conftest import make_stereo
+
+pytestmark = pytest.mark.gpu
+
+
+def spectrum_f64(x, rate, n):
+    """One window of the reference's get_fft restated with numpy in f64 (window values rounded to f32 as the crate's)."""
+    i = np.arange(n, dtype=np.float64)
+    w = (0.5 * (1.0 - np.cos(2.0 * np.pi * i / n))).astype(np.float32).astype(np.float64)
+    mag = np.abs(np.fft.rfft(x.astype(np.float64) * w))
+    freq32 = np.arange(n // 2 + 1, dtype=np.float32) * (np.float32(rate) / np.float32(n))
+    keep = (freq32 >= 20.0) & (freq32 <= 20000.0)
+    with np.errstate(divide="ignore"):
+        db = np.where(mag[keep] == 0.0, -150.0, 20.0 * np.log10(mag[keep] * 4.0 / n))
+    return db + 10.0 * np.log10(freq32[keep].astype(np.float64) / 1000.0)
+
+
+@pytest.mark.parametrize("rate,n,hop", [(48000, 4096, 1024), (44100, 4096, 1024), (48000, 16384, 1024), (96000, 16384, 1024)])
+def test_spectrum_against_numpy_f64(rate, n, hop):
+    frames = n + hop * 9 + 5
+    xs = [make_stereo(40 + i, frames, rate, level=0.2 + 0.3 * i) for i in range(2)]
+    b = ssa.Batch(rate, 2, 2, frames, n, hop, flags=L.SS_BATCH_FFT)
+    b.upload(0, np.concatenate(xs)); b.run(); b.sync()
+    lay = b.layout
+    for i, x in enumerate(xs):
+        lr = x.reshape(-1, 2)
+        mid = ((lr[:, 0] + lr[:, 1]) / np.float32(2.0)).astype(np.float32)
+        side = ((lr[:, 0] - lr[:, 1]) / np.float32(2.0)).astype(np.float32)
+        got = b.fft(i)
+        assert got.shape[0] == lay.n_windows > 0
+        for wdx in range(lay.n_windows):
+            p = (wdx + n // hop + 1) * hop                       # window = frames [p - N, p), left edge > 0 (tui.rs:1489)
+            for c, sig in enumerate((mid, side)):
+                ref = spectrum_f64(sig[p - n:p], rate, n)
+                strong = ref >= -90.0
+                assert np.abs(got[wdx, c][strong] - ref[strong]).max() <= 0.01, (i, wdx, c)
+                peak = 10.0 ** (ref.max() / 20.0)
+                weak_err = np.abs(10.0 ** (got[wdx, c][~strong] / 20.0) - 10.0 ** (ref[~strong] / 20.0))
+                assert weak_err.size == 0 or weak_err.max() <= 1e-4 * peak
+
+
+def lufs_f64(x, rate, channels, coeffs):
+    """BS.1770-4 integrated loudness with exact (non-histogram) gating of a sequential f64 K-weighting."""
+    b, a = coeffs
+    y = signal.lfilter(b, a, x.reshape(-1, channels).astype(np.float64), axis=0)
+    s100 = (rate + 5) // 10
+    n = y.shape[0] // s100
+    sub = np.array([np.sum(y[k * s100:(k + 1) * s100] ** 2, axis=0) for k in range(n)])          # [sub-block][channel]
+    blocks = np.array([sub[k - 3:k + 1].sum(axis=0).sum() / (4.0 * s100) for k in range(3, n)])  # L = R = 1.0
+    absolute = blocks[10.0 * np.log10(np.maximum(blocks, 1e-300)) - 0.691 >= -70.0]
+    if absolute.size == 0:
+        return -np.inf
+    rel = absolute.mean() * 0.1
+    gated = absolute[absolute >= rel]
+    return 10.0 * np.log10(gated.mean()) - 0.691
+
+
+@pytest.mark.parametrize("rate", [44100, 48000, 96000, 192000])
+def test_integrated_loudness_against_exact_f64_gating(oracle, rate):
+    """The device bins block energies in 0.1 LU steps like the crate's histogram mode; exact gating of the same blocks
+    differs from that by at most half a bin in each block's weight — 0.05 LU is the bar here, the oracle comparisons hold
+    the 0.01 LU one."""
+    frames = rate * 6 + 17
+    xs = [make_stereo(70 + i, frames, rate, level=0.05 + 0.4 * i, gap=(i == 1)) for i in range(3)]
+    b = ssa.Batch(rate, 2, 3, frames, 4096, 1024, flags=L.SS_BATCH_LUFS)
+    b.upload(0, np.concatenate(xs)); b.run(); b.sync()
+    coeffs = oracle.Meter(2, rate).coeffs()            # the design is pinned separately (tests/test_product_tables.py)
+    for i, x in enumerate(xs):
+        assert abs(b.results()[i].integrated_lufs - lufs_f64(x, rate, 2, coeffs)) <= 0.05, i
+
+
+def interpolator_taps(factor):
+    j = np.arange(49, dtype=np.float64)
+    m = j - 24.0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        c = np.where(np.abs(m) > 1e-6, np.sin(m * np.pi / factor) / (m * np.pi / factor), 1.0)
+    c *= 0.5 * (1.0 - np.cos(2.0 * np.pi * j / 48.0))
+    return c.astype(np.float32).astype(np.float64)      # the crate keeps f32 taps
+
+
+@pytest.mark.parametrize("rate,factor", [(48000, 4), (44100, 4), (96000, 2)])
+def test_true_peak_against_f64_polyphase(rate, factor):
+    frames = rate * 2 + 33
+    xs = [make_stereo(90 + i, frames, rate, level=0.3 + 0.6 * i) for i in range(2)]
+    xs[1][2 * 5000:2 * 5000 + 2 * 64] *= np.float32(3.0)             # an inter-sample-peak prone burst
+    b = ssa.Batch(rate, 2, 2, frames, 4096, 1024, flags=L.SS_BATCH_TRUE_PEAK | L.SS_BATCH_LUFS)
+    b.upload(0, np.concatenate(xs)); b.run(); b.sync()
+    taps = interpolator_taps(factor)
+    for i, x in enumerate(xs):
+        tp, sp = b.peaks(i)
+        for c in range(2):
+            ch = x[c::2].astype(np.float64)
+            up = signal.upfirdn(taps, ch, up=factor)               # zero-stuffed input through the 49 taps: every phase
+            want = max(np.abs(up[:factor * ch.size]).max(), np.abs(ch).max())
+            assert abs(tp[c] - want) <= 2e-6 * want, (i, c, tp[c], want)
+            assert sp[c] == np.abs(x[c::2]).max()
