@@ -108,3 +108,43 @@ def test_true_peak_against_f64_polyphase(rate, factor):
             want = max(np.abs(up[:factor * ch.size]).max(), np.abs(ch).max())
             assert abs(tp[c] - want) <= 2e-6 * want, (i, c, tp[c], want)
             assert sp[c] == np.abs(x[c::2]).max()
+
+
+def lra_f64(x, rate, channels, coeffs):
+    """EBU Tech 3342 loudness range with exact short-term values (3 s window every 1 s, the crate's cadence) instead of
+    the 0.1 LU histogram: absolute gate -70 LUFS, relative gate -20 LU under the gated power mean, 10th / 95th percentile
+    entries at ranks floor((n - 1) p + 0.5)."""
+    b, a = coeffs
+    y = signal.lfilter(b, a, x.reshape(-1, channels).astype(np.float64), axis=0)
+    s100 = (rate + 5) // 10
+    n = y.shape[0] // s100
+    sub = np.array([np.sum(y[k * s100:(k + 1) * s100] ** 2) for k in range(n)])
+    st = np.array([sub[k - 29:k + 1].sum() / (30.0 * s100) for k in range(29, n, 10)])
+    st = st[10.0 * np.log10(np.maximum(st, 1e-300)) - 0.691 >= -70.0]
+    if st.size == 0:
+        return 0.0
+    st = np.sort(st[st >= st.mean() * 0.01])
+    lo = st[int((st.size - 1) * 0.10 + 0.5)]
+    hi = st[int((st.size - 1) * 0.95 + 0.5)]
+    return 10.0 * np.log10(hi / lo)
+
+
+@pytest.mark.parametrize("rate", [44100, 48000, 96000])
+def test_loudness_range_against_exact_f64_percentiles(oracle, rate):
+    """Programme-like material: 40 s whose level moves over 25 dB in steps and ramps; histogram mode quantises each
+    short-term value to 0.1 LU, so the device may differ from the exact percentiles by up to 0.1 LU at either end."""
+    frames = rate * 40
+    rng = np.random.default_rng(5)
+    xs = []
+    for i in range(2):
+        x = make_stereo(120 + i, frames, rate, level=0.9).reshape(-1, 2)
+        t = np.arange(frames) / rate
+        gain_db = -25.0 + 12.0 * np.sin(2 * np.pi * t / (13.0 + 4 * i)) + 6.0 * np.floor(t / 7.0) % 3 + rng.uniform(-1, 1)
+        xs.append((x * (10.0 ** (gain_db / 20.0))[:, None]).astype(np.float32).reshape(-1))
+    b = ssa.Batch(rate, 2, 2, frames, 4096, 1024, flags=L.SS_BATCH_LUFS)
+    b.upload(0, np.concatenate(xs)); b.run(); b.sync()
+    coeffs = oracle.Meter(2, rate).coeffs()
+    for i, x in enumerate(xs):
+        want = lra_f64(x, rate, 2, coeffs)
+        assert want > 5.0                                   # the material really has a range
+        assert abs(b.results()[i].loudness_range - want) <= 0.21, (i, b.results()[i].loudness_range, want)
