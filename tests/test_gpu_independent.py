@@ -148,3 +148,30 @@ def test_loudness_range_against_exact_f64_percentiles(oracle, rate):
         want = lra_f64(x, rate, 2, coeffs)
         assert want > 5.0                                   # the material really has a range
         assert abs(b.results()[i].loudness_range - want) <= 0.21, (i, b.results()[i].loudness_range, want)
+
+
+@pytest.mark.parametrize("rate,slice_frames", [(48000, 8192), (44100, 3000), (96000, 16384), (192000, 9999)])
+def test_streaming_shortterm_and_momentary_against_f64_windows(oracle, rate, slice_frames):
+    """The streaming handle (the twelve-method mirror of `Analyzer`): after every `add_samples` the short-term and
+    momentary readings are -0.691 + 10 log10 of the mean square of the K-weighted signal over the last 3 s / 400 ms
+    (zeros before the start) — no histogram in between, so the bar is tight: 1e-6 LU against a sequential f64 filter."""
+    frames = int(rate * 4.3)
+    x = make_stereo(150, frames, rate, level=0.4)
+    bq, aq = oracle.Meter(2, rate).coeffs()
+    y = signal.lfilter(bq, aq, x.reshape(-1, 2).astype(np.float64), axis=0)
+    csum = np.concatenate([[0.0], np.cumsum((y ** 2).sum(axis=1))])
+    a = ssa.Analyzer(2, rate)
+    fed = 0
+    while fed < frames:
+        n = min(slice_frames, frames - fed)
+        a.add_samples(x[2 * fed:2 * (fed + n)])
+        fed += n
+        for win, got in ((3.0, a.get_shortterm_lufs()), (0.4, a.get_momentary_lufs())):
+            w = int(round(win * rate))
+            if win == 3.0:
+                w = ((w + (rate + 5) // 10 - 1) // ((rate + 5) // 10)) * ((rate + 5) // 10)    # ring length: a multiple of 100 ms
+            lo = max(fed - w, 0)
+            e = (csum[fed] - csum[lo]) / w
+            want = -np.inf if e <= 0 else 10.0 * np.log10(e) - 0.691
+            assert abs(got - want) <= 1e-6, (fed, win, got, want)
+    a.close()
