@@ -175,3 +175,37 @@ def test_streaming_shortterm_and_momentary_against_f64_windows(oracle, rate, sli
             want = -np.inf if e <= 0 else 10.0 * np.log10(e) - 0.691
             assert abs(got - want) <= 1e-6, (fed, win, got, want)
     a.close()
+
+
+def waveform_numpy(x, window_s):
+    """analyzer.rs:107-137 with numpy: W = window_s * 1000 bins, spp = len / W in f64, bin i = [floor(i spp),
+    min(ceil((i + 1) spp), len)), points (i, min), (i, max); stops at the first bin that starts past the end."""
+    w = int(window_s * 1000.0)
+    spp = len(x) / w
+    out = []
+    for i in range(w):
+        bs = int(np.floor(i * spp))
+        be = min(int(np.ceil((i + 1) * spp)), len(x))
+        if bs >= len(x):
+            break
+        seg = x[bs:be]
+        out += [np.nanmin(seg) if seg.size and not np.all(np.isnan(seg)) else (np.nan if seg.size else 0.0),
+                np.nanmax(seg) if seg.size and not np.all(np.isnan(seg)) else (np.nan if seg.size else 0.0)]
+    return np.array(out, np.float32)
+
+
+@pytest.mark.parametrize("rate,channels,seconds", [(48000, 2, 2.0), (44100, 2, 2.0), (96000, 8, 1.0), (48000, 1, 0.0294), (22050, 2, 3.7)])
+def test_decimation_against_numpy(rate, channels, seconds):
+    """Min-max decimation, fused in the batch kernel or standalone, and the handle-less `get_waveform`: bit for bit
+    against the definition restated with numpy (integer and fractional samples per bin)."""
+    frames = max(int(rate * seconds), 4)
+    rng = np.random.default_rng(9)
+    xs = [(rng.standard_normal(frames * channels) * 0.2).astype(np.float32) for _ in range(2)]
+    b = ssa.Batch(rate, channels, 2, frames, 4096, 1024, flags=L.SS_BATCH_WAVEFORM | L.SS_BATCH_LUFS)
+    b.upload(0, np.concatenate(xs)); b.run(); b.sync()
+    for i, x in enumerate(xs):
+        want = waveform_numpy(x, frames / rate)
+        got = b.waveform(i).reshape(-1)[:want.size]
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), i
+        pts = ssa.Analyzer.get_waveform(x, frames / rate)
+        assert np.array_equal(np.asarray(pts)[:, 1].astype(np.float32).view(np.uint32), want.view(np.uint32)), i
