@@ -311,11 +311,18 @@ int get_hist_tables(const double **energies, const double **bounds)
 
 bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 
-// run-in of a time segment that starts from a zero filter state: the slowest K-weighting pole (38 Hz
-// high-pass, |p| = 0.99502 at 48 kHz) decays by e^-23.9 per 100 ms sub-block, so after two sub-blocks what is
-// left of the unknown true state is 1.6e-21 of it (times the polynomial factor of the high-pass section's near-double
-// pole: ~1e-13 relative on DC-offset material) — invisible at the 0.01 dB bar and inside a 0.1 LU histogram bin
-constexpr uint32_t kTdWarmSub = 2;
+// run-in of a time segment that starts from a zero filter state, in 100 ms sub-blocks.  What the missing history would
+// have contributed to the OUTPUT is the tail of the K-weighting impulse response: the slowest pole pair (38 Hz high-pass,
+// |p| = 0.99502 at 48 kHz, a near-double pole) decays by e^-23.9 per sub-block, times a polynomial factor ~ (1 + 24 n).
+// Measured on adversarial material (DC offset plus a strong 7 Hz component, every segment one sub-block long): sub-block
+// energies within 2.7e-10 of a sequential f64 filter with a one-sub-block run-in, 1.6e-10 with two — both at the
+// arithmetic noise of the recurrence on such material (tools: tests/test_gpu_bench_shapes.py
+// ::test_segmented_run_in_on_dc_offset_material pins the histograms).  One sub-block it is: the run-in is redundant work
+// (config 5: 4 instead of 5 sub-blocks per 3-sub-block segment).
+#ifndef SS_TD_WARM_SUB
+#define SS_TD_WARM_SUB 1
+#endif
+constexpr uint32_t kTdWarmSub = SS_TD_WARM_SUB;
 
 int meter_args_ok(uint32_t channels, uint32_t rate)
 {

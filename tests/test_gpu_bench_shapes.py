@@ -48,7 +48,7 @@ def test_config3_bench_geometry_matches_oracle(oracle, overlap):
     g, lay = b.geometry, b.layout
     assert (lay.n_windows, lay.n_bins) == (464, 1705)
     assert g.fft_windows_per_block == 116 and g.fft_blocks == 4096
-    assert g.td_segments == 4 and g.td_segment_subblocks == 25 and g.td_warm_subblocks == 2
+    assert g.td_segments == 4 and g.td_segment_subblocks == 25 and g.td_warm_subblocks == 1
     assert g.waveform_fused == 1 and g.td_true_peak_factor == 4 and g.overlap == int(overlap)
     res = b.results()
     picks = [0, 1, 255, 256, 511, 512, 1022, 1023]
