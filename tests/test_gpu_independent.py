@@ -209,3 +209,23 @@ def test_decimation_against_numpy(rate, channels, seconds):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), i
         pts = ssa.Analyzer.get_waveform(x, frames / rate)
         assert np.array_equal(np.asarray(pts)[:, 1].astype(np.float32).view(np.uint32), want.view(np.uint32)), i
+
+
+@pytest.mark.parametrize("rate,n", [(48000, 1024), (48000, 2048), (44100, 4096), (48000, 8192), (96000, 16384), (48000, 32768)])
+def test_single_window_get_fft_against_numpy_f64(rate, n):
+    """`Analyzer::get_fft` (one mono window of any power-of-two length: the generic, the 4096- and the 16384-point kernels)
+    against the numpy restatement; the x axis of the pairs is the log-frequency chart position (analyzer.rs:88-98)."""
+    rng = np.random.default_rng(n)
+    t = np.arange(n) / rate
+    x = (0.4 * np.sin(2 * np.pi * 1234.5 * t) + 0.1 * np.sin(2 * np.pi * 77.0 * t) + 0.02 * rng.standard_normal(n)).astype(np.float32)
+    a = ssa.Analyzer(2, rate)
+    got = np.asarray(a.get_fft(x))
+    a.close()
+    ref = spectrum_f64(x, rate, n)
+    assert got.shape == (ref.size, 2)
+    strong = ref >= -90.0
+    assert np.abs(got[strong, 1] - ref[strong]).max() <= 0.01
+    freq32 = np.arange(n // 2 + 1, dtype=np.float32) * (np.float32(rate) / np.float32(n))
+    keep = (freq32 >= 20.0) & (freq32 <= 20000.0)
+    xpos = (np.log10(freq32[keep].astype(np.float64)) - np.log10(20.0)) / (np.log10(20000.0) - np.log10(20.0)) * 100.0
+    assert np.abs(got[:, 0] - xpos).max() <= 1e-9
