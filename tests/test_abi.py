@@ -72,19 +72,28 @@ def test_corpus_gate_host_helpers_match_oracle(oracle):
     assert ssa.corpus_loudness_range(z) == 0.0
 
 
-def build_c_client(tmp_path):
-    """gcc -std=c99 on tests/cabi/cabi_client.c against the header and the in-tree library."""
+def build_c_client(tmp_path, name="cabi_client", env=None):
+    """gcc -std=c99 on tests/cabi/<name>.c against the header and the in-tree library."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "cabi_client")
+    exe = str(tmp_path / name)
     L.lib()                                              # builds the library on demand
     libdir = os.path.dirname(L.LIB_PATH)
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
-                           os.path.join(root, "tests", "cabi", "cabi_client.c"), "-o", exe,
+                           os.path.join(root, "tests", "cabi", name + ".c"), "-o", exe,
                            "-L", libdir, "-lsoundscope_hip", "-lm", "-Wl,-rpath," + libdir])
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=env)
     assert out.returncode == 0, out.stderr
     return dict(kv.split("=", 1) for kv in re.findall(r'(\w+=(?:"[^"]*"|\S+))', out.stdout))
+
+
+def test_c99_batch_client_links_and_fails_loudly_without_device(tmp_path):
+    """The batch / corpus-gate client (tests/cabi/cabi_batch.c) compiles as strict C99 against the header, links against
+    the in-tree library, and without a GPU `ss_batch_create` returns SS_ERR_DEVICE."""
+    kv = build_c_client(tmp_path, "cabi_batch")
+    assert kv["abi"] == "1" and kv["sizeof_cfg"] == "48" and kv["sizeof_result"] == "56"
+    if int(kv["devices"]) == 0:
+        assert int(kv["create"]) == L.SS_ERR_DEVICE
 
 
 def test_c99_client_links_and_fails_loudly_without_device(tmp_path):

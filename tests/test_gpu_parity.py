@@ -3,6 +3,8 @@
 Bars (BASELINE.json north_star): min-max decimation bit-exact; FFT magnitudes, LUFS and
 true peak within +-0.01 dB / 1e-4 relative.  The spectrum metric is `conftest.db_close`.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -517,6 +519,57 @@ def test_c99_client_runs_a_tick(oracle, tmp_path):
     assert abs(float(kv["gain_db"]) - app.fft_gain_compensation_db) <= TOL_DB
     assert rel_close(float(kv["true_peak_l"]), max(app.analyzer.meter.true_peak(0), app.analyzer.meter.sample_peak(0)), 2e-4)
     assert float(kv["true_peak_r"]) == 0.0
+
+
+def test_c99_batch_client_equals_the_python_path_and_the_oracle(oracle, tmp_path):
+    """tests/cabi/cabi_batch.c (plain C: batch, one pass in overlap mode 2, the corpus gate queued on the device): the
+    numbers it prints are the numbers the ctypes mirror gets for the same synthetic batch, and stream 0 / the corpus gate
+    equal the oracle's."""
+    from test_abi import build_c_client
+    kv = build_c_client(tmp_path, "cabi_batch")
+    assert int(kv["create"]) == 0 and int(kv["run"]) == 0 and int(kv["overlap"]) == 2
+    b = ssa.Batch(48000, 2, 16, 48000 * 3, 4096, 1024, flags=L.SS_BATCH_ALL)
+    b.synthesize(0x5EED0000, 0); b.run(); b.sync()
+    res = b.results()
+    assert float(kv["i0"]) == pytest.approx(res[0].integrated_lufs, abs=1e-11)
+    assert float(kv["i15"]) == pytest.approx(res[15].integrated_lufs, abs=1e-11)
+    assert float(kv["lra7"]) == pytest.approx(res[7].loudness_range, abs=1e-11)
+    tp, sp = b.peaks(5)
+    assert float(kv["tp5l"]) == pytest.approx(tp[0], abs=1e-9) and float(kv["tp5r"]) == pytest.approx(tp[1], abs=1e-9)
+    assert float(kv["sp5l"]) == pytest.approx(sp[0], abs=1e-9)
+    hb, hs = b.histograms()
+    assert int(kv["blocks"]) == int(hb.sum())
+    assert float(kv["gate_lufs"]) == pytest.approx(oracle.gated_loudness_hist(hb), abs=1e-9)
+    assert float(kv["host_gate"]) == pytest.approx(float(kv["gate_lufs"]), abs=1e-9)
+    assert float(kv["gate_lra"]) == pytest.approx(oracle.loudness_range_hist(hs), abs=1e-9)
+    m = oracle.Meter(2, 48000); m.add_frames(b.download_input(0))
+    assert lufs_close(float(kv["i0"]), m.integrated())
+
+
+def test_c99_batch_client_as_two_ranks_without_a_launcher(oracle, tmp_path):
+    """The same C program twice, RANK 0 and 1 of a WORLD_SIZE 2 job described by plain environment variables (no torchrun,
+    no Python in the ranks), both on this GPU with the host-TCP transport: each analyses its 16-stream shard, the library
+    sums the histograms across the ranks, and both report the gate of the 32-stream corpus — equal to the oracle's gate on
+    the summed histograms of one 32-stream batch."""
+    import subprocess
+    from test_abi import build_c_client
+    build_c_client(tmp_path, "cabi_batch")                       # builds the executable (and runs it once alone)
+    exe = str(tmp_path / "cabi_batch")
+    env = dict(os.environ, WORLD_SIZE="2", SS_COMM_TRANSPORT="host-tcp", SS_COMM_FILE=str(tmp_path / "ranks.rdzv"))
+    procs = [subprocess.Popen([exe], env=dict(env, RANK=str(r), LOCAL_RANK="0"), stdout=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    import re
+    kvs = [dict(kv.split("=", 1) for kv in re.findall(r'(\w+=(?:"[^"]*"|\S+))', o)) for o in outs]
+    for kv in kvs:
+        assert int(kv["comm"]) == 0 and int(kv["ranks"]) == 2 and int(kv["run"]) == 0, kv
+    assert kvs[0]["gate_lufs"] == kvs[1]["gate_lufs"] and kvs[0]["gate_lra"] == kvs[1]["gate_lra"] and kvs[0]["blocks"] == kvs[1]["blocks"]
+    b = ssa.Batch(48000, 2, 32, 48000 * 3, 4096, 1024, flags=L.SS_BATCH_LUFS)
+    b.synthesize(0x5EED0000, 0); b.run(); b.sync()
+    hb, hs = b.histograms()
+    assert int(kvs[0]["blocks"]) == int(hb.sum())
+    assert float(kvs[0]["gate_lufs"]) == pytest.approx(oracle.gated_loudness_hist(hb), abs=1e-9)
+    assert float(kvs[0]["gate_lra"]) == pytest.approx(oracle.loudness_range_hist(hs), abs=1e-9)
+    assert kvs[0]["i0"] != kvs[1]["i0"]                          # different shards
 
 
 def test_two_handles_and_threads_do_not_interfere(oracle):
