@@ -1,0 +1,452 @@
+// ss_analyzer.cpp — the Analyzer mirror of include/soundscope_hip.h: one entry point per Rust method of
+// `pub struct Analyzer` (/root/reference/src/analyzer.rs:29-183) plus get_mid_and_side_samples
+// (/root/reference/src/audio_player.rs:400-419).  Host logic only: argument validation with the reference's error
+// order, device-resident meter state, launches.  No CPU compute path.
+#include "ss_host.h"
+
+using namespace ssh;
+
+namespace ssh {
+
+// EbuR128::new + assignment (analyzer.rs:49-53): the new meter replaces the old one only when every fallible step
+// has succeeded — on failure the handle keeps its previous meter (only sample_rate has changed by then).
+SS_HIDDEN int handle_make_meter(ss_analyzer *h, uint32_t channels, uint32_t rate)
+{
+    int rc = meter_args_ok(channels, rate);
+    if (rc) return rc;
+    const int tp_factor = h->tp_cfg ? h->tp_cfg : sst::true_peak_factor_for_rate(rate);
+    TdTables *td = nullptr;
+    rc = get_td_tables(rate, tp_factor, channels, &td);
+    if (rc) return rc;
+    const uint64_t s100 = (rate + 5) / 10;
+    uint64_t ring_frames = (uint64_t)rate * 3000 / 1000;
+    if (ring_frames % s100) ring_frames += s100 - ring_frames % s100;
+    DevBuf<ssk::TdState> state;
+    DevBuf<uint64_t> hist;
+    DevBuf<double> sub, ring, weights, out2, ring_scratch;
+    DevBuf<uint32_t> counts;
+    HIPCHK(state.alloc(1));
+    HIPCHK(hist.alloc(2 * sst::kHistBins));
+    HIPCHK(sub.alloc((size_t)ss_analyzer::kSubCap * channels));
+    HIPCHK(ring.alloc(ring_frames * channels));
+    HIPCHK(counts.alloc(2));
+    HIPCHK(out2.alloc(2));
+    HIPCHK(ring_scratch.alloc(128));
+    std::vector<double> w(channels);
+    sst::channel_weights(channels, w.data());
+    HIPCHK(weights.upload(w));
+    // commit
+    h->channels = channels; h->meter_rate = rate; h->tp_factor = tp_factor; h->tp_cfg_applied = h->tp_cfg; h->td = td; h->ring_frames = ring_frames;
+    h->state.swap(state); h->hist.swap(hist); h->sub.swap(sub); h->ring.swap(ring); h->counts.swap(counts);
+    h->out2.swap(out2); h->ring_scratch.swap(ring_scratch); h->weights.swap(weights);
+    h->meter_ok = true;
+    return SS_OK;
+}
+
+int handle_reset(ss_analyzer *h)
+{
+    if (!h->meter_ok) return SS_OK;
+    if (h->tp_cfg != h->tp_cfg_applied) {        // ss_analyzer_set_true_peak_factor since the meter was built
+        HIPCHK(hipStreamSynchronize(h->stream));
+        int rc = handle_make_meter(h, h->channels, h->meter_rate);
+        if (rc) return rc;
+    }
+    HIPCHK(hipMemsetAsync(h->state.p, 0, sizeof(ssk::TdState), h->stream));
+    HIPCHK(hipMemsetAsync(h->hist.p, 0, h->hist.n * sizeof(uint64_t), h->stream));
+    HIPCHK(hipMemsetAsync(h->sub.p, 0, h->sub.n * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(h->ring.p, 0, h->ring.n * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(h->counts.p, 0, 2 * sizeof(uint32_t), h->stream));
+    h->frames_fed = 0;
+    return SS_OK;
+}
+
+}  // namespace ssh
+
+extern "C" {
+
+int ss_analyzer_create(uint32_t channels, uint32_t rate, ss_analyzer **out)
+{
+    if (!out) return SS_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (require_device()) return SS_ERR_DEVICE;
+    // destroyed (stream included) on every early return
+    std::unique_ptr<ss_analyzer, decltype(&ss_analyzer_destroy)> h(new ss_analyzer(), &ss_analyzer_destroy);
+    h->device = current_device();
+    h->rate = rate;
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(h->in.alloc(32768));
+    HIPCHK(h->fft_out.alloc(16385));
+    int rc = handle_make_meter(h.get(), channels, rate);
+    if (rc) return rc;
+    rc = handle_reset(h.get());
+    if (rc) return rc;
+    *out = h.release();
+    return SS_OK;
+}
+
+void ss_analyzer_destroy(ss_analyzer *h)
+{
+    SS_ON_DEVICE(h);
+    if (!h) return;
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    delete h;
+}
+
+int ss_analyzer_configure(ss_analyzer *h, uint32_t channels, uint32_t rate)
+{
+    SS_ON_DEVICE(h);
+    if (!h) return SS_ERR_INVALID_ARG;
+    h->rate = rate;                         // analyzer.rs:50: before the fallible call
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int rc = handle_make_meter(h, channels, rate);
+    if (rc) return rc;
+    return handle_reset(h);
+}
+
+int ss_analyzer_set_true_peak_factor(ss_analyzer *h, int factor)
+{
+    SS_ON_DEVICE(h);
+    if (!h || (factor != 0 && factor != 2 && factor != 4)) return SS_ERR_INVALID_ARG;
+    h->tp_cfg = factor;
+    return SS_OK;
+}
+
+int ss_get_fft(const ss_analyzer *hc, const float *samples, size_t n,
+               double *out_xy, size_t cap_pairs, size_t *out_n)
+{
+    SS_ON_DEVICE(hc);
+    ss_analyzer *h = const_cast<ss_analyzer *>(hc);
+    if (out_n) *out_n = 0;
+    if (!h || (!samples && n) || !out_xy) return SS_ERR_INVALID_ARG;
+    // samples_fft_to_spectrum checks, in the crate's order, applied to the
+    // windowed samples (hann_window runs first, analyzer.rs:57)
+    if (n < 2) return SS_ERR_TOO_FEW_SAMPLES;
+    const bool pow2 = is_pow2(n);
+    if (n > 32768 && pow2) return SS_ERR_UNSUPPORTED;
+    {
+        // w[i] == 0 turns an infinite sample into NaN (0 * inf); only the first few
+        // window entries can be exactly zero
+        bool any_nan = false, any_inf = false;
+        const std::vector<float> *win = nullptr;
+        std::vector<float> win_local;
+        for (size_t i = 0; i < n; i++) {
+            const float x = samples[i];
+            if (std::isnan(x)) { any_nan = true; continue; }
+            if (!std::isinf(x)) continue;
+            if (!win) {
+                if (pow2) {
+                    FftTables *wt = nullptr;
+                    int rc = get_fft_tables(n, &wt);
+                    if (rc) return rc;
+                    win = &wt->window_host;
+                } else {
+                    win_local = sst::hann_window(n);
+                    win = &win_local;
+                }
+            }
+            if ((*win)[i] == 0.0f) any_nan = true; else any_inf = true;
+        }
+        if (any_nan) return SS_ERR_NAN;
+        if (any_inf) return SS_ERR_INFINITY;
+    }
+    if (!pow2) return SS_ERR_NOT_POW2;
+    if (20000.0f > (float)h->rate / 2.0f) return SS_ERR_FREQ_LIMIT;
+
+    FftTables *ft; BinTables *bt;
+    int rc = get_fft_tables(n, &ft);
+    if (rc) return rc;
+    rc = get_bin_tables(h->rate, n, &bt);
+    if (rc) return rc;
+    if (bt->count > cap_pairs) return SS_ERR_CAPACITY;
+    if (bt->count == 0) return SS_OK;
+
+    HIPCHK(hipMemcpyAsync(h->in.p, samples, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    ssk::FftBatchParams p{};
+    p.pcm = h->in.p; p.out = h->fft_out.p;
+    p.window = ft->window.p; p.half_window = ft->half_window.p;
+    p.tw_n = ft->tw_n.p; p.tw_256 = ft->tw_256.p; p.pink = nullptr;
+    p.frames_per_stream = n; p.first_start = 0; p.n_streams = 1; p.channels = 1;
+    p.n_windows = 1; p.hop = 0; p.n = (uint32_t)n;
+    p.first_bin = (uint32_t)bt->first; p.n_bins = (uint32_t)bt->count; p.bin_stride = p.n_bins; p.windows_per_block = 1;
+    p.db_offset = (float)(20.0 * std::log10(4.0 / (double)n));
+    if (n == 16384) {
+        p.tw_core = ft->core_tw4096; p.tw_256 = ft->core_tw256;
+        HIPCHK(ssk::launch_fft16k(p, 0, h->stream));
+    } else {
+        HIPCHK(ssk::launch_fft_generic(p, 0, h->stream));
+    }
+    std::vector<float> db(bt->count);
+    HIPCHK(hipMemcpyAsync(db.data(), h->fft_out.p, bt->count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < bt->count; i++)
+        if (std::isnan(db[i]) || std::isinf(db[i])) return SS_ERR_SCALING;
+    // analyzer.rs:75-102 in f64: + pink compensation, log-x chart position
+    for (size_t i = 0; i < bt->count; i++) {
+        out_xy[2 * i] = bt->chart_x[i];
+        out_xy[2 * i + 1] = (double)db[i] + bt->pink[i];
+    }
+    if (out_n) *out_n = bt->count;
+    return SS_OK;
+}
+
+// get_waveform's shape (analyzer.rs:108-118): W = (window_s * 1000.) as usize, and the number of
+// bins whose start floor(i * spp) is still inside the buffer
+}  // extern "C"
+void ssh::waveform_shape(size_t n, double waveform_window, size_t *window_out, size_t *bins_out)
+{
+    const double wd = waveform_window * 1000.0;
+    // Rust `as usize`: saturating, NaN -> 0
+    size_t window = (wd != wd || wd <= 0.0) ? 0 : (wd >= 1.8446744073709552e19 ? SIZE_MAX : (size_t)wd);
+    size_t bins = window;
+    if (window != 0 && n != 0 && window > n) {
+        // first i with floor(i*spp) >= n; start = floor(i * spp) is monotone
+        const double spp = (double)n / (double)window;
+        size_t lo = 0, hi = window;
+        while (lo < hi) {
+            size_t mid = lo + (hi - lo) / 2;
+            if ((size_t)((double)mid * spp) >= n) hi = mid; else lo = mid + 1;
+        }
+        bins = lo;
+    }
+    if (window == 0 || n == 0) bins = 0;
+    *window_out = window; *bins_out = bins;
+}
+extern "C" {
+
+int ss_get_waveform(const float *samples, size_t n, double waveform_window,
+                    double *out_xy, size_t cap_pairs, size_t *out_n)
+{
+    if (out_n) *out_n = 0;
+    if ((!samples && n) || (!out_xy && cap_pairs)) return SS_ERR_INVALID_ARG;
+    if (require_device()) return SS_ERR_DEVICE;
+    size_t window, bins;
+    waveform_shape(n, waveform_window, &window, &bins);
+    if (window == 0 || n == 0) return SS_OK;        // loop body never pushes a point
+    if (bins > 0xFFFFFFFFull) return SS_ERR_UNSUPPORTED;
+    if (2 * bins > cap_pairs) return SS_ERR_CAPACITY;
+    Scratch &c = scratch();
+    if (!c.stream) HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    HIPCHK(c.in.ensure(n));
+    HIPCHK(c.out.ensure(2 * bins));
+    HIPCHK(hipMemcpyAsync(c.in.p, samples, n * sizeof(float), hipMemcpyHostToDevice, c.stream));
+    ssk::WaveParams p{};
+    p.pcm = c.in.p; p.stream_stride = n; p.n_samples = n; p.n_streams = 1;
+    p.window = (uint32_t)window; p.out = c.out.p; p.out_stride = 2 * bins;
+    if (window > 0xFFFFFFFFull) return SS_ERR_UNSUPPORTED;
+    HIPCHK(ssk::launch_waveform(p, c.stream));
+    std::vector<float> mm(2 * bins);
+    HIPCHK(hipMemcpyAsync(mm.data(), c.out.p, 2 * bins * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    for (size_t i = 0; i < bins; i++) {
+        out_xy[4 * i + 0] = (double)i; out_xy[4 * i + 1] = (double)mm[2 * i];
+        out_xy[4 * i + 2] = (double)i; out_xy[4 * i + 3] = (double)mm[2 * i + 1];
+    }
+    if (out_n) *out_n = 2 * bins;
+    return SS_OK;
+}
+
+int ss_mid_side(const float *interleaved, size_t n, float *mid, float *side, size_t *out_frames)
+{
+    if (out_frames) *out_frames = 0;
+    const size_t frames = n / 2;
+    if (!frames) return SS_OK;
+    if (!interleaved || !mid || !side) return SS_ERR_INVALID_ARG;
+    if (require_device()) return SS_ERR_DEVICE;
+    Scratch &c = scratch();
+    if (!c.stream) HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    HIPCHK(c.in.ensure(2 * frames));
+    HIPCHK(c.out.ensure(2 * frames));
+    HIPCHK(hipMemcpyAsync(c.in.p, interleaved, 2 * frames * sizeof(float), hipMemcpyHostToDevice, c.stream));
+    HIPCHK(ssk::launch_mid_side(c.in.p, frames, c.out.p, c.out.p + frames, c.stream));
+    HIPCHK(hipMemcpyAsync(mid, c.out.p, frames * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipMemcpyAsync(side, c.out.p + frames, frames * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    if (out_frames) *out_frames = frames;
+    return SS_OK;
+}
+
+// add_frames_f32 on the handle's meter.  on_device: `samples` already lives in HBM (tick drivers):
+// no staging copy and no synchronisation — everything is only enqueued on the handle's stream.
+}  // extern "C"
+int ssh::add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool on_device)
+{
+    SS_ON_DEVICE(h);
+    if (!h) return SS_ERR_INVALID_ARG;
+    if (!h->meter_ok) return SS_ERR_INVALID_MODE;
+    if (n == 0) return SS_OK;
+    if (!samples) return SS_ERR_INVALID_ARG;
+    const uint32_t C = h->channels;
+    if (n % C) return SS_ERR_NOMEM;             // add_frames_f32: partial frame
+    const uint64_t S = h->td->host.s100;
+    const double *he, *hb;
+    int rc = get_hist_tables(&he, &hb);
+    if (rc) return rc;
+    // pieces of at most 32 sub-blocks so the sub-block ring (96) always holds the
+    // 30-block history a short-term block needs
+    const uint64_t piece_frames = 32 * S;
+    uint64_t frames = n / C, done = 0;
+    while (done < frames) {
+        const uint64_t take = frames - done < piece_frames ? frames - done : piece_frames;
+        if (!on_device) {
+            HIPCHK(h->in.ensure(take * C));
+            HIPCHK(hipMemcpyAsync(h->in.p, samples + done * C, take * C * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        }
+        ssk::TdParams p{};
+        p.pcm = on_device ? samples + done * C : h->in.p; p.stream_stride = 0; p.n_frames = take; p.n_streams = 1; p.channels = C;
+        p.k = h->td->dev.p; p.state = h->state.p;
+        p.subblocks = h->sub.p; p.sub_stride = 0; p.sub_cap = ss_analyzer::kSubCap;
+        p.ring = h->ring.p; p.ring_frames = h->ring_frames; p.tp_factor = h->tp_factor;
+        p.s100 = (uint32_t)S; p.nseg = 1; p.seg_sub = 0; p.warm_sub = 0;
+        HIPCHK(ssk::launch_time_domain(p, h->stream));
+        const uint64_t sb0 = h->frames_fed / S, sb1 = (h->frames_fed + take) / S;
+        if (sb1 > sb0) {
+            ssk::FinalizeParams f{};
+            f.k = h->td->dev.p; f.subblocks = h->sub.p; f.sub_stride = 0; f.sub_cap = ss_analyzer::kSubCap;
+            f.hist_energies = he; f.hist_bounds = hb; f.weights = h->weights.p;
+            f.hist = h->hist.p; f.corpus_hist = nullptr; f.n_streams = 1; f.channels = C;
+            f.sub_begin = sb0; f.sub_end = sb1;
+            f.out_integrated = nullptr; f.out_lra = nullptr; f.out_counts = h->counts.p;
+            HIPCHK(ssk::launch_finalize(f, h->stream));
+        }
+        // the staging buffer is reused by the next piece
+        if (!on_device) HIPCHK(hipStreamSynchronize(h->stream));
+        h->frames_fed += take;
+        done += take;
+    }
+    return SS_OK;
+}
+extern "C" {
+
+int ss_add_samples(ss_analyzer *h, const float *samples, size_t n)
+{
+    SS_ON_DEVICE(h);
+    return add_samples_impl(h, samples, n, false);
+}
+
+void ss_reset(ss_analyzer *h)
+{
+    SS_ON_DEVICE(h);
+    if (h) (void)handle_reset(h);
+}
+
+// energy of the last `frames` frames of the filtered ring -> out2[1] = loudness (enqueue only)
+}  // extern "C"
+int ssh::ring_loudness_enqueue(ss_analyzer *h, uint64_t frames)
+{
+    SS_ON_DEVICE(h);
+    HIPCHK(ssk::launch_ring_energy(h->ring.p, h->ring_frames, h->channels, h->frames_fed, frames,
+                                   h->weights.p, h->out2.p, h->ring_scratch.p, h->stream));
+    return SS_OK;
+}
+extern "C" {
+
+static int ring_loudness(ss_analyzer *h, uint64_t frames, double *out)
+{
+    SS_ON_DEVICE(h);
+    if (!h || !out) return SS_ERR_INVALID_ARG;
+    if (!h->meter_ok) return SS_ERR_INVALID_MODE;
+    if (frames > h->ring_frames) return SS_ERR_INVALID_MODE;
+    int rc = ring_loudness_enqueue(h, frames);
+    if (rc) return rc;
+    double r[2];
+    HIPCHK(hipMemcpyAsync(r, h->out2.p, sizeof r, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *out = r[1];
+    return SS_OK;
+}
+
+int ss_get_shortterm_lufs(ss_analyzer *h, double *out)
+{
+    SS_ON_DEVICE(h);
+    if (!h || !h->meter_ok) return h ? SS_ERR_INVALID_MODE : SS_ERR_INVALID_ARG;
+    return ring_loudness(h, (uint64_t)h->td->host.s100 * 30, out);
+}
+
+int ss_get_momentary_lufs(ss_analyzer *h, double *out)
+{
+    SS_ON_DEVICE(h);
+    if (!h || !h->meter_ok) return h ? SS_ERR_INVALID_MODE : SS_ERR_INVALID_ARG;
+    return ring_loudness(h, (uint64_t)h->td->host.s100 * 4, out);
+}
+
+static int hist_eval(ss_analyzer *h, double r[2])
+{
+    SS_ON_DEVICE(h);
+    if (!h) return SS_ERR_INVALID_ARG;
+    if (!h->meter_ok) return SS_ERR_INVALID_MODE;
+    const double *he, *hb;
+    int rc = get_hist_tables(&he, &hb);
+    if (rc) return rc;
+    HIPCHK(ssk::launch_hist_eval(h->hist.p, he, hb, h->out2.p, h->stream));
+    HIPCHK(hipMemcpyAsync(r, h->out2.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SS_OK;
+}
+
+int ss_get_integrated_lufs(ss_analyzer *h, double *out)
+{
+    SS_ON_DEVICE(h);
+    if (!out) return SS_ERR_INVALID_ARG;
+    double r[2];
+    int rc = hist_eval(h, r);
+    if (rc) return rc;
+    *out = r[0];
+    return SS_OK;
+}
+
+int ss_get_loudness_range(ss_analyzer *h, double *out)
+{
+    SS_ON_DEVICE(h);
+    if (!out) return SS_ERR_INVALID_ARG;
+    double r[2];
+    int rc = hist_eval(h, r);
+    if (rc) return rc;
+    *out = r[1];
+    return SS_OK;
+}
+
+static int read_peaks(ss_analyzer *h, uint32_t ch, double *sample_pk, double *true_pk)
+{
+    SS_ON_DEVICE(h);
+    if (!h) return SS_ERR_INVALID_ARG;
+    if (!h->meter_ok) return SS_ERR_INVALID_MODE;
+    if (ch >= h->channels) return SS_ERR_INVALID_CHANNEL;
+    float sp, tp;
+    HIPCHK(hipMemcpyAsync(&sp, &h->state.p->sample_peak[ch], sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&tp, &h->state.p->true_peak[ch], sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (sample_pk) *sample_pk = (double)sp;
+    if (true_pk) *true_pk = (double)(tp > sp ? tp : sp);    // true_peak(): max(true, sample)
+    return SS_OK;
+}
+
+int ss_get_true_peak(ss_analyzer *h, double *left, double *right)
+{
+    SS_ON_DEVICE(h);
+    if (!left || !right) return SS_ERR_INVALID_ARG;
+    double l, r;
+    int rc = read_peaks(h, 0, nullptr, &l);     // analyzer.rs:160
+    if (rc) return rc;
+    rc = read_peaks(h, 1, nullptr, &r);         // analyzer.rs:161
+    if (rc) return rc;
+    *left = l; *right = r;
+    return SS_OK;
+}
+
+int ss_get_true_peak_channel(ss_analyzer *h, uint32_t channel, double *out)
+{
+    SS_ON_DEVICE(h);
+    if (!out) return SS_ERR_INVALID_ARG;
+    return read_peaks(h, channel, nullptr, out);
+}
+
+int ss_get_sample_peak_channel(ss_analyzer *h, uint32_t channel, double *out)
+{
+    SS_ON_DEVICE(h);
+    if (!out) return SS_ERR_INVALID_ARG;
+    return read_peaks(h, channel, out, nullptr);
+}
+
+uint32_t ss_sample_rate(const ss_analyzer *h) { return h ? h->rate : 0; }
+
+}  // extern "C"

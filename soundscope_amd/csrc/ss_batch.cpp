@@ -1,0 +1,988 @@
+// ss_batch.cpp — the batch extension of the C ABI (NOT in the reference): many streams resident in HBM analysed in one
+// pass — the data-parallel form of receive_audio_file + analyze_audio_file_samples
+// (/root/reference/src/tui.rs:1207-1241, :1482-1552) over a corpus — plus the render-side reductions (N3) and the
+// one-shot calculate_integrated_lufs (/root/reference/src/analyzer.rs:170-182), which runs the batch path on one stream.
+#include "ss_host.h"
+
+using namespace ssh;
+
+// ============================================================================
+//  batch
+// ============================================================================
+struct ss_batch {
+    int device = 0;             // the HIP device this batch lives on
+    ss_batch_config cfg{};
+    ss_batch_layout lay{};
+    hipStream_t stream = nullptr;
+    int tp_factor = 0;
+    int fft_mode = 1;           // generic-kernel mode (1 mid/side, 2 per channel)
+    bool fft_fast = false;      // N=4096 stereo kernel
+    bool fft_pairw = false;     // N=4096, hop 1024, mono / per-channel: two windows per transform
+    uint64_t first_start = 0;
+    uint32_t wave_window = 0;
+    uint32_t windows_per_block = 16;
+    uint32_t td_nseg = 1, td_seg_sub = 0;
+    bool wave_fused = false;     // decimation runs inside the time-domain kernel
+    uint32_t wave_halo = 0;
+    FftTables *ft = nullptr;
+    BinTables *bt = nullptr;
+    TdTables *td = nullptr;
+    DevBuf<float> pcm, fft, wave;
+    DevBuf<ssk::TdState> state;
+    DevBuf<double> sub, weights, integrated, lra, out2;
+    DevBuf<uint64_t> hist, corpus;
+    DevBuf<uint32_t> counts;
+    DevBuf<unsigned char> raw;      // device staging of raw PCM for the asynchronous ingest
+    // ragged batches (ss_batch_set_lengths): per-stream frames / windows / sub-blocks / decimation bins
+    bool ragged = false;
+    std::vector<uint64_t> frames_h, wave_samples_h;
+    std::vector<uint32_t> windows_h, sub_h, wave_window_h, wave_bins_h;
+    DevBuf<uint64_t> frames_d, wave_samples_d;
+    DevBuf<uint32_t> windows_d, sub_d, wave_window_d;
+    // render-side reductions (N3)
+    DevBuf<float> render_spec, render_wave;
+    DevBuf<uint32_t> col_start;
+    uint32_t render_cols = 0, render_wave_cols = 0;
+    // opt-in (SS_BATCH_OVERLAP=1): the spectrum kernel on a second stream beside the time-domain chain
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int overlap = 0;                  // 0 sequential, 1 the spectrum kernel beside the time-domain chain, 2 beside its tail only
+    bool timing = false;
+    hipEvent_t ev[2 * SS_KERNEL_COUNT] = {};
+    bool ev_ready = false;
+    double t_ms[SS_KERNEL_COUNT] = {0, 0, 0, 0};
+    uint64_t t_n[SS_KERNEL_COUNT] = {0, 0, 0, 0};
+    bool pending_events = false;
+};
+
+namespace ssi {
+void *batch_corpus_device(ss_batch *b) { return b ? b->corpus.p : nullptr; }
+hipStream_t batch_stream(ss_batch *b) { return b ? b->stream : nullptr; }
+int batch_device(const ss_batch *b) { return b ? b->device : 0; }
+}  // namespace ssi
+
+namespace {
+
+int batch_collect_timing(ss_batch *b)
+{
+    if (!b->pending_events) return SS_OK;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (int k = 0; k < SS_KERNEL_COUNT; k++) {
+        float ms = 0.f;
+        hipError_t e = hipEventElapsedTime(&ms, b->ev[2 * k], b->ev[2 * k + 1]);
+        if (e == hipSuccess) { b->t_ms[k] += ms; b->t_n[k]++; }
+    }
+    b->pending_events = false;
+    return SS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
+{
+    if (!cfg || !out) return SS_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (require_device()) return SS_ERR_DEVICE;
+    if (cfg->n_streams == 0 || cfg->frames_per_stream == 0) return SS_ERR_INVALID_ARG;
+    if ((cfg->flags & SS_BATCH_ALL) == 0) return SS_ERR_INVALID_ARG;
+    // destroyed (streams and events included) on every early return
+    std::unique_ptr<ss_batch, decltype(&ss_batch_destroy)> b(new ss_batch(), &ss_batch_destroy);
+    b->device = current_device();
+    b->cfg = *cfg;
+    const uint32_t C = cfg->channels;
+    const uint64_t F = cfg->frames_per_stream;
+    if (C == 0 || C > 64) return SS_ERR_NOMEM;
+    if (cfg->flags & (SS_BATCH_LUFS | SS_BATCH_TRUE_PEAK)) {
+        int rc = meter_args_ok(C, cfg->sample_rate);
+        if (rc) return rc;
+    }
+    if (cfg->true_peak_factor != 0 && cfg->true_peak_factor != 2 && cfg->true_peak_factor != 4) return SS_ERR_INVALID_ARG;
+    HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    ss_batch_layout &L = b->lay;
+    L.input_bytes = (uint64_t)cfg->n_streams * F * C * sizeof(float);
+    HIPCHK(b->pcm.alloc((size_t)cfg->n_streams * F * C));
+
+    if (cfg->flags & SS_BATCH_FFT) {
+        const size_t n = cfg->fft_n;
+        if (n < 2) return SS_ERR_TOO_FEW_SAMPLES;
+        if (!is_pow2(n)) return SS_ERR_NOT_POW2;
+        if (n > 32768) return SS_ERR_UNSUPPORTED;
+        if (20000.0f > (float)cfg->sample_rate / 2.0f) return SS_ERR_FREQ_LIMIT;
+        if (cfg->hop_frames == 0) return SS_ERR_INVALID_ARG;
+        int rc = get_fft_tables(n, &b->ft);
+        if (rc) return rc;
+        rc = get_bin_tables(cfg->sample_rate, n, &b->bt);
+        if (rc) return rc;
+        // cadence of analyze_audio_file_samples (tui.rs:1482-1526): window [p-N, p) at
+        // p = k*hop, skipped when p - N == 0 (saturating_sub) => k from N/hop + 1
+        const uint64_t hop = cfg->hop_frames;
+        const uint64_t k_min = n / hop + 1, k_max = F / hop;
+        L.n_windows = k_max >= k_min ? (uint32_t)(k_max - k_min + 1) : 0;
+        b->first_start = k_min * hop - n;
+        L.fft_channels = (C == 2) ? 2 : C;
+        b->fft_mode = (C == 2) ? 1 : (C == 1 ? 0 : 2);
+        L.n_bins = (uint32_t)b->bt->count;
+        L.first_bin = (uint32_t)b->bt->first;
+        b->fft_fast = (C == 2 && n == 4096 && hop % 256 == 0);
+        b->fft_pairw = (C != 2 && n == 4096 && hop == 1024);
+#ifdef SS_TUNING        // development builds only: the shipped library takes no kernel selection from the environment
+        if (std::getenv("SS_FFT_NO_PAIRW")) b->fft_pairw = false;
+#endif
+        {
+            // windows per workgroup: long runs amortise the per-workgroup constants and the 3-hop halo,
+            // but keep >= ~4096 workgroups (8 rounds of the 512 resident ones) for load balance
+            uint32_t tgt = (4096u + cfg->n_streams - 1) / cfg->n_streams;
+            if (tgt > L.n_windows / 16) tgt = L.n_windows / 16;
+            if (tgt < 1) tgt = 1;
+            uint32_t wpb = (L.n_windows + tgt - 1) / tgt;
+            wpb = (wpb + 1) & ~1u;
+            b->windows_per_block = wpb < 2 ? 2 : wpb;
+        }
+#ifdef SS_TUNING
+        if (const char *e = std::getenv("SS_FFT_WPB")) { int v = std::atoi(e); if (v >= 2 && v <= 4096) b->windows_per_block = (uint32_t)(v & ~1); }
+#endif
+        // Rows start 16-byte aligned (16-byte stores).  Padding them to whole 128-byte lines lifts a pure streaming-store
+        // kernel with this row pattern from 3.7 to 4.4 TB/s (tools/ubench_fftio.hip) but does nothing for the real kernel
+        // (A/B in one process: 3.14 vs 3.12 ms), so the rows stay compact.  -DSS_FFT_ROW_ALIGN=32u rebuilds the padded form.
+#ifndef SS_FFT_ROW_ALIGN
+#define SS_FFT_ROW_ALIGN 4u
+#endif
+        L.fft_bin_stride = (L.n_bins + (SS_FFT_ROW_ALIGN - 1u)) & ~(SS_FFT_ROW_ALIGN - 1u);
+        L.fft_bytes = (uint64_t)cfg->n_streams * L.n_windows * L.fft_channels * L.fft_bin_stride * sizeof(float);
+        HIPCHK(b->fft.alloc((size_t)(L.fft_bytes / sizeof(float))));
+    }
+    if (cfg->flags & (SS_BATCH_LUFS | SS_BATCH_TRUE_PEAK)) {
+        b->tp_factor = (cfg->flags & SS_BATCH_TRUE_PEAK)
+                           ? (cfg->true_peak_factor ? cfg->true_peak_factor : sst::true_peak_factor_for_rate(cfg->sample_rate))
+                           : 0;
+        int rc = get_td_tables(cfg->sample_rate, b->tp_factor, C, &b->td);
+        if (rc) return rc;
+        const uint64_t S = b->td->host.s100;
+        L.n_subblocks = (uint32_t)(F / S);
+        HIPCHK(b->state.alloc(cfg->n_streams));
+        HIPCHK(b->sub.alloc((size_t)cfg->n_streams * (L.n_subblocks ? L.n_subblocks : 1) * C));
+        HIPCHK(b->hist.alloc((size_t)cfg->n_streams * 2 * sst::kHistBins));
+        HIPCHK(b->corpus.alloc(2 * sst::kHistBins));
+        HIPCHK(b->integrated.alloc(cfg->n_streams));
+        HIPCHK(b->lra.alloc(cfg->n_streams));
+        HIPCHK(b->counts.alloc((size_t)cfg->n_streams * 2));
+        HIPCHK(b->out2.alloc(2));
+        std::vector<double> w(C);
+        sst::channel_weights(C, w.data());
+        HIPCHK(b->weights.upload(w));
+    }
+    if (cfg->flags & SS_BATCH_WAVEFORM) {
+        const double win = cfg->waveform_window > 0.0 ? cfg->waveform_window : (double)F / (double)cfg->sample_rate;
+        const double wd = win * 1000.0;
+        const uint64_t W = (wd != wd || wd <= 0.0) ? 0 : (uint64_t)wd;
+        if (W > 0xFFFFFFFFull) return SS_ERR_UNSUPPORTED;
+        b->wave_window = (uint32_t)W;
+        // points: bins whose start floor(i*spp) < len
+        const uint64_t len = F * C;
+        const double spp = (double)len / (double)W;
+        uint64_t bins = W;
+        if (W > len) {
+            uint64_t lo = 0, hi = W;
+            while (lo < hi) { uint64_t mid = lo + (hi - lo) / 2; if ((uint64_t)((double)mid * spp) >= len) hi = mid; else lo = mid + 1; }
+            bins = lo;
+        }
+        L.n_wave_points = (uint32_t)(2 * bins);
+        HIPCHK(b->wave.alloc((size_t)cfg->n_streams * (W ? 2 * W : 2)));
+        // fuse into the time-domain pass when that pass runs and a bin (plus its shared edge sample)
+        // fits the per-wave halo; otherwise the standalone kernel handles it
+        if (b->td && W > 0 && spp >= 16.0 && spp <= 1000.0 && len < (1ull << 31)) {
+            const uint32_t need = ((uint32_t)std::ceil(spp) + 2 + C - 1) / C;
+            uint32_t halo = need < 24 ? 24 : need;
+            halo = (halo + 3u) & ~3u;
+            if (halo <= 512) { b->wave_fused = true; b->wave_halo = halo; }
+        }
+    }
+    // time segments per stream.  A segment costs a kTdWarmSub-sub-block filter run-in and the chip holds W0
+    // waves at once (LDS per wave grows with channels and halo).  Pick the segment length that maximises
+    //   useful fraction  seg / (seg + warm)  x  fill of the last round  waves / (ceil(waves / W0) W0)
+    // (ranks the measured config-5 sweep seg = 2..13 in the right order; measured within noise for config 3)
+    if (b->td) {
+        const uint32_t nsub = L.n_subblocks;
+        const double W0 = 256.0 * ssk::td_resident_waves_per_cu(C, b->td->host.s100, b->wave_fused ? b->wave_halo : 0);
+        auto score_of = [&](uint32_t seg, uint32_t nseg) {
+            const double waves = (double)cfg->n_streams * nseg;
+            const double useful = nseg > 1 ? (double)seg / (double)(seg + kTdWarmSub) : 1.0;
+            return useful * waves / (std::ceil(waves / W0) * W0);
+        };
+        uint32_t best_seg = 0;
+        double best = nsub ? score_of(nsub, 1) : 0.0;                         // one segment: no run-in
+        for (uint32_t want = 2; want <= nsub; want++) {                     // balanced segments: seg = ceil(nsub / want)
+            const uint32_t seg = (nsub + want - 1) / want;
+            if (seg < kTdWarmSub) break;
+            const double sc = score_of(seg, (nsub + seg - 1) / seg);
+            if (sc > best * 1.0000001) { best = sc; best_seg = seg; }
+        }
+#ifdef SS_TUNING
+        if (const char *e = std::getenv("SS_TD_SEG_SUB")) best_seg = (uint32_t)std::atoi(e);
+#endif
+        if (best_seg >= kTdWarmSub && best_seg < nsub) {
+            b->td_seg_sub = best_seg;
+            b->td_nseg = (nsub + best_seg - 1) / best_seg;
+        } else {
+            b->td_nseg = 1; b->td_seg_sub = 0;
+        }
+    }
+    for (auto &e : b->ev) HIPCHK(hipEventCreate(&e));
+    b->ev_ready = true;
+    *out = b.release();
+    return SS_OK;
+}
+
+void ss_batch_destroy(ss_batch *b)
+{
+    SS_ON_DEVICE(b);
+    if (!b) return;
+    if (b->stream) { (void)hipStreamSynchronize(b->stream); }
+    if (b->stream2) { (void)hipStreamSynchronize(b->stream2); (void)hipStreamDestroy(b->stream2); }
+    if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+    if (b->ev_join) (void)hipEventDestroy(b->ev_join);
+    for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+int ss_batch_layout_get(const ss_batch *b, ss_batch_layout *out)
+{
+    SS_ON_DEVICE(b);
+    if (!b || !out) return SS_ERR_INVALID_ARG;
+    *out = b->lay;
+    return SS_OK;
+}
+
+int ss_batch_upload(ss_batch *b, uint32_t first, uint32_t count, const float *pcm)
+{
+    SS_ON_DEVICE(b);
+    if (!b || !pcm) return SS_ERR_INVALID_ARG;
+    if ((uint64_t)first + count > b->cfg.n_streams) return SS_ERR_INVALID_ARG;
+    const size_t per = (size_t)b->cfg.frames_per_stream * b->cfg.channels;
+    HIPCHK(hipMemcpyAsync(b->pcm.p + (size_t)first * per, pcm, (size_t)count * per * sizeof(float),
+                          hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return SS_OK;
+}
+
+int ss_batch_upload_pcm(ss_batch *b, uint32_t first, uint32_t count, const void *pcm, int format)
+{
+    SS_ON_DEVICE(b);
+    const size_t sb = ss_pcm_sample_bytes(format);
+    if (!b || !pcm || !sb) return SS_ERR_INVALID_ARG;
+    if ((uint64_t)first + count > b->cfg.n_streams) return SS_ERR_INVALID_ARG;
+    const size_t per = (size_t)b->cfg.frames_per_stream * b->cfg.channels;
+    const size_t n = per * count;
+    DevBuf<unsigned char> raw;
+    HIPCHK(raw.alloc(n * sb + 8));
+    HIPCHK(hipMemcpyAsync(raw.p, pcm, n * sb, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(ssk::launch_pcm_to_f32(raw.p, n, format, b->pcm.p + (size_t)first * per, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return SS_OK;
+}
+
+// ---- ragged batches: streams of different lengths in one batch ------------------------------------------------
+// The batch is created for the longest stream (frames_per_stream = the slot size); every stream then gets its own
+// window count, sub-block count and decimation geometry by the very rules ss_batch_create applies to the whole
+// batch.  Slots are uploaded as before (the tail of a short stream's slot is never read).
+int ss_batch_set_lengths(ss_batch *b, const uint64_t *frames, uint32_t count)
+{
+    SS_ON_DEVICE(b);
+    if (!b || !frames || count != b->cfg.n_streams) return SS_ERR_INVALID_ARG;
+    const ss_batch_config &c = b->cfg;
+    const uint32_t C = c.channels;
+    for (uint32_t i = 0; i < count; i++) if (frames[i] > c.frames_per_stream) return SS_ERR_INVALID_ARG;
+    b->frames_h.assign(frames, frames + count);
+    b->windows_h.assign(count, 0); b->sub_h.assign(count, 0);
+    b->wave_window_h.assign(count, 0); b->wave_bins_h.assign(count, 0); b->wave_samples_h.assign(count, 0);
+    for (uint32_t i = 0; i < count; i++) {
+        const uint64_t F = frames[i];
+        if (c.flags & SS_BATCH_FFT) {
+            const uint64_t hop = c.hop_frames, k_min = c.fft_n / hop + 1, k_max = F / hop;
+            b->windows_h[i] = k_max >= k_min ? (uint32_t)(k_max - k_min + 1) : 0;
+        }
+        if (b->td) b->sub_h[i] = (uint32_t)(F / b->td->host.s100);
+        if (c.flags & SS_BATCH_WAVEFORM) {
+            const double win = c.waveform_window > 0.0 ? c.waveform_window : (double)F / (double)c.sample_rate;
+            size_t window, bins;
+            waveform_shape((size_t)(F * C), win, &window, &bins);
+            if (window > b->wave_window) return SS_ERR_INVALID_ARG;      // cannot happen for F <= frames_per_stream
+            b->wave_window_h[i] = (uint32_t)window; b->wave_bins_h[i] = (uint32_t)bins; b->wave_samples_h[i] = F * C;
+        }
+    }
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(b->frames_d.upload(b->frames_h));
+    HIPCHK(b->windows_d.upload(b->windows_h));
+    HIPCHK(b->sub_d.upload(b->sub_h));
+    HIPCHK(b->wave_window_d.upload(b->wave_window_h));
+    HIPCHK(b->wave_samples_d.upload(b->wave_samples_h));
+    b->ragged = true;
+    return SS_OK;
+}
+
+int ss_batch_stream_shape(const ss_batch *b, uint32_t stream, ss_stream_shape *out)
+{
+    SS_ON_DEVICE(b);
+    if (!b || !out || stream >= b->cfg.n_streams) return SS_ERR_INVALID_ARG;
+    if (b->ragged) {
+        out->frames = b->frames_h[stream]; out->n_windows = b->windows_h[stream];
+        out->n_subblocks = b->sub_h[stream]; out->n_wave_points = 2 * b->wave_bins_h[stream];
+    } else {
+        out->frames = b->cfg.frames_per_stream; out->n_windows = b->lay.n_windows;
+        out->n_subblocks = b->lay.n_subblocks; out->n_wave_points = b->lay.n_wave_points;
+    }
+    out->reserved = 0;
+    return SS_OK;
+}
+
+// ---- pipelined ingest: page-locked host memory + uploads that do not wait -------------------------------------
+// A batch owns its stream, so two batches are a double buffer: while one runs, the other's upload is in flight
+// on the copy engine.  That only holds for page-locked host memory (pageable copies are staged synchronously).
+int ss_host_register(void *ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return SS_ERR_INVALID_ARG;
+    if (require_device()) return SS_ERR_DEVICE;
+    HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return SS_OK;
+}
+
+int ss_host_unregister(void *ptr)
+{
+    if (!ptr) return SS_ERR_INVALID_ARG;
+    HIPCHK(hipHostUnregister(ptr));
+    return SS_OK;
+}
+
+// like ss_batch_upload_pcm, but returns as soon as the copy and the conversion are queued on the batch's stream:
+// `pcm` must stay valid (and should be page-locked) until the next ss_batch_sync / ss_batch_results on this batch
+int ss_batch_upload_pcm_async(ss_batch *b, uint32_t first, uint32_t count, const void *pcm, int format)
+{
+    SS_ON_DEVICE(b);
+    const size_t sb = ss_pcm_sample_bytes(format);
+    if (!b || !pcm || !sb) return SS_ERR_INVALID_ARG;
+    if ((uint64_t)first + count > b->cfg.n_streams) return SS_ERR_INVALID_ARG;
+    const size_t per = (size_t)b->cfg.frames_per_stream * b->cfg.channels;
+    const size_t n = per * count;
+    if (format == SS_PCM_F32) {
+        HIPCHK(hipMemcpyAsync(b->pcm.p + (size_t)first * per, pcm, n * sizeof(float), hipMemcpyHostToDevice, b->stream));
+        return SS_OK;
+    }
+    // one raw staging area per batch, sized for the whole batch; ranges of different `first` do not overlap
+    const size_t total = per * b->cfg.n_streams;
+    if (b->raw.n < total * sb + 8) {
+        HIPCHK(hipStreamSynchronize(b->stream));
+        HIPCHK(b->raw.alloc(total * sb + 8));
+    }
+    unsigned char *dst = b->raw.p + (size_t)first * per * sb;
+    HIPCHK(hipMemcpyAsync(dst, pcm, n * sb, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(ssk::launch_pcm_to_f32(dst, n, format, b->pcm.p + (size_t)first * per, b->stream));
+    return SS_OK;
+}
+
+// the first n_samples interleaved samples of one stream's slot, raw PCM of any supported format (ragged batches:
+// a stream shorter than the slot).  Queued on the batch's stream like ss_batch_upload_pcm_async.
+int ss_batch_upload_samples(ss_batch *b, uint32_t stream, const void *pcm, size_t n_samples, int format)
+{
+    SS_ON_DEVICE(b);
+    const size_t sb = ss_pcm_sample_bytes(format);
+    if (!b || (!pcm && n_samples) || !sb || stream >= b->cfg.n_streams) return SS_ERR_INVALID_ARG;
+    const size_t per = (size_t)b->cfg.frames_per_stream * b->cfg.channels;
+    if (n_samples > per) return SS_ERR_INVALID_ARG;
+    if (!n_samples) return SS_OK;
+    float *dst = b->pcm.p + (size_t)stream * per;
+    if (format == SS_PCM_F32) {
+        HIPCHK(hipMemcpyAsync(dst, pcm, n_samples * sizeof(float), hipMemcpyHostToDevice, b->stream));
+        return SS_OK;
+    }
+    const size_t total = per * b->cfg.n_streams;
+    if (b->raw.n < total * sb + 8) {
+        HIPCHK(hipStreamSynchronize(b->stream));
+        HIPCHK(b->raw.alloc(total * sb + 8));
+    }
+    unsigned char *raw = b->raw.p + (size_t)stream * per * sb;
+    HIPCHK(hipMemcpyAsync(raw, pcm, n_samples * sb, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(ssk::launch_pcm_to_f32(raw, n_samples, format, dst, b->stream));
+    return SS_OK;
+}
+
+int ss_batch_download_input(ss_batch *b, uint32_t stream, float *pcm, size_t cap)
+{
+    SS_ON_DEVICE(b);
+    if (!b || !pcm || stream >= b->cfg.n_streams) return SS_ERR_INVALID_ARG;
+    const size_t per = (size_t)b->cfg.frames_per_stream * b->cfg.channels;
+    if (cap < per) return SS_ERR_CAPACITY;
+    HIPCHK(hipMemcpyAsync(pcm, b->pcm.p + (size_t)stream * per, per * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return SS_OK;
+}
+
+void *ss_batch_input_device_ptr(ss_batch *b) { return b ? b->pcm.p : nullptr; }
+
+int ss_batch_synthesize(ss_batch *b, uint64_t seed, uint32_t first_stream_id)
+{
+    SS_ON_DEVICE(b);
+    if (!b) return SS_ERR_INVALID_ARG;
+    HIPCHK(ssk::launch_synth(b->pcm.p, b->cfg.n_streams, b->cfg.frames_per_stream, b->cfg.channels,
+                             b->cfg.sample_rate, seed, first_stream_id, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return SS_OK;
+}
+
+int ss_batch_run(ss_batch *b)
+{
+    SS_ON_DEVICE(b);
+    if (!b) return SS_ERR_INVALID_ARG;
+    int rc = batch_collect_timing(b);
+    if (rc) return rc;
+    const ss_batch_config &c = b->cfg;
+    const ss_batch_layout &L = b->lay;
+    const uint32_t C = c.channels;
+    const bool tm = b->timing;
+    auto rec = [&](int idx) -> hipError_t { return tm ? hipEventRecord(b->ev[idx], b->stream) : hipSuccess; };
+
+    // overlap mode: fork — the spectrum kernel goes to stream2 after everything already queued on the main stream
+    // (uploads, the previous pass), the time-domain chain stays on the main stream, join at the end.  Per-kernel
+    // event timing is meaningless while two kernels share the chip, so timing passes stay sequential.
+    // Mode 2 (tail overlap): the time-domain kernel runs first and alone; the spectrum kernel starts behind it on stream2
+    // while the short latency-bound tail of the chain (gating / histograms per stream, a standalone decimation) runs on
+    // the main stream beside it.
+    const int mode = tm ? 0 : b->overlap;
+    const bool ov = mode != 0;
+    hipStream_t fft_stream = ov ? b->stream2 : b->stream;
+    if (mode == 1) {
+        HIPCHK(hipEventRecord(b->ev_fork, b->stream));
+        HIPCHK(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
+    }
+    auto launch_spectrum = [&]() -> int {
+    HIPCHK(rec(2 * SS_KERNEL_FFT));
+    if ((c.flags & SS_BATCH_FFT) && L.n_windows) {
+        ssk::FftBatchParams p{};
+        p.pcm = b->pcm.p; p.out = b->fft.p;
+        p.window = b->ft->window.p; p.half_window = b->ft->half_window.p;
+        p.tw_n = b->ft->tw_n.p; p.tw_256 = b->ft->tw_256.p; p.pink = b->bt->pink_dev.p;
+        p.frames_per_stream = c.frames_per_stream; p.first_start = b->first_start;
+        p.n_streams = c.n_streams; p.channels = C; p.n_windows = L.n_windows; p.hop = c.hop_frames;
+        p.n = c.fft_n; p.first_bin = L.first_bin; p.n_bins = L.n_bins; p.bin_stride = L.fft_bin_stride;
+        p.windows_per_block = b->windows_per_block;
+        p.windows_of = b->ragged ? b->windows_d.p : nullptr;
+        if (b->fft_fast || b->fft_pairw) {
+            p.db_offset = (float)(10.0 * std::log10(4.0 / ((double)c.fft_n * (double)c.fft_n)));
+            p.offpink = b->bt->offpink4096_dev.p;
+            {
+                const uint32_t lo = L.first_bin, hi = L.first_bin + L.n_bins - 1;      // retained bins and their mirrors
+                uint32_t mask = 0;
+                for (uint32_t kc = 0; kc < 16; kc++) {
+                    const uint32_t a0 = 256 * kc, a1 = a0 + 255;
+                    const bool direct = a0 <= hi + 3 && a1 >= lo;                       // +3: the last group of four may run past
+                    const bool mirror = a0 <= 4096 - lo && a1 + 3 >= 4096 - hi - 3;
+                    if (direct || mirror) mask |= 1u << kc;
+                }
+                p.publish_mask = mask;
+            }
+            if (b->fft_fast) HIPCHK(ssk::launch_fft4096_ms(p, fft_stream));
+            else HIPCHK(ssk::launch_fft4096_pairw(p, b->fft_mode, fft_stream));
+        } else {
+            p.db_offset = (float)(20.0 * std::log10(4.0 / (double)c.fft_n));
+            if (c.fft_n == 16384) {
+                p.tw_core = b->ft->core_tw4096; p.tw_256 = b->ft->core_tw256;
+                bool run_kernel = (c.hop_frames == 1024 && L.n_windows >= 8);
+#ifdef SS_TUNING
+                if (std::getenv("SS_FFT16K_SINGLE")) run_kernel = false;
+#endif
+                if (run_kernel)
+                    HIPCHK(ssk::launch_fft16k_run(p, b->fft_mode, fft_stream));
+                else
+                    HIPCHK(ssk::launch_fft16k(p, b->fft_mode, fft_stream));
+            } else {
+                HIPCHK(ssk::launch_fft_generic(p, b->fft_mode, fft_stream));
+            }
+        }
+    }
+    HIPCHK(rec(2 * SS_KERNEL_FFT + 1));
+    return SS_OK;
+    };
+    if (mode != 2) { rc = launch_spectrum(); if (rc) return rc; }
+
+    const bool td = (c.flags & (SS_BATCH_LUFS | SS_BATCH_TRUE_PEAK)) != 0;
+    HIPCHK(rec(2 * SS_KERNEL_TIME_DOMAIN));
+    if (td) {
+        HIPCHK(hipMemsetAsync(b->state.p, 0, b->state.n * sizeof(ssk::TdState), b->stream));
+        HIPCHK(hipMemsetAsync(b->hist.p, 0, b->hist.n * sizeof(uint64_t), b->stream));
+        HIPCHK(hipMemsetAsync(b->corpus.p, 0, b->corpus.n * sizeof(uint64_t), b->stream));
+        HIPCHK(hipMemsetAsync(b->counts.p, 0, b->counts.n * sizeof(uint32_t), b->stream));
+        HIPCHK(rec(2 * SS_KERNEL_TIME_DOMAIN));   // time the kernel, not the memsets
+        ssk::TdParams p{};
+        p.pcm = b->pcm.p; p.stream_stride = c.frames_per_stream * C; p.n_frames = c.frames_per_stream;
+        p.n_streams = c.n_streams; p.channels = C; p.k = b->td->dev.p; p.state = b->state.p;
+        p.subblocks = b->sub.p; p.sub_cap = L.n_subblocks ? L.n_subblocks : 1;
+        p.sub_stride = (uint64_t)p.sub_cap * C; p.ring = nullptr; p.ring_frames = 0; p.tp_factor = b->tp_factor;
+        p.s100 = b->td->host.s100; p.nseg = b->td_nseg; p.seg_sub = b->td_seg_sub; p.warm_sub = kTdWarmSub;
+        p.frames_of = b->ragged ? b->frames_d.p : nullptr;
+        if (b->wave_fused && !b->ragged) { p.wave_out = b->wave.p; p.wave_stride = (uint64_t)2 * b->wave_window; p.wave_window = b->wave_window; p.halo_frames = b->wave_halo; }
+        HIPCHK(ssk::launch_time_domain(p, b->stream));
+    }
+    HIPCHK(rec(2 * SS_KERNEL_TIME_DOMAIN + 1));
+    if (mode == 2) {
+        HIPCHK(hipEventRecord(b->ev_fork, b->stream));
+        HIPCHK(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
+        rc = launch_spectrum(); if (rc) return rc;
+    }
+
+    HIPCHK(rec(2 * SS_KERNEL_FINALIZE));
+    if (td) {
+        const double *he, *hb;
+        rc = get_hist_tables(&he, &hb);
+        if (rc) return rc;
+        ssk::FinalizeParams f{};
+        f.k = b->td->dev.p; f.subblocks = b->sub.p; f.sub_cap = L.n_subblocks ? L.n_subblocks : 1;
+        f.sub_stride = (uint64_t)f.sub_cap * C;
+        f.hist_energies = he; f.hist_bounds = hb; f.weights = b->weights.p; f.hist = b->hist.p;
+        f.corpus_hist = b->corpus.p; f.n_streams = c.n_streams; f.channels = C;
+        f.sub_begin = 0; f.sub_end = L.n_subblocks;
+        f.sub_end_of = b->ragged ? b->sub_d.p : nullptr;
+        f.out_integrated = b->integrated.p; f.out_lra = b->lra.p; f.out_counts = b->counts.p;
+        HIPCHK(ssk::launch_finalize(f, b->stream));
+    }
+    HIPCHK(rec(2 * SS_KERNEL_FINALIZE + 1));
+
+    HIPCHK(rec(2 * SS_KERNEL_WAVEFORM));
+    if ((c.flags & SS_BATCH_WAVEFORM) && b->wave_window && (!b->wave_fused || b->ragged)) {
+        ssk::WaveParams p{};
+        p.pcm = b->pcm.p; p.stream_stride = c.frames_per_stream * C; p.n_samples = c.frames_per_stream * C;
+        p.n_streams = c.n_streams; p.window = b->wave_window; p.out = b->wave.p; p.out_stride = (uint64_t)2 * b->wave_window;
+        if (b->ragged) { p.samples_of = b->wave_samples_d.p; p.window_of = b->wave_window_d.p; }
+        HIPCHK(ssk::launch_waveform(p, b->stream));
+    }
+    HIPCHK(rec(2 * SS_KERNEL_WAVEFORM + 1));
+    if (ov) {                                  // join: later work on the main stream (downloads, the next pass) sees the spectrum
+        HIPCHK(hipEventRecord(b->ev_join, b->stream2));
+        HIPCHK(hipStreamWaitEvent(b->stream, b->ev_join, 0));
+    }
+    b->pending_events = tm;
+    return SS_OK;
+}
+
+// measurement utility: the spectrum kernel's loads and stores alone (see the header)
+int ss_batch_traffic_floor(ss_batch *b, uint32_t reps, double *ms_per_launch)
+{
+    SS_ON_DEVICE(b);
+    if (!b || !ms_per_launch || reps == 0) return SS_ERR_INVALID_ARG;
+    const ss_batch_config &c = b->cfg;
+    const ss_batch_layout &L = b->lay;
+    if (!(c.flags & SS_BATCH_FFT) || !b->fft_fast || c.hop_frames != 1024 || !L.n_windows || b->ragged) return SS_ERR_UNSUPPORTED;
+    ssk::FftBatchParams p{};
+    p.pcm = b->pcm.p; p.out = b->fft.p;
+    p.frames_per_stream = c.frames_per_stream; p.first_start = b->first_start;
+    p.n_streams = c.n_streams; p.channels = c.channels; p.n_windows = L.n_windows; p.hop = c.hop_frames;
+    p.n = c.fft_n; p.first_bin = L.first_bin; p.n_bins = L.n_bins; p.bin_stride = L.fft_bin_stride;
+    p.windows_per_block = b->windows_per_block;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(hipEventCreate(&e0));
+    hipError_t err = hipEventCreate(&e1);
+    if (err == hipSuccess) err = ssk::launch_fft4096_traffic(p, b->stream);            // warm
+    if (err == hipSuccess) err = hipEventRecord(e0, b->stream);
+    for (uint32_t r = 0; r < reps && err == hipSuccess; r++) err = ssk::launch_fft4096_traffic(p, b->stream);
+    if (err == hipSuccess) err = hipEventRecord(e1, b->stream);
+    if (err == hipSuccess) err = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    HIPCHK(err);
+    *ms_per_launch = (double)ms / reps;
+    return SS_OK;
+}
+
+int ss_batch_sync(ss_batch *b)
+{
+    SS_ON_DEVICE(b);
+    if (!b) return SS_ERR_INVALID_ARG;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return batch_collect_timing(b);
+}
+
+int ss_batch_results(ss_batch *b, ss_stream_result *out, uint32_t cap)
+{
+    SS_ON_DEVICE(b);
+    if (!b || !out) return SS_ERR_INVALID_ARG;
+    const uint32_t n = b->cfg.n_streams;
+    if (cap < n) return SS_ERR_CAPACITY;
+    std::memset(out, 0, sizeof(ss_stream_result) * n);
+    if (!b->state.p) return SS_OK;
+    std::vector<double> integ(n), lra(n);
+    std::vector<uint32_t> cnt(2 * (size_t)n);
+    std::vector<ssk::TdState> st(n);
+    HIPCHK(hipMemcpyAsync(integ.data(), b->integrated.p, n * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(lra.data(), b->lra.p, n * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(cnt.data(), b->counts.p, 2 * (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(st.data(), b->state.p, n * sizeof(ssk::TdState), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (uint32_t i = 0; i < n; i++) {
+        out[i].integrated_lufs = integ[i];
+        out[i].loudness_range = lra[i];
+        for (uint32_t c = 0; c < 2 && c < b->cfg.channels; c++) {
+            const float sp = st[i].sample_peak[c], tp = st[i].true_peak[c];
+            out[i].sample_peak[c] = sp;
+            out[i].true_peak[c] = tp > sp ? tp : sp;
+        }
+        out[i].n_gating_blocks = cnt[2 * i];
+        out[i].n_st_blocks = cnt[2 * i + 1];
+    }
+    return SS_OK;
+}
+
+// every channel's peaks of one stream: EbuR128::true_peak(c) = max(true, sample) and EbuR128::sample_peak(c)
+int ss_batch_peaks(ss_batch *b, uint32_t stream, double *true_pk, double *sample_pk, uint32_t cap_channels)
+{
+    SS_ON_DEVICE(b);
+    if (!b || stream >= b->cfg.n_streams) return SS_ERR_INVALID_ARG;
+    if (!b->state.p) return SS_ERR_INVALID_MODE;                 // the batch runs no meter pass
+    const uint32_t C = b->cfg.channels;
+    if (cap_channels < C) return SS_ERR_CAPACITY;
+    float sp[ssk::kMaxChannels], tp[ssk::kMaxChannels];
+    const ssk::TdState *st = b->state.p + stream;
+    HIPCHK(hipMemcpyAsync(sp, st->sample_peak, C * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(tp, st->true_peak, C * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (uint32_t c = 0; c < C; c++) {
+        if (sample_pk) sample_pk[c] = (double)sp[c];
+        if (true_pk) true_pk[c] = (double)(tp[c] > sp[c] ? tp[c] : sp[c]);
+    }
+    return SS_OK;
+}
+
+int ss_batch_geometry_get(const ss_batch *b, ss_batch_geometry *out)
+{
+    if (!b || !out) return SS_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof *out);
+    const ss_batch_layout &L = b->lay;
+    if ((b->cfg.flags & SS_BATCH_FFT) && L.n_windows) {
+        out->fft_windows_per_block = b->windows_per_block;
+        const bool run16k = b->cfg.fft_n == 16384 && b->cfg.hop_frames == 1024 && L.n_windows >= 8 && !b->fft_fast && !b->fft_pairw;
+        if (b->fft_fast) {
+            out->fft_blocks = b->cfg.n_streams * ((L.n_windows + b->windows_per_block - 1) / b->windows_per_block);
+        } else if (b->fft_pairw) {
+            const uint32_t ppb = b->windows_per_block >> 1, np = (L.n_windows + 1) >> 1;
+            out->fft_blocks = b->cfg.n_streams * L.fft_channels * ((np + ppb - 1) / ppb);
+        } else if (run16k) {
+            uint32_t wpb = 0, groups = 0;
+            ssk::fft16k_run_geometry(b->cfg.n_streams, L.fft_channels, L.n_windows, &wpb, &groups);
+            out->fft_windows_per_block = wpb;
+            out->fft_blocks = b->cfg.n_streams * L.fft_channels * groups;
+        } else {
+            out->fft_windows_per_block = 1;
+            out->fft_blocks = b->cfg.n_streams * L.n_windows * L.fft_channels;
+        }
+    }
+    if (b->td) {
+        out->td_segments = b->td_nseg;
+        out->td_segment_subblocks = b->td_seg_sub;
+        out->td_warm_subblocks = b->td_nseg > 1 ? kTdWarmSub : 0;
+        out->td_true_peak_factor = (uint32_t)b->tp_factor;
+    }
+    out->waveform_fused = (b->wave_fused && !b->ragged) ? 1u : 0u;
+    out->overlap = (uint32_t)b->overlap;
+    return SS_OK;
+}
+
+int ss_batch_set_overlap(ss_batch *b, int enable)
+{
+    SS_ON_DEVICE(b);
+    if (!b) return SS_ERR_INVALID_ARG;
+    if (enable && !b->stream2) {
+        HIPCHK(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+    }
+    HIPCHK(hipStreamSynchronize(b->stream));
+    b->overlap = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
+    return SS_OK;
+}
+
+int ss_batch_download_fft(ss_batch *b, uint32_t stream, float *out, size_t cap)
+{
+    SS_ON_DEVICE(b);
+    if (!b || !out || stream >= b->cfg.n_streams) return SS_ERR_INVALID_ARG;
+    const size_t rows = (size_t)b->lay.n_windows * b->lay.fft_channels;
+    const size_t per = rows * b->lay.n_bins;
+    if (cap < per) return SS_ERR_CAPACITY;
+    if (!per) return SS_OK;
+    // device rows are padded to fft_bin_stride floats; hand back the compact [window][channel][bin] array
+    HIPCHK(hipMemcpy2DAsync(out, (size_t)b->lay.n_bins * sizeof(float),
+                            b->fft.p + (size_t)stream * rows * b->lay.fft_bin_stride,
+                            (size_t)b->lay.fft_bin_stride * sizeof(float), (size_t)b->lay.n_bins * sizeof(float), rows,
+                            hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return SS_OK;
+}
+
+int ss_batch_bin_tables(const ss_batch *b, double *chart_x, double *freq, double *pink_db)
+{
+    SS_ON_DEVICE(b);
+    if (!b || !b->bt) return SS_ERR_INVALID_ARG;
+    const size_t n = b->bt->count;
+    if (chart_x) std::memcpy(chart_x, b->bt->chart_x.data(), n * sizeof(double));
+    if (freq) std::memcpy(freq, b->bt->freq.data(), n * sizeof(double));
+    if (pink_db) std::memcpy(pink_db, b->bt->pink.data(), n * sizeof(double));
+    return SS_OK;
+}
+
+int ss_batch_download_waveform(ss_batch *b, uint32_t stream, float *out, size_t cap)
+{
+    SS_ON_DEVICE(b);
+    if (!b || !out || stream >= b->cfg.n_streams) return SS_ERR_INVALID_ARG;
+    const size_t pts = b->lay.n_wave_points;
+    if (cap < pts) return SS_ERR_CAPACITY;
+    if (!pts) return SS_OK;
+    HIPCHK(hipMemcpyAsync(out, b->wave.p + (size_t)stream * 2 * b->wave_window, pts * sizeof(float),
+                          hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return SS_OK;
+}
+
+int ss_batch_download_subblocks(ss_batch *b, uint32_t stream, double *out, size_t cap)
+{
+    SS_ON_DEVICE(b);
+    if (!b || !out || stream >= b->cfg.n_streams || !b->sub.p) return SS_ERR_INVALID_ARG;
+    const size_t per = (size_t)b->lay.n_subblocks * b->cfg.channels;
+    if (cap < per) return SS_ERR_CAPACITY;
+    if (!per) return SS_OK;
+    HIPCHK(hipMemcpyAsync(out, b->sub.p + (size_t)stream * per, per * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return SS_OK;
+}
+
+int ss_batch_histograms(ss_batch *b, uint64_t *out2000)
+{
+    SS_ON_DEVICE(b);
+    if (!b || !out2000 || !b->corpus.p) return SS_ERR_INVALID_ARG;
+    HIPCHK(hipMemcpyAsync(out2000, b->corpus.p, 2 * sst::kHistBins * sizeof(uint64_t), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return SS_OK;
+}
+
+int ss_batch_histograms_device(ss_batch *b, void *dst)
+{
+    SS_ON_DEVICE(b);
+    if (!b || !dst || !b->corpus.p) return SS_ERR_INVALID_ARG;
+    HIPCHK(hipMemcpyAsync(dst, b->corpus.p, 2 * sst::kHistBins * sizeof(uint64_t), hipMemcpyDeviceToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return SS_OK;
+}
+
+// The corpus gate without leaving the device: [sum over the ranks] + loudness_global / loudness_range of the corpus
+// histograms, queued on the batch's stream behind ss_batch_run.  Nothing is copied or waited for, so a loop of passes
+// needs no host synchronisation per pass; ss_batch_corpus_gate_read fetches the pair.
+int ss_batch_corpus_gate_enqueue(ss_batch *b, ss_comm *comm)
+{
+    SS_ON_DEVICE(b);
+    if (!b) return SS_ERR_INVALID_ARG;
+    if (!b->corpus.p) return SS_ERR_INVALID_MODE;
+    if (comm) {
+        int rc = ss_batch_allreduce_histograms(b, comm, nullptr);
+        if (rc) return rc;
+    }
+    const double *he, *hb;
+    int rc = get_hist_tables(&he, &hb);
+    if (rc) return rc;
+    HIPCHK(ssk::launch_hist_eval(b->corpus.p, he, hb, b->out2.p, b->stream));
+    return SS_OK;
+}
+
+int ss_batch_corpus_gate_read(ss_batch *b, double *integrated, double *lra)
+{
+    SS_ON_DEVICE(b);
+    if (!b) return SS_ERR_INVALID_ARG;
+    if (!b->corpus.p) return SS_ERR_INVALID_MODE;
+    double r[2];
+    HIPCHK(hipMemcpyAsync(r, b->out2.p, sizeof r, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (integrated) *integrated = r[0];
+    if (lra) *lra = r[1];
+    return SS_OK;
+}
+
+double ss_corpus_integrated_lufs(const uint64_t *h) { return h ? sst::gated_loudness(h) : NAN; }
+double ss_corpus_loudness_range(const uint64_t *h) { return h ? sst::loudness_range(h) : NAN; }
+
+// ---- render-side reductions ---------------------------------
+int ss_batch_render_spectrum(ss_batch *b, uint32_t cols, int gain_mode, float gain_db)
+{
+    SS_ON_DEVICE(b);
+    if (!b || cols == 0 || cols > 65536 || (gain_mode != SS_GAIN_FIXED && gain_mode != SS_GAIN_REFERENCE))
+        return SS_ERR_INVALID_ARG;
+    const ss_batch_layout &L = b->lay;
+    if (!(b->cfg.flags & SS_BATCH_FFT) || !L.n_windows || !L.n_bins) return SS_ERR_INVALID_MODE;
+    if (gain_mode == SS_GAIN_REFERENCE && !(b->cfg.flags & SS_BATCH_LUFS)) return SS_ERR_INVALID_MODE;
+    // column of a bin: floor(chart_x / 100 * cols), the last column closed on the right; chart_x ascends
+    std::vector<uint32_t> start(cols + 1, L.n_bins);
+    {
+        uint32_t c = 0;
+        start[0] = 0;
+        for (uint32_t i = 0; i < L.n_bins; i++) {
+            double f = std::floor(b->bt->chart_x[i] / 100.0 * (double)cols);
+            if (f < 0) f = 0;
+            uint32_t ci = f >= (double)cols ? cols - 1 : (uint32_t)f;
+            while (c < ci) start[++c] = i;
+        }
+        while (c < cols) start[++c] = L.n_bins;
+    }
+    const uint64_t rows = (uint64_t)b->cfg.n_streams * L.n_windows * L.fft_channels;
+    HIPCHK(b->col_start.ensure(cols + 1));
+    HIPCHK(hipMemcpyAsync(b->col_start.p, start.data(), (cols + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));           // `start` is a local
+    HIPCHK(b->render_spec.ensure(rows * cols));
+    b->render_cols = cols;
+    HIPCHK(ssk::launch_render_spectrum(b->fft.p, L.fft_bin_stride, L.n_bins, rows, L.n_windows * L.fft_channels,
+                                       b->col_start.p, cols,
+                                       gain_mode == SS_GAIN_REFERENCE ? b->integrated.p : nullptr, gain_db,
+                                       b->render_spec.p, b->stream));
+    return SS_OK;
+}
+
+int ss_batch_download_spectrum_columns(ss_batch *b, uint32_t stream, float *out, size_t cap)
+{
+    SS_ON_DEVICE(b);
+    if (!b || !out || stream >= b->cfg.n_streams || !b->render_cols) return SS_ERR_INVALID_ARG;
+    const size_t per = (size_t)b->lay.n_windows * b->lay.fft_channels * b->render_cols;
+    if (cap < per) return SS_ERR_CAPACITY;
+    HIPCHK(hipMemcpyAsync(out, b->render_spec.p + (size_t)stream * per, per * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return SS_OK;
+}
+
+int ss_batch_render_waveform(ss_batch *b, uint32_t cols, uint32_t x_min, uint32_t x_max)
+{
+    SS_ON_DEVICE(b);
+    if (!b || cols == 0 || cols > 65536 || x_max <= x_min) return SS_ERR_INVALID_ARG;
+    if (!(b->cfg.flags & SS_BATCH_WAVEFORM) || !b->wave_window) return SS_ERR_INVALID_MODE;
+    HIPCHK(b->render_wave.ensure((size_t)b->cfg.n_streams * cols * 2));
+    b->render_wave_cols = cols;
+    HIPCHK(ssk::launch_render_waveform(b->wave.p, (uint64_t)2 * b->wave_window, b->lay.n_wave_points / 2,
+                                       b->cfg.n_streams, x_min, x_max, cols, b->render_wave.p, b->stream));
+    return SS_OK;
+}
+
+int ss_batch_download_waveform_columns(ss_batch *b, uint32_t stream, float *out, size_t cap)
+{
+    SS_ON_DEVICE(b);
+    if (!b || !out || stream >= b->cfg.n_streams || !b->render_wave_cols) return SS_ERR_INVALID_ARG;
+    const size_t per = (size_t)2 * b->render_wave_cols;
+    if (cap < per) return SS_ERR_CAPACITY;
+    HIPCHK(hipMemcpyAsync(out, b->render_wave.p + (size_t)stream * per, per * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return SS_OK;
+}
+
+// the waveform chart's x bounds in Player mode (tui.rs:664-681), f64 like the reference
+void ss_waveform_view(double playhead_ms, double waveform_window_s, size_t chart_points, double *x_min, double *x_max)
+{
+    const double half_window = waveform_window_s * 500.0;
+    const double max_x = (double)chart_points / 2.0;
+    double lo = playhead_ms - half_window;
+    lo = std::fmin(lo, max_x - waveform_window_s * 1000.0);
+    lo = std::fmax(lo, 0.0);
+    double hi = playhead_ms + half_window;
+    hi = std::fmin(hi, max_x);
+    hi = std::fmax(hi, waveform_window_s * 1000.0);
+    if (x_min) *x_min = lo;
+    if (x_max) *x_max = hi;
+}
+
+int ss_batch_timing_enable(ss_batch *b, int enable)
+{
+    SS_ON_DEVICE(b);
+    if (!b) return SS_ERR_INVALID_ARG;
+    int rc = batch_collect_timing(b);
+    if (rc) return rc;
+    b->timing = enable != 0;
+    for (int k = 0; k < SS_KERNEL_COUNT; k++) { b->t_ms[k] = 0; b->t_n[k] = 0; }
+    return SS_OK;
+}
+
+int ss_batch_timing_read(ss_batch *b, int kernel, double *total_ms, uint64_t *launches)
+{
+    SS_ON_DEVICE(b);
+    if (!b || kernel < 0 || kernel >= SS_KERNEL_COUNT) return SS_ERR_INVALID_ARG;
+    int rc = batch_collect_timing(b);
+    if (rc) return rc;
+    if (total_ms) *total_ms = b->t_ms[kernel];
+    if (launches) *launches = b->t_n[kernel];
+    return SS_OK;
+}
+
+// the spectrum kernel a batch of this shape launches (names as rocprofv3 prints them, without template arguments)
+const char *ss_batch_kernel_name(const ss_batch *b, int kernel)
+{
+    if (!b || kernel != SS_KERNEL_FFT) return ss_kernel_name(kernel);
+    if (b->fft_pairw) return "k_fft4096_pairw";
+    if (b->fft_fast) {
+        const uint32_t hop = b->cfg.hop_frames;
+        return hop == 1024 ? "k_fft4096_ms1" : ((hop == 512 || hop == 2048) ? "k_fft4096_ms" : "k_fft4096_ms_anyhop");
+    }
+    if (b->cfg.fft_n == 16384)
+        return (b->cfg.hop_frames == 1024 && b->lay.n_windows >= 8) ? "k_fft16k_run" : "k_fft16k";
+    return "k_fft_generic";
+}
+
+const char *ss_kernel_name(int kernel)
+{
+    switch (kernel) {
+        case SS_KERNEL_FFT: return "k_fft4096_ms1";
+        case SS_KERNEL_TIME_DOMAIN: return "k_time_domain";
+        case SS_KERNEL_FINALIZE: return "k_finalize";
+        case SS_KERNEL_WAVEFORM: return "k_waveform";
+        default: return "?";
+    }
+}
+
+// Analyzer::calculate_integrated_lufs (analyzer.rs:170-182): fresh meter at the
+// handle's sample rate, whole buffer fed in 2*sr-sample chunks, loudness_global.
+}  // extern "C"
+int ssh::integrated_oneshot(uint32_t rate, uint32_t channels, const float *samples, size_t n,
+                            bool on_device, double *out)
+{
+    int rc = meter_args_ok(channels, rate);           // EbuR128::new(...) else return None
+    if (rc) return rc;
+    // every chunk of samples.chunks(2*sr) must hold whole frames, else add_frames fails -> None
+    const size_t chunk = (size_t)rate * 2;
+    if (n > 0) {
+        if (chunk % channels) { if (n >= chunk || n % channels) return SS_ERR_NOMEM; }
+        else if (n % channels) return SS_ERR_NOMEM;
+    }
+    if (n == 0) { *out = -INFINITY; return SS_OK; }    // no blocks: loudness_global() = -inf
+    if (!samples) return SS_ERR_INVALID_ARG;
+    ss_batch_config cfg{};
+    cfg.sample_rate = rate; cfg.channels = channels; cfg.n_streams = 1; cfg.flags = SS_BATCH_LUFS;
+    cfg.frames_per_stream = n / channels; cfg.fft_n = 0; cfg.hop_frames = 0;
+    ss_batch *b = nullptr;
+    rc = ss_batch_create(&cfg, &b);
+    if (rc) return rc;
+    if (on_device) {
+        if (!hip_ok(hipMemcpyAsync(b->pcm.p, samples, n * sizeof(float), hipMemcpyDeviceToDevice, b->stream),
+                    "hipMemcpyAsync(D2D)")) rc = SS_ERR_DEVICE;
+    } else {
+        rc = ss_batch_upload(b, 0, 1, samples);
+    }
+    if (!rc) rc = ss_batch_run(b);
+    if (!rc) rc = ss_batch_sync(b);
+    ss_stream_result r{};
+    if (!rc) rc = ss_batch_results(b, &r, 1);
+    ss_batch_destroy(b);
+    if (rc) return rc;
+    *out = r.integrated_lufs;
+    return SS_OK;
+}
+extern "C" {
+
+int ss_calculate_integrated_lufs(ss_analyzer *h, uint32_t channels, const float *samples, size_t n, double *out)
+{
+    SS_ON_DEVICE(h);
+    if (!h || !out) return SS_ERR_INVALID_ARG;
+    return integrated_oneshot(h->rate, channels, samples, n, false, out);
+}
+
+}  // extern "C"

@@ -1,5 +1,5 @@
 // ss_kernels.h — parameter blocks and launchers of the gfx950 kernels.
-// Host code (ss_api.cpp) sees only this header; device code lives in ss_fft.hip, ss_time_domain.hip, ss_loudness.hip, ss_util.hip.
+// Host code (ss_host.cpp, ss_analyzer.cpp, ss_batch.cpp, ss_session.cpp, ss_ingest.cpp) sees only this header; device code lives in ss_fft.hip, ss_time_domain.hip, ss_loudness.hip, ss_util.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 

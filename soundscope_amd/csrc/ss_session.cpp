@@ -1,0 +1,422 @@
+// ss_session.cpp — the tick drivers: the per-file / per-device state of the reference's App and its
+// per-tick analysis with the audio resident in HBM (/root/reference/src/tui.rs:1207-1241, :1427-1552, :1586-1614).
+#include "ss_host.h"
+
+using namespace ssh;
+
+// ============================================================================
+//  Tick drivers: App's per-file / per-device analysis state
+// ============================================================================
+struct ss_session {
+    int device = 0;                     // the HIP device this session lives on
+    ss_analyzer *an = nullptr;          // file_analyzer / device_analyzer
+    bool is_file = false;
+    uint32_t file_channels = 2, rate = 0;
+    size_t n_samples = 0;               // file: interleaved samples; capture: 30 * rate
+    DevBuf<float> pcm;                  // the file / the capture ring, resident
+    DevBuf<float> ms;                   // capture: mid | side (n/2 each)
+    DevBuf<float> spec;                 // [2][bin_stride] dB rows of a tick
+    DevBuf<float> wave;                 // capture: [bins][2]
+    hipStream_t fft_stream = nullptr;   // the spectrum of a tick runs beside the loudness chain
+    float *stage = nullptr;             // pinned: 2 * bin_stride floats | wave floats
+    double *stage_d = nullptr;          // pinned: short-term loudness (2 doubles)
+    size_t stage_floats = 0;
+    FftTables *ft = nullptr;
+    BinTables *bt = nullptr;
+    uint32_t bin_stride = 0;
+    // pairs whose mid or side value is NaN / infinite (normally none): index -> class bits
+    // (1 mid NaN, 2 mid inf, 4 side NaN, 8 side inf)
+    std::vector<std::pair<size_t, uint8_t>> bad;
+    std::vector<double> waveform_xy;    // audio_file_chart
+    float gain_db = 0.0f;
+    uint64_t duration_ms = 0;
+    double lufs[SS_LUFS_HISTORY];
+};
+
+namespace {
+
+uint8_t pair_class(float l, float r)
+{
+    const float m = (l + r) * 0.5f, sd = (l - r) * 0.5f;
+    uint8_t c = 0;
+    if (std::isnan(m)) c |= 1; else if (std::isinf(m)) c |= 2;
+    if (std::isnan(sd)) c |= 4; else if (std::isinf(sd)) c |= 8;
+    return c;
+}
+
+// the crate's NaN / infinity rejection on the windowed slice [lb, lb + n) of mid (shift 0) or side (shift 2)
+int window_value_status(const ss_session *s, size_t lb, size_t n, int shift,
+                        const std::vector<std::pair<size_t, uint8_t>> &bad)
+{
+    auto it = std::lower_bound(bad.begin(), bad.end(), std::make_pair(lb, (uint8_t)0));
+    bool any_nan = false, any_inf = false;
+    for (; it != bad.end() && it->first < lb + n; ++it) {
+        const uint8_t c = (uint8_t)((it->second >> shift) & 3u);
+        if (c & 1u) any_nan = true;
+        else if (c & 2u) { if (s->ft->window_host[it->first - lb] == 0.0f) any_nan = true; else any_inf = true; }
+    }
+    return any_nan ? SS_ERR_NAN : (any_inf ? SS_ERR_INFINITY : SS_OK);
+}
+
+int session_common_init(ss_session *s, uint32_t meter_channels, uint32_t rate)
+{
+    s->rate = rate;
+    for (double &v : s->lufs) v = -100.0;
+    int rc = ss_analyzer_create(2, 44100, &s->an);                 // Analyzer::default()
+    if (rc) return rc;
+    // create_loudness_meter: the rate sticks even when the meter cannot be made (analyzer.rs:50);
+    // the reference only reports the error and carries on
+    (void)ss_analyzer_configure(s->an, meter_channels, rate);
+    rc = get_fft_tables(SS_TICK_WINDOW, &s->ft);
+    if (rc) return rc;
+    rc = get_bin_tables(rate, SS_TICK_WINDOW, &s->bt);
+    if (rc) return rc;
+    s->bin_stride = (uint32_t)((s->bt->count + 3) & ~(size_t)3);
+    if (s->bin_stride == 0) s->bin_stride = 4;
+    HIPCHK(s->spec.alloc((size_t)2 * s->bin_stride));
+    HIPCHK(hipStreamCreateWithFlags(&s->fft_stream, hipStreamNonBlocking));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->stage_d), 2 * sizeof(double), hipHostMallocDefault));
+    return SS_OK;
+}
+
+int session_stage(ss_session *s, size_t floats)
+{
+    if (floats <= s->stage_floats) return SS_OK;
+    if (s->stage) (void)hipHostFree(s->stage);
+    s->stage = nullptr; s->stage_floats = 0;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->stage), floats * sizeof(float), hipHostMallocDefault));
+    s->stage_floats = floats;
+    return SS_OK;
+}
+
+// enqueue the mid/side spectrum of pairs [lb, lb + 16384) of an interleaved pair buffer
+int session_enqueue_fft(ss_session *s, const float *pairs, size_t lb, hipStream_t stream)
+{
+    ssk::FftBatchParams p{};
+    p.pcm = pairs; p.out = s->spec.p;
+    p.window = s->ft->window.p; p.half_window = s->ft->half_window.p;
+    p.tw_n = s->ft->tw_n.p; p.tw_core = s->ft->core_tw4096; p.tw_256 = s->ft->core_tw256; p.pink = nullptr;
+    p.frames_per_stream = 0; p.first_start = lb; p.n_streams = 1; p.channels = 2;
+    p.n_windows = 1; p.hop = 0; p.n = SS_TICK_WINDOW;
+    p.first_bin = (uint32_t)s->bt->first; p.n_bins = (uint32_t)s->bt->count; p.bin_stride = s->bin_stride;
+    p.windows_per_block = 1;
+    p.db_offset = (float)(20.0 * std::log10(4.0 / (double)SS_TICK_WINDOW));
+    HIPCHK(ssk::launch_fft16k(p, 1, stream));
+    return SS_OK;
+}
+
+// after the synchronisation: dB rows in the pinned stage -> (chart_x, dB + pink) pairs, or the (0,0) fallback
+void session_emit_spectrum(const ss_session *s, const float *row, int status_in, double *xy,
+                           int32_t *status_out, uint32_t *n_out)
+{
+    int st = status_in;
+    const size_t nb = s->bt->count;
+    if (!st)
+        for (size_t i = 0; i < nb; i++)
+            if (std::isnan(row[i]) || std::isinf(row[i])) { st = SS_ERR_SCALING; break; }
+    if (st) {
+        xy[0] = 0.0; xy[1] = 0.0;                    // vec![(0., 0.)] (tui.rs:1437-1452, :1505-1524)
+        *n_out = 1;
+    } else {
+        for (size_t i = 0; i < nb; i++) {
+            xy[2 * i] = s->bt->chart_x[i];
+            xy[2 * i + 1] = (double)row[i] + s->bt->pink[i];
+        }
+        *n_out = (uint32_t)nb;
+    }
+    *status_out = st;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ss_session_close(ss_session *s)
+{
+    SS_ON_DEVICE(s);
+    if (!s) return;
+    if (s->fft_stream) { (void)hipStreamSynchronize(s->fft_stream); (void)hipStreamDestroy(s->fft_stream); }
+    if (s->an) ss_analyzer_destroy(s->an);
+    if (s->stage) (void)hipHostFree(s->stage);
+    if (s->stage_d) (void)hipHostFree(s->stage_d);
+    delete s;
+}
+
+ss_analyzer *ss_session_analyzer(ss_session *s) { return s ? s->an : nullptr; }
+
+int ss_session_open_file(const float *interleaved, size_t n_samples, uint32_t channels,
+                         uint32_t sample_rate, ss_session **out)
+{
+    if (!out) return SS_ERR_INVALID_ARG;
+    *out = nullptr;
+    if ((!interleaved && n_samples) || channels == 0 || sample_rate == 0) return SS_ERR_INVALID_ARG;
+    if (require_device()) return SS_ERR_DEVICE;
+    std::unique_ptr<ss_session, void (*)(ss_session *)> s(new ss_session(), ss_session_close);
+    s->device = current_device();
+    s->is_file = true; s->file_channels = channels; s->n_samples = n_samples;
+    int rc = session_common_init(s.get(), 2, sample_rate);          // meter: 2 channels (tui.rs:1217-1221)
+    if (rc) return rc;
+    ss_analyzer *h = s->an;
+    HIPCHK(s->pcm.alloc(n_samples ? n_samples : 1));
+    if (n_samples)
+        HIPCHK(hipMemcpyAsync(s->pcm.p, interleaved, n_samples * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    const size_t pairs = n_samples / 2;
+    for (size_t i = 0; i < pairs; i++) {
+        const uint8_t c = pair_class(interleaved[2 * i], interleaved[2 * i + 1]);
+        if (c) s->bad.emplace_back(i, c);
+    }
+    // AudioFile::from_file: duration = mid.len() / rate * 1000. ms, truncated (audio_player.rs:153-161)
+    const double dur_ms = (double)pairs / (double)sample_rate * 1000.0;
+    s->duration_ms = dur_ms >= 1.8446744073709552e19 ? UINT64_MAX : (uint64_t)dur_ms;
+    // Duration::as_secs_f64
+    const double dur_s = (double)(s->duration_ms / 1000) + (double)((s->duration_ms % 1000) * 1000000ull) / 1e9;
+    // audio_file_chart = get_waveform(samples, duration_s) on the resident buffer
+    size_t window, bins;
+    waveform_shape(n_samples, dur_s, &window, &bins);
+    if (bins > 0xFFFFFFFFull || window > 0xFFFFFFFFull) return SS_ERR_UNSUPPORTED;
+    if (bins) {
+        HIPCHK(s->wave.alloc(2 * bins));
+        ssk::WaveParams p{};
+        p.pcm = s->pcm.p; p.stream_stride = n_samples; p.n_samples = n_samples; p.n_streams = 1;
+        p.window = (uint32_t)window; p.out = s->wave.p; p.out_stride = 2 * bins;
+        HIPCHK(ssk::launch_waveform(p, h->stream));
+        std::vector<float> mm(2 * bins);
+        HIPCHK(hipMemcpyAsync(mm.data(), s->wave.p, 2 * bins * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        s->waveform_xy.resize(4 * bins);
+        for (size_t i = 0; i < bins; i++) {
+            s->waveform_xy[4 * i + 0] = (double)i; s->waveform_xy[4 * i + 1] = (double)mm[2 * i];
+            s->waveform_xy[4 * i + 2] = (double)i; s->waveform_xy[4 * i + 3] = (double)mm[2 * i + 1];
+        }
+        s->wave.release();
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    // fft_gain_compensation_db (tui.rs:1229-1238), f32 arithmetic
+    double integrated = 0.0;
+    rc = integrated_oneshot(sample_rate, 2, s->pcm.p, n_samples, true, &integrated);
+    s->gain_db = rc ? 0.0f : (-13.0f - (float)integrated);
+    rc = session_stage(s.get(), (size_t)2 * s->bin_stride);
+    if (rc) return rc;
+    *out = s.release();
+    return SS_OK;
+}
+
+int ss_session_open_capture(uint32_t channels, uint32_t sample_rate, ss_session **out)
+{
+    if (!out) return SS_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (sample_rate == 0) return SS_ERR_INVALID_ARG;
+    if ((uint64_t)15 * sample_rate < SS_TICK_WINDOW) return SS_ERR_INVALID_ARG;   // 15*sr - 2^14 underflows (tui.rs:1431)
+    if (require_device()) return SS_ERR_DEVICE;
+    std::unique_ptr<ss_session, void (*)(ss_session *)> s(new ss_session(), ss_session_close);
+    s->device = current_device();
+    s->is_file = false; s->file_channels = channels; s->n_samples = (size_t)30 * sample_rate;
+    int rc = session_common_init(s.get(), channels, sample_rate);
+    if (rc) return rc;
+    HIPCHK(s->pcm.alloc(s->n_samples));
+    HIPCHK(s->ms.alloc(s->n_samples));
+    size_t window, bins;
+    waveform_shape(s->n_samples / 2, 15.0, &window, &bins);
+    HIPCHK(s->wave.alloc(2 * bins ? 2 * bins : 2));
+    rc = session_stage(s.get(), (size_t)2 * s->bin_stride + 2 * bins);
+    if (rc) return rc;
+    *out = s.release();
+    return SS_OK;
+}
+
+int ss_session_waveform(ss_session *s, double *out_xy, size_t cap_pairs, size_t *out_n)
+{
+    SS_ON_DEVICE(s);
+    if (out_n) *out_n = 0;
+    if (!s || !s->is_file || (!out_xy && cap_pairs)) return SS_ERR_INVALID_ARG;
+    const size_t pairs = s->waveform_xy.size() / 2;
+    if (pairs > cap_pairs) return SS_ERR_CAPACITY;
+    if (pairs) std::memcpy(out_xy, s->waveform_xy.data(), s->waveform_xy.size() * sizeof(double));
+    if (out_n) *out_n = pairs;
+    return SS_OK;
+}
+
+int ss_session_gain_db(ss_session *s, float *out)
+{
+    SS_ON_DEVICE(s);
+    if (!s || !out) return SS_ERR_INVALID_ARG;
+    *out = s->gain_db;
+    return SS_OK;
+}
+
+int ss_session_duration_ms(ss_session *s, uint64_t *out)
+{
+    SS_ON_DEVICE(s);
+    if (!s || !out || !s->is_file) return SS_ERR_INVALID_ARG;
+    *out = s->duration_ms;
+    return SS_OK;
+}
+
+int ss_session_restart(ss_session *s)
+{
+    SS_ON_DEVICE(s);
+    if (!s) return SS_ERR_INVALID_ARG;
+    for (double &v : s->lufs) v = -100.0;
+    ss_reset(s->an);
+    return SS_OK;
+}
+
+int ss_session_lufs_history(ss_session *s, double *out300)
+{
+    SS_ON_DEVICE(s);
+    if (!s || !out300) return SS_ERR_INVALID_ARG;
+    std::memcpy(out300, s->lufs, sizeof s->lufs);
+    return SS_OK;
+}
+
+// analyze_audio_file_samples(pos) (tui.rs:1482-1552) on the resident file
+int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side_xy,
+                         size_t cap_pairs, ss_tick_result *res)
+{
+    SS_ON_DEVICE(s);
+    if (!s || !s->is_file || !res || !mid_xy || !side_xy) return SS_ERR_INVALID_ARG;
+    if (cap_pairs < s->bt->count || cap_pairs < 1) return SS_ERR_CAPACITY;
+    ss_analyzer *h = s->an;
+    std::memset(res, 0, sizeof *res);
+    const size_t pos_f = pos / s->file_channels;
+    res->playhead = pos_f;
+    bool fft_launched = false, st_launched = false;
+    int mid_st = SS_OK, side_st = SS_OK;
+
+    // ---- spectrum: the last 16384 mid / side samples before the playhead
+    const size_t fft_lb = pos_f > SS_TICK_WINDOW ? pos_f - SS_TICK_WINDOW : 0;     // saturating_sub
+    if (fft_lb != 0) {
+        res->fft_ran = 1;
+        const size_t ms_len = s->n_samples / 2;
+        if (pos_f <= ms_len && fft_lb < ms_len) {
+            // get_fft's own checks on a 16384-sample slice
+            mid_st = window_value_status(s, fft_lb, SS_TICK_WINDOW, 0, s->bad);
+            side_st = window_value_status(s, fft_lb, SS_TICK_WINDOW, 2, s->bad);
+            const int lim = (20000.0f > (float)h->rate / 2.0f) ? SS_ERR_FREQ_LIMIT : SS_OK;
+            if (!mid_st) mid_st = lim;
+            if (!side_st) side_st = lim;
+            if ((!mid_st || !side_st) && s->bt->count) {
+                // the file is resident and read-only: the spectrum runs on its own stream beside the loudness chain
+                int rc = session_enqueue_fft(s, s->pcm.p, fft_lb, s->fft_stream);
+                if (rc) return rc;
+                HIPCHK(hipMemcpyAsync(s->stage, s->spec.p, (size_t)2 * s->bin_stride * sizeof(float),
+                                      hipMemcpyDeviceToHost, s->fft_stream));
+                fft_launched = true;
+            }
+        } else {
+            mid_st = side_st = SS_ERR_TOO_FEW_SAMPLES;          // get_fft(&[])
+        }
+    }
+
+    // ---- loudness: the last 16384 interleaved samples, every tick (8x overlap at hop 1024 frames)
+    const size_t pos_i = pos_f * s->file_channels;
+    const size_t lufs_lb = pos_i > SS_TICK_WINDOW ? pos_i - SS_TICK_WINDOW : 0;
+    if (lufs_lb != 0) {
+        res->lufs_ran = 1;
+        std::memmove(&s->lufs[0], &s->lufs[1], (SS_LUFS_HISTORY - 1) * sizeof(double));
+        if (pos_i <= s->n_samples && lufs_lb < s->n_samples) {
+            res->fed = 1;
+            res->add_status = add_samples_impl(h, s->pcm.p + lufs_lb, SS_TICK_WINDOW, true);
+            if (res->add_status == SS_ERR_DEVICE) return SS_ERR_DEVICE;
+            if (!h->meter_ok) {
+                res->shortterm_status = SS_ERR_INVALID_MODE;
+            } else {
+                int rc = ring_loudness_enqueue(h, (uint64_t)h->td->host.s100 * 30);
+                if (rc) return rc;
+                HIPCHK(hipMemcpyAsync(s->stage_d, h->out2.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+                st_launched = true;
+            }
+        }
+    }
+    if (st_launched || res->fed) HIPCHK(hipStreamSynchronize(h->stream));
+    if (fft_launched) HIPCHK(hipStreamSynchronize(s->fft_stream));
+
+    if (res->fft_ran) {
+        session_emit_spectrum(s, s->stage, fft_launched ? mid_st : (mid_st ? mid_st : SS_OK), mid_xy,
+                              &res->mid_status, &res->n_mid);
+        session_emit_spectrum(s, s->stage + s->bin_stride, side_st, side_xy, &res->side_status, &res->n_side);
+    }
+    if (res->fed) s->lufs[SS_LUFS_HISTORY - 1] = st_launched ? s->stage_d[1] : 0.0;
+    res->shortterm = s->lufs[SS_LUFS_HISTORY - 1];
+    return SS_OK;
+}
+
+// analyze_microphone_input (tui.rs:1427-1480) on one snapshot of the capture ring
+int ss_session_tick_capture(ss_session *s, const float *latest, size_t n, double *mid_xy,
+                            double *side_xy, size_t cap_pairs, double *wave_xy,
+                            size_t wave_cap_pairs, size_t *wave_n, ss_tick_result *res)
+{
+    SS_ON_DEVICE(s);
+    if (wave_n) *wave_n = 0;
+    if (!s || s->is_file || !res || !mid_xy || !side_xy || !latest) return SS_ERR_INVALID_ARG;
+    if (n != s->n_samples) return SS_ERR_INVALID_ARG;
+    if (cap_pairs < s->bt->count || cap_pairs < 1) return SS_ERR_CAPACITY;
+    ss_analyzer *h = s->an;
+    const size_t pairs = n / 2;                                 // 15 * rate
+    size_t window, bins;
+    waveform_shape(pairs, 15.0, &window, &bins);
+    if (wave_xy && 2 * bins > wave_cap_pairs) return SS_ERR_CAPACITY;
+    std::memset(res, 0, sizeof *res);
+    res->fft_ran = 1; res->lufs_ran = 1; res->fed = 1;
+    HIPCHK(hipMemcpyAsync(s->pcm.p, latest, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    const size_t lb = pairs - SS_TICK_WINDOW;
+    // get_fft's value checks on the two 16384-sample slices
+    std::vector<std::pair<size_t, uint8_t>> bad;
+    for (size_t i = lb; i < pairs; i++) {
+        const uint8_t c = pair_class(latest[2 * i], latest[2 * i + 1]);
+        if (c) bad.emplace_back(i, c);
+    }
+    int mid_st = window_value_status(s, lb, SS_TICK_WINDOW, 0, bad);
+    int side_st = window_value_status(s, lb, SS_TICK_WINDOW, 2, bad);
+    const int lim = (20000.0f > (float)h->rate / 2.0f) ? SS_ERR_FREQ_LIMIT : SS_OK;
+    if (!mid_st) mid_st = lim;
+    if (!side_st) side_st = lim;
+    bool fft_launched = false;
+    if ((!mid_st || !side_st) && s->bt->count) {
+        int rc = session_enqueue_fft(s, s->pcm.p, lb, h->stream);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(s->stage, s->spec.p, (size_t)2 * s->bin_stride * sizeof(float),
+                              hipMemcpyDeviceToHost, h->stream));
+        fft_launched = true;
+    }
+    // microphone_input_chart = get_waveform(&mid_samples, 15.)
+    if (wave_xy && bins) {
+        HIPCHK(ssk::launch_mid_side(s->pcm.p, pairs, s->ms.p, s->ms.p + pairs, h->stream));
+        ssk::WaveParams p{};
+        p.pcm = s->ms.p; p.stream_stride = pairs; p.n_samples = pairs; p.n_streams = 1;
+        p.window = (uint32_t)window; p.out = s->wave.p; p.out_stride = 2 * bins;
+        HIPCHK(ssk::launch_waveform(p, h->stream));
+        HIPCHK(hipMemcpyAsync(s->stage + (size_t)2 * s->bin_stride, s->wave.p, 2 * bins * sizeof(float),
+                              hipMemcpyDeviceToHost, h->stream));
+    }
+    // loudness: shift, feed the newest 16384 samples, read short-term
+    std::memmove(&s->lufs[0], &s->lufs[1], (SS_LUFS_HISTORY - 1) * sizeof(double));
+    res->add_status = add_samples_impl(h, s->pcm.p + (n - SS_TICK_WINDOW), SS_TICK_WINDOW, true);
+    if (res->add_status == SS_ERR_DEVICE) return SS_ERR_DEVICE;
+    bool st_launched = false;
+    if (!h->meter_ok) {
+        res->shortterm_status = SS_ERR_INVALID_MODE;
+    } else {
+        int rc = ring_loudness_enqueue(h, (uint64_t)h->td->host.s100 * 30);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(s->stage_d, h->out2.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        st_launched = true;
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    (void)fft_launched;
+    session_emit_spectrum(s, s->stage, mid_st, mid_xy, &res->mid_status, &res->n_mid);
+    session_emit_spectrum(s, s->stage + s->bin_stride, side_st, side_xy, &res->side_status, &res->n_side);
+    if (wave_xy && bins) {
+        const float *mm = s->stage + (size_t)2 * s->bin_stride;
+        for (size_t i = 0; i < bins; i++) {
+            wave_xy[4 * i + 0] = (double)i; wave_xy[4 * i + 1] = (double)mm[2 * i];
+            wave_xy[4 * i + 2] = (double)i; wave_xy[4 * i + 3] = (double)mm[2 * i + 1];
+        }
+        if (wave_n) *wave_n = 2 * bins;
+    }
+    s->lufs[SS_LUFS_HISTORY - 1] = st_launched ? s->stage_d[1] : 0.0;
+    res->shortterm = s->lufs[SS_LUFS_HISTORY - 1];
+    return SS_OK;
+}
+
+}  // extern "C"
