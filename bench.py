@@ -73,18 +73,18 @@ def cpu_baseline(batch, rate, fft_n, hop, budget_s=15.0, all_cores_budget_s=8.0)
            "sample": f"{done - 1} of the batch's streams ({samples} samples), single thread, "
                      f"gcc -O3{' -march=native' if native else ''}, full analyze_stream pass "
                      "(waveform + mid/side + 2 FFTs/window incl. the crate's stats sorts + meter with true peak)"}
-    # the same pass on every host core, streams sharded over threads; ctypes drops the
-    # GIL inside the C call.  Informational: the reference itself is single-threaded (main.rs:67).
+    # the same pass on every host core: POSIX threads INSIDE the oracle library, streams dealt round-robin,
+    # eight whole stream passes per core, the clock started and stopped in C — no Python, no pool start-up in the timed
+    # region.  Informational: the reference itself is single-threaded (main.rs:67).
     try:
-        from concurrent.futures import ThreadPoolExecutor
         cores = len(os.sched_getaffinity(0))
-        per = 2 if cores <= 64 else 1            # streams per core: the leg stays a few seconds even on a 256-core host
-        xs = [batch.download_input(i % n_streams) for i in range(cores * per)]
-        t0 = time.perf_counter()
-        with ThreadPoolExecutor(cores) as ex:
-            list(ex.map(lambda x: po.analyze_stream(rate, x, fft_n, hop, want_fft=True, want_wave=True, native=native), xs))
-        dt = time.perf_counter() - t0
-        out["all_cores"] = {"value": sum(x.size for x in xs) / dt, "cores": cores, "streams": len(xs)}
+        distinct = min(n_streams, 64, 2 * cores)
+        xs = np.stack([batch.download_input(i) for i in range(distinct)])
+        po.analyze_streams_all_cores(rate, xs[:min(distinct, cores)], min(distinct, cores), fft_n, hop, cores, 1, native=native)   # page in, spin up
+        n_mt, reps = 2 * cores, 4
+        dt = po.analyze_streams_all_cores(rate, xs, n_mt, fft_n, hop, cores, reps, native=native)
+        out["all_cores"] = {"value": n_mt * reps * xs.shape[1] / dt, "cores": cores, "stream_passes": n_mt * reps,
+                            "seconds": dt, "how": "pthread workers inside oracle/libss_oracle (so_analyze_streams_mt), timed in C"}
     except Exception as e:            # never let the informational leg break the bench line
         out["all_cores"] = {"error": str(e)}
     return out, check
@@ -109,10 +109,12 @@ def self_check(batch, stream, ref):
             "true_peak_rel_err": tp_rel, "decimation_bit_exact": wave_ok, "ok": bool(ok)}
 
 
-def time_config(ssa, L, rate, channels, streams, frames, fft_n, hop, tp_factor, steps, warmup=1, flags=None):
+def time_config(ssa, L, rate, channels, streams, frames, fft_n, hop, tp_factor, steps, warmup=1, flags=None, tp_arith=None):
     """Per-kernel HIP-event times of one extra BASELINE configuration (informational lines under config.extra)."""
     b = ssa.Batch(rate, channels, streams, frames, fft_n, hop, flags=L.SS_BATCH_ALL if flags is None else flags, true_peak_factor=tp_factor)
     b.synthesize(0x5EED0000, 0)
+    if tp_arith is not None:
+        b.set_true_peak_arith(tp_arith)
     for _ in range(warmup):
         b.run(); b.sync()
     b.timing_enable(True)
@@ -156,8 +158,8 @@ def time_config(ssa, L, rate, channels, streams, frames, fft_n, hop, tp_factor, 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200, help="timed passes (default: a timed region of about 1 s)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--streams", type=int, default=1024, help="streams per GPU (config 3; weak scaling)")
     ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto",
                     help="auto: config 3 on one GPU, config 4 (8192 streams in total, strong scaling) on several")
@@ -166,9 +168,13 @@ def main():
     ap.add_argument("--rate", type=int, default=48000)
     ap.add_argument("--fft-n", type=int, default=4096)
     ap.add_argument("--hop", type=int, default=1024)
-    ap.add_argument("--sequential", action="store_true", help="spectrum kernel, then the time-domain chain, on one stream")
-    ap.add_argument("--overlap", type=int, default=2, choices=[0, 1, 2],
-                    help="ss_batch_set_overlap mode: 1 = spectrum kernel beside the whole time-domain chain, 2 (default) = beside its tail only")
+    ap.add_argument("--sequential", action="store_true", help="(the default) spectrum kernel, then the time-domain chain, on one stream")
+    ap.add_argument("--overlap", type=int, default=0, choices=[0, 1, 2],
+                    help="ss_batch_set_overlap mode: 0 (default) sequential; 1 = spectrum kernel beside the whole time-domain chain; "
+                         "2 = beside its tail only.  Measured step times are equal within 1 %% (DESIGN section 4), so the simplest one is timed")
+    ap.add_argument("--allow-host-fallback", action="store_true",
+                    help="N > 1: if the RCCL communicator cannot be created, stage the 16 kB exchange through host memory instead of failing "
+                         "(the JSON says which transport ran).  Without this flag a failed RCCL setup ends the run non-zero.")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg (and its parity check)")
     ap.add_argument("--no-extra", action="store_true", help="skip the config 2 / config 5 lines")
     args = ap.parse_args()
@@ -200,20 +206,37 @@ def main():
         raise SystemExit("ss_set_device failed: " + lib.ss_last_device_error().decode())
     comm = None
     if world > 1:
+        # The ranks must agree on the transport BEFORE using it.  With --allow-host-fallback every rank first joins a host-TCP
+        # control communicator, tries RCCL (the library makes ncclCommInitRank all-or-nothing across ranks and bounds it with
+        # a watchdog), and the ranks then sum their verdicts over the control channel: RCCL is used only if every rank has
+        # it.  Without the flag a rank that cannot create the RCCL communicator ends the run non-zero.
+        ctrl = None
+        if args.allow_host_fallback and transport == "rccl":
+            os.environ["SS_COMM_FILE"] = f"/tmp/ss_comm_ctrl_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}.rdzv"
+            ctrl = Comm.from_env("host-tcp")
+            os.environ.pop("SS_COMM_FILE")
+        err = None
         try:
             comm = Comm.from_env(transport)       # RCCL: ncclCommInitRank inside the library
             comm.barrier()                        # proves the communicator before anything is timed
-        except Exception as e:
-            # a broken RCCL setup must not cost the whole line: the 16 kB exchange can be staged through host memory
-            # (every rank takes this branch together when the bootstrap itself fails; the JSON says which transport ran)
-            print(f"[bench] rank {rank}: {transport} communicator failed ({e}); falling back to host-tcp", file=sys.stderr, flush=True)
-            if transport == "host-tcp":
-                raise
-            os.environ["SS_COMM_FILE"] = f"/tmp/ss_comm_fallback_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}.rdzv"
-            comm = Comm.from_env("host-tcp")
-            comm.barrier()
+        except Exception as e:                    # noqa: BLE001
+            err, comm = e, None
+        if ctrl is not None:
+            n_bad = int(ctrl.allreduce_sum_u64(np.array([0 if err is None else 1], np.uint64))[0])
+            if n_bad:
+                print(f"[bench] rank {rank}: {transport} unavailable on {n_bad} rank(s) ({err}); all ranks use host-tcp", file=sys.stderr, flush=True)
+                if comm is not None:
+                    comm.close()
+                comm = ctrl
+            else:
+                ctrl.close()
+        elif err is not None:
+            print(f"[bench] rank {rank}: {transport} communicator failed: {err} (--allow-host-fallback would stage the exchange "
+                  "through host memory)", file=sys.stderr, flush=True)
+            sys.exit(3)
         if comm.size != world:
             raise SystemExit(f"communicator reports {comm.size} ranks, expected {world}")
+        print(f"[bench] rank {rank}/{world}: collective = {comm.transport}, {comm.size} ranks", file=sys.stderr, flush=True)
 
     frames = int(round(args.seconds * args.rate))
     strong = args.scaling == "strong" or args.total_streams > 0 or (args.scaling == "auto" and world > 1)
@@ -311,6 +334,8 @@ def main():
                                    f" x {args.seconds:g} s, {args.rate} Hz stereo f32: mid/side {args.fft_n}-pt Hann FFT "
                                    f"hop {args.hop} + K-weighted gated LUFS/LRA + 4x true peak + min-max decimation "
                                    "+ corpus gate (1 all-reduce of 2x1000 u64)",
+                       "n1_workload": "N = 1 runs BASELINE config 3 (1024 streams on the GPU); N > 1 runs config 4 (8192 streams in total, "
+                                      "sharded, strong scaling): samples/s are comparable across N, ms_per_step are not",
                        "streams_total": total_streams, "streams_this_rank": count, "windows_per_stream": lay.n_windows, "bins": lay.n_bins,
                        "sharding": f"streams, {world} rank(s)",
                        "collective": ({"lib": "none", "nranks": 1} if comm is None else {"lib": comm.transport, "nranks": comm.size, "call": "ncclAllReduce(2000, ncclUint64, ncclSum) per step" if comm.transport == "rccl" else "host-staged sum over loopback TCP"}),
@@ -328,6 +353,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": lib.ss_batch_kernel_name(b._h, L.SS_KERNEL_FFT).decode(),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_note": "committed-profile data (PMC counters cannot be read inside this run); not an input of frac",
                          "algorithmic_bytes_per_launch": alg_bytes,
                          # context, measured in this run: the same loads and stores with no arithmetic in between
                          "io_floor": ({"ms": io_floor_ms, "GBps": alg_bytes / (io_floor_ms * 1e-3) / 1e9,
@@ -361,6 +387,10 @@ def main():
                 # 4x true peak and the decimation that north_star puts on the path
                 e = time_config(ssa, L, args.rate, 2, count, frames, args.fft_n, args.hop, 0, steps=5, flags=L.SS_BATCH_FFT | L.SS_BATCH_LUFS)
                 e["workload"] = f"config 3 without true peak and decimation: {count} streams x {args.seconds:g} s, spectrum + K-weighted gated LUFS / LRA only"
+                extra.append(e)
+                # the headline step with the true peak at the reference's f32 width (v_mfma_f32_16x16x4_f32 instead of the f16x3 split)
+                e = time_config(ssa, L, args.rate, 2, count, frames, args.fft_n, args.hop, 0, steps=5, tp_arith=L.SS_TP_ARITH_F32)
+                e["workload"] = f"config 3, full path, true peak in f32 MFMA arithmetic (ss_batch_set_true_peak_arith): {count} streams x {args.seconds:g} s"
                 extra.append(e)
                 # config 2: one stream (10 s and the 600 s steady-state variant)
                 for secs in (10, 600):

@@ -138,6 +138,10 @@ int ss_get_sample_peak_channel(ss_analyzer *h, uint32_t channel, double *out);
  * off); 2 or 4 = forced (BASELINE config 5 asks for 4x at 96 kHz).  Takes
  * effect at the next ss_analyzer_configure or ss_reset (both start a fresh meter). */
 int ss_analyzer_set_true_peak_factor(ss_analyzer *h, int factor);
+/* inspection (tests): the K-weighting filter's carried DF-II state v1..v4 of one channel, as ebur128's Filter keeps it
+ * between add_frames calls — sub-normal values flushed to zero at the end of every internal filter call like the crate
+ * does.  Waits for the handle's stream. */
+int ss_inspect_filter_state(ss_analyzer *h, uint32_t channel, double v4[4]);
 
 /* ------------------------------------------------------------------------ *
  *  PCM ingest: the step before the path.  The reference decodes a
@@ -294,6 +298,20 @@ int ss_batch_geometry_get(const ss_batch *b, ss_batch_geometry *out);
  *      latency-bound tail (per-stream gating / histograms, a standalone decimation).
  * Per-kernel event timing (ss_batch_timing_enable) always runs sequentially. */
 int ss_batch_set_overlap(ss_batch *b, int mode);
+/* arithmetic of the 4x true-peak interpolator in batches (2 / 8 channels; other shapes always take SS_TP_ARITH_F32):
+ *   SS_TP_ARITH_F16X3 (default)  three-term f16 split on the matrix cores with f32 accumulation, scaled per tile by a
+ *                                power of two from the tile's own peak: within 2^-21 of the tile peak of the f32 result
+ *                                (measured 1.4e-7 relative on the bench corpus; north_star's bar is 1e-4);
+ *   SS_TP_ARITH_F32              v_mfma_f32_16x16x4_f32: an f32 fmaf chain per output, the width of ebur128's interpolator
+ *                                (its 12 products per phase summed in f32), ~25 % more time-domain kernel time. */
+enum { SS_TP_ARITH_F16X3 = 0, SS_TP_ARITH_F32 = 1 };
+int ss_batch_set_true_peak_arith(ss_batch *b, int arith);
+/* verification utility: order-independent 64-bit checksums, computed on the device, of everything a pass left in HBM for
+ * each stream: out[3 * s + 0] the stream's whole spectrum block ([n_windows][fft_channels][fft_bin_stride] f32 bit patterns),
+ * out[3 * s + 1] its decimation bins, out[3 * s + 2] its sub-block energies (f64 bit patterns).  Two passes agree on a
+ * checksum iff (up to 2^-64) they agree bit for bit on the data: a stress test can compare EVERY window of a multi-gigabyte
+ * batch between launch modes (ss_batch_set_overlap) without downloading it.  Waits for the batch's stream. */
+int ss_batch_checksums(ss_batch *b, uint64_t *out, uint32_t cap_streams);
 /* spectrum of one stream: compact [n_windows][fft_channels][n_bins] f32 dB (pink-compensated);
  * on the device the rows are fft_bin_stride floats apart */
 int ss_batch_download_fft(ss_batch *b, uint32_t stream, float *out, size_t cap_floats);

@@ -49,6 +49,9 @@ def _load(native: bool = False):
     lib.so_meter_st_hist.argtypes = [vp]
     lib.so_meter_st_hist.restype = C.POINTER(C.c_uint64)
     lib.so_meter_filter_coeffs.argtypes = [vp, f64p, f64p]
+    lib.so_meter_filter_state.argtypes = [vp, C.c_uint32, f64p]
+    lib.so_analyze_streams_mt.argtypes = [C.c_uint32, f32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
+                                          C.c_int, C.c_int, f64p]
     lib.so_gated_loudness_hist.argtypes = [C.POINTER(C.c_uint64)]
     lib.so_gated_loudness_hist.restype = C.c_double
     lib.so_loudness_range_hist.argtypes = [C.POINTER(C.c_uint64)]
@@ -213,6 +216,14 @@ class Meter:
     def st_hist(self):
         return np.ctypeslib.as_array(lib().so_meter_st_hist(self._h), (1000,)).copy()
 
+    def filter_state(self, ch):
+        """carried DF-II state v1..v4 of channel `ch` after the last add_frames"""
+        v = (C.c_double * 4)()
+        rc = lib().so_meter_filter_state(self._h, ch, v)
+        if rc:
+            raise OracleError(rc)
+        return np.array(v)
+
     def coeffs(self):
         b = (C.c_double * 5)()
         a = (C.c_double * 5)()
@@ -280,3 +291,15 @@ def analyze_stream(sample_rate, x, fft_n=4096, hop=1024, force_tp_factor=0, want
             "sample_peak": list(res.sample_peak), "n_windows": res.n_windows, "n_bins": res.n_bins,
             "fft": fft[:res.n_windows] if want_fft else None,
             "wave": wave[:res.n_wave_points] if want_wave else None}
+
+
+def analyze_streams_all_cores(sample_rate, xs, n_streams, fft_n, hop, n_threads, reps=1, native=False):
+    """Wall-clock seconds for `n_streams` whole analyze_stream passes (stream s = row s % len(xs) of the 2-D array xs) on
+    `n_threads` POSIX threads, `reps` times — timed inside the C library (bench.py's all-cores CPU leg)."""
+    xs = np.ascontiguousarray(xs, dtype=np.float32)
+    el = C.c_double()
+    rc = lib(native).so_analyze_streams_mt(sample_rate, xs.ctypes.data_as(C.POINTER(C.c_float)), xs.shape[1], xs.shape[0],
+                                           n_streams, fft_n, hop, n_threads, reps, C.byref(el))
+    if rc:
+        raise OracleError(rc)
+    return el.value

@@ -12,9 +12,11 @@
  * Build: see oracle/Makefile (gcc -O3 -ffp-contract=off: the Rust reference
  * never contracts a*b+c into an FMA, so neither may this file).
  */
+#define _POSIX_C_SOURCE 200809L   /* clock_gettime, pthread barriers (all-cores timing leg) */
 #include "ss_oracle.h"
 
 #include <float.h>
+#include <stdio.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -516,6 +518,14 @@ void so_meter_filter_coeffs(so_meter *m, double b[5], double a[5])
     memcpy(b, m->b, sizeof m->b); memcpy(a, m->a, sizeof m->a);
 }
 
+/* carried DF-II state v1..v4 of one channel (what Filter::process leaves behind, sub-normals flushed) */
+int so_meter_filter_state(so_meter *m, uint32_t ch, double v4[4])
+{
+    if (ch >= m->channels) return SO_ERR_INVALID_CHANNEL;
+    for (int k = 0; k < 4; k++) v4[k] = m->v[ch][k + 1];
+    return SO_OK;
+}
+
 /* Filter::process: sample peak, true peak (polyphase FIR, f32), K-weighting
  * (DF-II, f64) into the ring buffer at audio_data_index. */
 static void filter_process(so_meter *m, const float *src, size_t frames)
@@ -794,4 +804,63 @@ int so_analyze_stream(uint32_t sample_rate, const float *x, size_t n_samples,
     }
     so_meter_free(m);
     return SO_OK;
+}
+
+/* ---- all-cores timing leg of bench.py's cpu_baseline (no Python inside the timed region) ---------------------------
+ * n_streams equal-length stereo streams (stream s reads buffer s % n_distinct), dealt round-robin to n_threads POSIX threads; every thread runs the whole
+ * so_analyze_stream pass (waveform + mid/side + two spectra per window incl. the crate's stats sorts + meter with true
+ * peak) on its streams, `reps` times.  Returns the wall-clock seconds between the start barrier and the last join. */
+#include <pthread.h>
+#include <time.h>
+typedef struct {
+    uint32_t rate; const float *x; size_t n_samples, n_streams, n_distinct, fft_n, hop; int tid, n_threads, reps, rc;
+    pthread_barrier_t *start;
+} mt_job;
+
+static void *mt_worker(void *arg)
+{
+    mt_job *j = (mt_job *)arg;
+    size_t first_k, nb = so_fft_bins(j->rate, j->fft_n, &first_k);
+    size_t F = j->n_samples / 2, nwin = F / j->hop > j->fft_n / j->hop ? F / j->hop - j->fft_n / j->hop : 0;
+    float *fft_out = (float *)malloc((nwin * 2 * nb + 1) * sizeof(float));
+    pthread_barrier_wait(j->start);
+    for (int r = 0; r < j->reps; r++)
+        for (size_t s = (size_t)j->tid; s < j->n_streams; s += (size_t)j->n_threads) {
+            so_stream_result res;
+            int rc = so_analyze_stream(j->rate, j->x + (s % j->n_distinct) * j->n_samples, j->n_samples, j->fft_n, j->hop, 0, fft_out, NULL, &res);
+            if (rc) j->rc = rc;
+        }
+    free(fft_out);
+    return NULL;
+}
+
+int so_analyze_streams_mt(uint32_t rate, const float *x, size_t n_samples, size_t n_distinct, size_t n_streams, size_t fft_n,
+                          size_t hop, int n_threads, int reps, double *elapsed_s)
+{
+    if (n_threads < 1 || !n_streams || !n_distinct || !elapsed_s) return SO_ERR_NOMEM;
+    pthread_t *th = (pthread_t *)malloc((size_t)n_threads * sizeof *th);
+    mt_job *jobs = (mt_job *)calloc((size_t)n_threads, sizeof *jobs);
+    pthread_barrier_t start;
+    pthread_barrier_init(&start, NULL, (unsigned)n_threads + 1);
+    hist_init();                                  /* shared tables are built before the threads start */
+    int started = 0;
+    for (int t = 0; t < n_threads; t++) {
+        jobs[t] = (mt_job){rate, x, n_samples, n_streams, n_distinct, fft_n, hop, t, n_threads, reps, 0, &start};
+        if (pthread_create(&th[t], NULL, mt_worker, &jobs[t]) != 0) break;
+        started++;
+    }
+    int rc = SO_OK;
+    if (started != n_threads) {                   /* cannot release the barrier with fewer threads: fail loudly */
+        fprintf(stderr, "so_analyze_streams_mt: only %d of %d threads started\n", started, n_threads);
+        abort();
+    }
+    struct timespec t0, t1;
+    pthread_barrier_wait(&start);
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int t = 0; t < n_threads; t++) { pthread_join(th[t], NULL); if (jobs[t].rc) rc = jobs[t].rc; }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    *elapsed_s = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    pthread_barrier_destroy(&start);
+    free(th); free(jobs);
+    return rc;
 }

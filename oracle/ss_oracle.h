@@ -85,6 +85,8 @@ int so_meter_true_peak(so_meter *m, uint32_t ch, double *out);
 const uint64_t *so_meter_block_hist(so_meter *m);   /* 1000 bins */
 const uint64_t *so_meter_st_hist(so_meter *m);      /* 1000 bins */
 void so_meter_filter_coeffs(so_meter *m, double b[5], double a[5]);
+/* carried DF-II state v1..v4 of one channel after the last add_frames (sub-normals flushed like ebur128's Filter::process) */
+int so_meter_filter_state(so_meter *m, uint32_t ch, double v4[4]);
 /* loudness_global_multiple / loudness_range_multiple on summed histograms */
 double so_gated_loudness_hist(const uint64_t *hist);
 double so_loudness_range_hist(const uint64_t *st_hist);
@@ -110,6 +112,12 @@ typedef struct {
 int so_analyze_stream(uint32_t sample_rate, const float *interleaved, size_t n_samples,
                       size_t fft_n, size_t hop_frames, int force_tp_factor,
                       float *fft_out, double *wave_out, so_stream_result *res);
+
+/* bench.py's all-cores CPU leg: n_streams equal-length stereo streams (stream s = buffer s % n_distinct of `interleaved`)
+ * dealt round-robin to n_threads POSIX threads, each running the whole so_analyze_stream pass `reps` times;
+ * *elapsed_s = wall clock of the threaded region (no Python inside it). */
+int so_analyze_streams_mt(uint32_t sample_rate, const float *interleaved, size_t n_samples_per_stream, size_t n_distinct,
+                          size_t n_streams, size_t fft_n, size_t hop_frames, int n_threads, int reps, double *elapsed_s);
 
 #ifdef __cplusplus
 }

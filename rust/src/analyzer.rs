@@ -1,6 +1,9 @@
 //! soundscope Analyzer on libsoundscope_hip.so (MI355X).  Same public API as upstream analyzer.rs.
 use eyre::{eyre, Result};
-use std::os::raw::{c_double, c_float, c_int};
+use spectrum_analyzer::error::SpectrumAnalyzerError;
+use spectrum_analyzer::FrequencyLimitError;
+use std::ffi::CStr;
+use std::os::raw::{c_char, c_double, c_float, c_int};
 
 #[repr(C)]
 pub struct SsAnalyzer { _private: [u8; 0] }
@@ -28,10 +31,27 @@ extern "C" {
     fn ss_get_true_peak_channel(h: *mut SsAnalyzer, channel: u32, out: *mut c_double) -> c_int;
     fn ss_get_sample_peak_channel(h: *mut SsAnalyzer, channel: u32, out: *mut c_double) -> c_int;
     fn ss_analyzer_set_true_peak_factor(h: *mut SsAnalyzer, factor: c_int) -> c_int;
+    fn ss_status_string(status: c_int) -> *const c_char;
 }
 
 fn ebu_err(rc: c_int) -> ebur128::Error {
     match rc { 2 => ebur128::Error::InvalidMode, 3 => ebur128::Error::InvalidChannelIndex, _ => ebur128::Error::NoMem }
+}
+
+/// get_fft's `?` in upstream analyzer.rs:60-65 turns a `SpectrumAnalyzerError` into the eyre report whose text the TUI
+/// prints (tui.rs:1439-1442): the same variants come back here, so the message a user sees does not change.  The C ABI
+/// carries the variant, not its payload: the frequency-limit error can only be the upper bound of Range(20, 20000)
+/// against Nyquist; the scaling error's two values (original, scaled) are not known at this boundary.
+fn fft_err(rc: c_int) -> eyre::Report {
+    match rc {
+        10 => SpectrumAnalyzerError::TooFewSamples.into(),
+        11 => SpectrumAnalyzerError::NaNValuesNotSupported.into(),
+        12 => SpectrumAnalyzerError::InfinityValuesNotSupported.into(),
+        13 => SpectrumAnalyzerError::SamplesLengthNotAPowerOfTwo.into(),
+        14 => SpectrumAnalyzerError::InvalidFrequencyLimit(FrequencyLimitError::ValueAboveNyquist(20000.)).into(),
+        15 => SpectrumAnalyzerError::ScalingError(f32::NAN, f32::NAN).into(),
+        _ => eyre!("soundscope_hip: {}", unsafe { CStr::from_ptr(ss_status_string(rc)) }.to_string_lossy()),
+    }
 }
 
 pub struct Analyzer { h: *mut SsAnalyzer }
@@ -57,7 +77,7 @@ impl Analyzer {
         let mut n = 0usize;
         let rc = unsafe { ss_get_fft(self.h, samples.as_ptr(), samples.len(),
                                      out.as_mut_ptr() as *mut f64, cap, &mut n) };
-        if rc != 0 { return Err(eyre!("spectrum analyzer error {rc}")); }
+        if rc != 0 { return Err(fft_err(rc)); }
         out.truncate(n);
         Ok(out)
     }

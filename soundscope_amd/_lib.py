@@ -39,7 +39,7 @@ SYMBOLS = [
     "ss_comm_init", "ss_comm_init_from_env", "ss_comm_destroy", "ss_comm_rank", "ss_comm_size",
     "ss_comm_transport_name", "ss_comm_barrier", "ss_comm_allreduce_u64_sum", "ss_comm_allreduce_f64_max",
     "ss_batch_allreduce_histograms", "ss_batch_traffic_floor",
-    "ss_batch_corpus_gate_enqueue", "ss_batch_corpus_gate_read",
+    "ss_batch_corpus_gate_enqueue", "ss_batch_corpus_gate_read", "ss_batch_checksums", "ss_inspect_filter_state", "ss_batch_set_true_peak_arith",
     "ss_inspect_kweight", "ss_inspect_true_peak", "ss_inspect_hann", "ss_inspect_bins", "ss_inspect_histogram",
 ]
 
@@ -52,6 +52,7 @@ SS_BATCH_FFT, SS_BATCH_LUFS, SS_BATCH_TRUE_PEAK, SS_BATCH_WAVEFORM, SS_BATCH_ALL
 SS_PCM_U8, SS_PCM_S16, SS_PCM_S24, SS_PCM_S32, SS_PCM_F32, SS_PCM_F64 = 1, 2, 3, 4, 5, 6
 SS_GAIN_FIXED, SS_GAIN_REFERENCE = 0, 1
 SS_COMM_RCCL, SS_COMM_HOST_TCP = 0, 1
+SS_TP_ARITH_F16X3, SS_TP_ARITH_F32 = 0, 1
 SS_KERNEL_FFT, SS_KERNEL_TIME_DOMAIN, SS_KERNEL_FINALIZE, SS_KERNEL_WAVEFORM, SS_KERNEL_COUNT = 0, 1, 2, 3, 4
 
 
@@ -200,6 +201,9 @@ def _bind(lib):
         "ss_batch_traffic_floor": (C.c_int, [vp, C.c_uint32, f64p]),
         "ss_batch_corpus_gate_enqueue": (C.c_int, [vp, vp]),
         "ss_batch_corpus_gate_read": (C.c_int, [vp, f64p, f64p]),
+        "ss_batch_checksums": (C.c_int, [vp, u64p, C.c_uint32]),
+        "ss_inspect_filter_state": (C.c_int, [vp, C.c_uint32, f64p]),
+        "ss_batch_set_true_peak_arith": (C.c_int, [vp, C.c_int]),
         "ss_inspect_kweight": (C.c_int, [C.c_uint32, f64p, f64p]),
         "ss_inspect_true_peak": (C.c_int, [C.c_int, f32p, C.c_uint32, C.POINTER(C.c_uint32)]),
         "ss_inspect_hann": (C.c_int, [C.c_uint32, f32p]),

@@ -142,6 +142,12 @@ class Analyzer:
         _check(L.lib().ss_get_sample_peak_channel(self._h, ch, C.byref(v)))
         return v.value
 
+    def filter_state(self, ch: int) -> np.ndarray:
+        """carried DF-II state v1..v4 of the K-weighting filter of channel `ch` (inspection; ebur128 Filter state)"""
+        v = np.zeros(4, np.float64)
+        _check(L.lib().ss_inspect_filter_state(self._h, ch, v.ctypes.data_as(C.POINTER(C.c_double))))
+        return v
+
     def set_true_peak_factor(self, factor: int) -> None:
         _check(L.lib().ss_analyzer_set_true_peak_factor(self._h, factor))
 

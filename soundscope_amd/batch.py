@@ -102,6 +102,10 @@ class Batch:
         2: beside the chain's tail only (time-domain kernel first and alone).  Same results in every mode."""
         _check(L.lib().ss_batch_set_overlap(self._h, int(mode)))
 
+    def set_true_peak_arith(self, arith):
+        """L.SS_TP_ARITH_F16X3 (default: f16x3 split on the matrix cores) or L.SS_TP_ARITH_F32 (f32 MFMA, the crate's width)."""
+        _check(L.lib().ss_batch_set_true_peak_arith(self._h, int(arith)))
+
     def allreduce_histograms(self, comm):
         """The corpus gate's exchange: in-place SUM all-reduce of this batch's corpus histograms over `comm`
         (soundscope_amd.distributed.Comm).  Returns (block_hist, shortterm_hist) of the whole corpus."""
@@ -124,6 +128,14 @@ class Batch:
         ms = C.c_double()
         _check(L.lib().ss_batch_traffic_floor(self._h, reps, C.byref(ms)))
         return ms.value
+
+    def checksums(self):
+        """[n_streams][3] u64, computed on the device: order-independent checksums of every stream's whole spectrum block,
+        decimation bins and sub-block energies (bit patterns).  Equal checksums <=> bit-equal data (up to 2^-64)."""
+        n = int(self.cfg.n_streams)
+        out = np.zeros((n, 3), np.uint64)
+        _check(L.lib().ss_batch_checksums(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), n))
+        return out
 
     def fft(self, stream):
         lay = self.layout

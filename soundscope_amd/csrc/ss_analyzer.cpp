@@ -447,6 +447,17 @@ int ss_get_sample_peak_channel(ss_analyzer *h, uint32_t channel, double *out)
     return read_peaks(h, channel, out, nullptr);
 }
 
+int ss_inspect_filter_state(ss_analyzer *h, uint32_t channel, double v4[4])
+{
+    SS_ON_DEVICE(h);
+    if (!h || !v4) return SS_ERR_INVALID_ARG;
+    if (!h->meter_ok) return SS_ERR_INVALID_MODE;
+    if (channel >= h->channels) return SS_ERR_INVALID_CHANNEL;
+    HIPCHK(hipMemcpyAsync(v4, &h->state.p->v[channel][0], 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SS_OK;
+}
+
 uint32_t ss_sample_rate(const ss_analyzer *h) { return h ? h->rate : 0; }
 
 }  // extern "C"

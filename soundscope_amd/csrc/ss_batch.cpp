@@ -33,6 +33,7 @@ struct ss_batch {
     DevBuf<uint64_t> hist, corpus;
     DevBuf<uint32_t> counts;
     DevBuf<unsigned char> raw;      // device staging of raw PCM for the asynchronous ingest
+    DevBuf<uint64_t> checks;        // ss_batch_checksums: [stream][3]
     // ragged batches (ss_batch_set_lengths): per-stream frames / windows / sub-blocks / decimation bins
     bool ragged = false;
     std::vector<uint64_t> frames_h, wave_samples_h;
@@ -46,6 +47,8 @@ struct ss_batch {
     // opt-in (SS_BATCH_OVERLAP=1): the spectrum kernel on a second stream beside the time-domain chain
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool corpus_reduced = false;      // this pass's corpus histograms already hold the all-reduced sums
+    int tp_arith = 0;                 // SS_TP_ARITH_*
     int overlap = 0;                  // 0 sequential, 1 the spectrum kernel beside the time-domain chain, 2 beside its tail only
     bool timing = false;
     hipEvent_t ev[2 * SS_KERNEL_COUNT] = {};
@@ -59,6 +62,7 @@ namespace ssi {
 void *batch_corpus_device(ss_batch *b) { return b ? b->corpus.p : nullptr; }
 hipStream_t batch_stream(ss_batch *b) { return b ? b->stream : nullptr; }
 int batch_device(const ss_batch *b) { return b ? b->device : 0; }
+bool &batch_corpus_reduced(ss_batch *b) { return b->corpus_reduced; }
 }  // namespace ssi
 
 namespace {
@@ -437,6 +441,7 @@ int ss_batch_run(ss_batch *b)
     if (!b) return SS_ERR_INVALID_ARG;
     int rc = batch_collect_timing(b);
     if (rc) return rc;
+    b->corpus_reduced = false;
     const ss_batch_config &c = b->cfg;
     const ss_batch_layout &L = b->lay;
     const uint32_t C = c.channels;
@@ -521,6 +526,7 @@ int ss_batch_run(ss_batch *b)
         p.sub_stride = (uint64_t)p.sub_cap * C; p.ring = nullptr; p.ring_frames = 0; p.tp_factor = b->tp_factor;
         p.s100 = b->td->host.s100; p.nseg = b->td_nseg; p.seg_sub = b->td_seg_sub; p.warm_sub = kTdWarmSub;
         p.frames_of = b->ragged ? b->frames_d.p : nullptr;
+        p.tp_f32 = b->tp_arith == SS_TP_ARITH_F32 ? 1u : 0u;
         if (b->wave_fused && !b->ragged) { p.wave_out = b->wave.p; p.wave_stride = (uint64_t)2 * b->wave_window; p.wave_window = b->wave_window; p.halo_frames = b->wave_halo; }
         HIPCHK(ssk::launch_time_domain(p, b->stream));
     }
@@ -699,6 +705,39 @@ int ss_batch_set_overlap(ss_batch *b, int enable)
     }
     HIPCHK(hipStreamSynchronize(b->stream));
     b->overlap = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
+    return SS_OK;
+}
+
+int ss_batch_checksums(ss_batch *b, uint64_t *out, uint32_t cap_streams)
+{
+    SS_ON_DEVICE(b);
+    if (!b || !out) return SS_ERR_INVALID_ARG;
+    const uint32_t ns = b->cfg.n_streams;
+    if (cap_streams < ns) return SS_ERR_CAPACITY;
+    HIPCHK(b->checks.ensure((size_t)3 * ns));
+    HIPCHK(hipMemsetAsync(b->checks.p, 0, (size_t)3 * ns * sizeof(uint64_t), b->stream));
+    const ss_batch_layout &L = b->lay;
+    if (b->fft.p && L.n_windows) {
+        const uint64_t words = (uint64_t)L.n_windows * L.fft_channels * L.fft_bin_stride;
+        HIPCHK(ssk::launch_checksum(b->fft.p, words, words, ns, b->checks.p, 3, b->stream));
+    }
+    if (b->wave.p && b->wave_window) {
+        const uint64_t words = (uint64_t)2 * b->wave_window;
+        HIPCHK(ssk::launch_checksum(b->wave.p, words, words, ns, b->checks.p + 1, 3, b->stream));
+    }
+    if (b->sub.p && L.n_subblocks) {
+        const uint64_t words = (uint64_t)2 * L.n_subblocks * b->cfg.channels;
+        HIPCHK(ssk::launch_checksum(b->sub.p, words, words, ns, b->checks.p + 2, 3, b->stream));
+    }
+    HIPCHK(hipMemcpyAsync(out, b->checks.p, (size_t)3 * ns * sizeof(uint64_t), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return SS_OK;
+}
+
+int ss_batch_set_true_peak_arith(ss_batch *b, int arith)
+{
+    if (!b || (arith != SS_TP_ARITH_F16X3 && arith != SS_TP_ARITH_F32)) return SS_ERR_INVALID_ARG;
+    b->tp_arith = arith;
     return SS_OK;
 }
 

@@ -11,8 +11,15 @@
 // Transport SS_COMM_HOST_TCP: the same entry points staged through host memory over loopback TCP (star through
 // rank 0).  It exists so the rank logic can be run on CPU-only machines and by ranks that share one GPU.
 //
-// Rendezvous (one node): rank 0 writes "<magic> <tcp port> <rccl unique id in hex>" to a file (write + rename,
-// so readers never see a partial file), the other ranks poll for it; rank 0 removes it once every rank has joined.
+// Rendezvous (one node): rank 0 listens on an ephemeral loopback port and writes
+//     "<magic> <tcp port> <rccl unique id in hex> <64-bit nonce>"
+// to the rendezvous file (created with O_EXCL | O_NOFOLLOW, mode 0600, then renamed into place, so readers never see a
+// partial file and a planted symlink is not followed).  Every other rank polls for the file, connects to the port and
+// sends (its rank, the nonce it read); rank 0 answers with the nonce.  A file left behind by a crashed or earlier job
+// therefore cannot be consumed: its port is dead (connection refused) or answers with another nonce, and the rank
+// simply keeps polling until the live rank 0 has replaced the file.  For SS_COMM_HOST_TCP those connections are the
+// data path; for SS_COMM_RCCL they carry only the join handshake and the ranks' verdicts on ncclCommInitRank (all ranks
+// succeed or all fail), which itself runs under a watchdog.  Rank 0 removes the file once every rank has joined.
 #include "../../include/soundscope_hip.h"
 
 #include <hip/hip_runtime.h>
@@ -22,6 +29,7 @@
 #include <dlfcn.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <fcntl.h>
 #include <sys/socket.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -31,6 +39,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -39,8 +49,21 @@
 
 namespace {
 
-constexpr const char *kMagic = "ssc1";
-constexpr int kJoinTimeoutS = 180;
+constexpr const char *kMagic = "ssc2";
+// SS_COMM_TIMEOUT_S (seconds, default 180): how long a rank waits for the others at the rendezvous and inside ncclCommInitRank
+int join_timeout_s()
+{
+    if (const char *e = std::getenv("SS_COMM_TIMEOUT_S")) { const int v = std::atoi(e); if (v >= 1 && v <= 3600) return v; }
+    return 180;
+}
+
+uint64_t fresh_nonce()
+{
+    uint64_t v = 0;
+    if (FILE *f = std::fopen("/dev/urandom", "rb")) { if (std::fread(&v, sizeof v, 1, f) != 1) v = 0; std::fclose(f); }
+    if (!v) v = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() * 0x9E3779B97F4A7C15ull ^ (uint64_t)::getpid();
+    return v ? v : 1;
+}
 
 struct Rccl {
     void *dl = nullptr;
@@ -117,27 +140,35 @@ bool unhex(const std::string &s, unsigned char *p, size_t n)
     return true;
 }
 
-bool write_rendezvous(const std::string &path, int port, const ncclUniqueId *id)
+bool write_rendezvous(const std::string &path, int port, const ncclUniqueId *id, uint64_t nonce)
 {
-    const std::string tmp = path + ".tmp";
-    FILE *f = std::fopen(tmp.c_str(), "w");
-    if (!f) return false;
+    const std::string tmp = path + ".tmp." + std::to_string((long)::getpid());
+    ::unlink(tmp.c_str());
+    const int fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    if (fd < 0) return false;
     const std::string hex = id ? hex_of(reinterpret_cast<const unsigned char *>(id->internal), sizeof id->internal) : std::string("-");
-    std::fprintf(f, "%s %d %s\n", kMagic, port, hex.c_str());
-    std::fclose(f);
-    return std::rename(tmp.c_str(), path.c_str()) == 0;
+    char head[64];
+    std::snprintf(head, sizeof head, "%s %d ", kMagic, port);
+    const std::string text = std::string(head) + hex + " " + std::to_string((unsigned long long)nonce) + "\n";
+    const bool ok = ::write(fd, text.data(), text.size()) == (ssize_t)text.size();
+    ::close(fd);
+    if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) { ::unlink(tmp.c_str()); return false; }
+    return true;
 }
 
-bool read_rendezvous(const std::string &path, int *port, std::string *hex)
+bool read_rendezvous(const std::string &path, int *port, std::string *hex, uint64_t *nonce)
 {
-    FILE *f = std::fopen(path.c_str(), "r");
-    if (!f) return false;
+    const int fd = ::open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0) return false;
+    FILE *f = ::fdopen(fd, "r");
+    if (!f) { ::close(fd); return false; }
     char magic[16] = {0}, idbuf[600] = {0};
     int p = 0;
-    const int n = std::fscanf(f, "%15s %d %599s", magic, &p, idbuf);
+    unsigned long long nn = 0;
+    const int n = std::fscanf(f, "%15s %d %599s %llu", magic, &p, idbuf, &nn);
     std::fclose(f);
-    if (n != 3 || std::strcmp(magic, kMagic) != 0) return false;
-    *port = p; *hex = idbuf;
+    if (n != 4 || std::strcmp(magic, kMagic) != 0 || p <= 0 || nn == 0) return false;
+    *port = p; *hex = idbuf; *nonce = (uint64_t)nn;
     return true;
 }
 
@@ -191,37 +222,55 @@ int tcp_listen(ss_comm *c, int *port_out)
     return SS_OK;
 }
 
-int tcp_accept_all(ss_comm *c)
+// rank 0: accept world - 1 joins.  A connection that does not present (rank, this init's nonce) is not one of ours
+// (a rank that read a stale file, a port scanner): it is dropped and the wait goes on.
+int tcp_accept_all(ss_comm *c, uint64_t nonce)
 {
     c->peers.assign((size_t)c->world, -1);
-    for (int k = 1; k < c->world; k++) {
-        timeval tv{kJoinTimeoutS, 0};
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(join_timeout_s());
+    for (int joined = 1; joined < c->world;) {
+        const auto left = std::chrono::duration_cast<std::chrono::milliseconds>(deadline - std::chrono::steady_clock::now()).count();
+        if (left <= 0) return fail("rank 0: timed out waiting for the other ranks");
+        timeval tv{(time_t)(left / 1000), (suseconds_t)((left % 1000) * 1000)};
         fd_set rd; FD_ZERO(&rd); FD_SET(c->listen_fd, &rd);
-        if (::select(c->listen_fd + 1, &rd, nullptr, nullptr, &tv) <= 0) return fail("rank 0: timed out waiting for the other ranks");
+        if (::select(c->listen_fd + 1, &rd, nullptr, nullptr, &tv) <= 0) continue;
         const int fd = ::accept(c->listen_fd, nullptr, nullptr);
-        if (fd < 0) return fail("accept() failed");
+        if (fd < 0) continue;
         int one = 1;
         ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
-        int32_t r = -1;
-        if (!recv_all(fd, &r, sizeof r) || r <= 0 || r >= c->world || c->peers[(size_t)r] != -1) { ::close(fd); return fail("bad rank handshake"); }
-        c->peers[(size_t)r] = fd;
+        timeval rto{5, 0};
+        ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &rto, sizeof rto);
+        uint64_t hello[2] = {0, 0};                 // (rank, nonce)
+        if (!recv_all(fd, hello, sizeof hello) || hello[1] != nonce || hello[0] == 0 || hello[0] >= (uint64_t)c->world ||
+            c->peers[(size_t)hello[0]] != -1) { ::close(fd); continue; }
+        if (!send_all(fd, &nonce, sizeof nonce)) { ::close(fd); continue; }
+        timeval none{0, 0};
+        ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &none, sizeof none);
+        c->peers[(size_t)hello[0]] = fd;
+        joined++;
     }
     return SS_OK;
 }
 
-int tcp_connect(ss_comm *c, int port)
+// other ranks: 0 joined; 1 the file is stale (nobody listens there, or whoever does is not this job's rank 0): poll again
+int tcp_try_join(ss_comm *c, int port, uint64_t nonce)
 {
     const int fd = ::socket(AF_INET, SOCK_STREAM, 0);
     if (fd < 0) return fail("socket() failed");
     sockaddr_in a{};
     a.sin_family = AF_INET; a.sin_addr.s_addr = htonl(INADDR_LOOPBACK); a.sin_port = htons((uint16_t)port);
-    if (::connect(fd, reinterpret_cast<sockaddr *>(&a), sizeof a) != 0) { ::close(fd); return fail("connect to rank 0 failed"); }
+    if (::connect(fd, reinterpret_cast<sockaddr *>(&a), sizeof a) != 0) { ::close(fd); return 1; }
     int one = 1;
     ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
-    const int32_t r = c->rank;
-    if (!send_all(fd, &r, sizeof r)) { ::close(fd); return fail("rank handshake failed"); }
+    timeval rto{5, 0};
+    ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &rto, sizeof rto);
+    const uint64_t hello[2] = {(uint64_t)c->rank, nonce};
+    uint64_t echo = 0;
+    if (!send_all(fd, hello, sizeof hello) || !recv_all(fd, &echo, sizeof echo) || echo != nonce) { ::close(fd); return 1; }
+    timeval none{0, 0};
+    ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &none, sizeof none);
     c->peers.assign(1, fd);
-    return SS_OK;
+    return 0;
 }
 
 // element-wise reduction of `n` 8-byte words across the ranks, in place (op 0: u64 sum, 1: f64 max)
@@ -315,28 +364,62 @@ int ss_comm_init(int transport, int rank, int world, const char *rendezvous_file
     int port = 0;
     if (world > 1) {
         if (rank == 0) {
-            if (transport == SS_COMM_HOST_TCP) { int rc = tcp_listen(c, &port); if (rc) return rc; }
-            ::unlink(c->file.c_str());
-            if (!write_rendezvous(c->file, port, transport == SS_COMM_RCCL ? &id : nullptr)) return fail("cannot write the rendezvous file " + c->file);
+            const uint64_t nonce = fresh_nonce();
+            int rc = tcp_listen(c, &port);                      // both transports: the join handshake runs over loopback TCP
+            if (rc) return rc;
+            ::unlink(c->file.c_str());                          // whatever an earlier job left there
+            if (!write_rendezvous(c->file, port, transport == SS_COMM_RCCL ? &id : nullptr, nonce)) return fail("cannot write the rendezvous file " + c->file);
+            rc = tcp_accept_all(c, nonce);
+            if (rc) return rc;
         } else {
             std::string hex;
+            uint64_t nonce = 0;
             const auto t0 = std::chrono::steady_clock::now();
-            while (!read_rendezvous(c->file, &port, &hex)) {
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(kJoinTimeoutS)) return fail("timed out waiting for rank 0's rendezvous file " + c->file);
+            for (;;) {
+                if (read_rendezvous(c->file, &port, &hex, &nonce)) {
+                    const int j = tcp_try_join(c, port, nonce);
+                    if (j == 0) break;
+                    if (j != 1) return j;
+                }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(join_timeout_s()))
+                    return fail("timed out waiting for a live rank 0 at the rendezvous file " + c->file);
                 std::this_thread::sleep_for(std::chrono::milliseconds(20));
             }
             if (transport == SS_COMM_RCCL && !unhex(hex, reinterpret_cast<unsigned char *>(id.internal), sizeof id.internal))
                 return fail("rendezvous file holds no RCCL id (mixed transports?)");
-            if (transport == SS_COMM_HOST_TCP && port <= 0) return fail("rendezvous file holds no TCP port (mixed transports?)");
         }
     }
     if (transport == SS_COMM_RCCL) {
         COMM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         COMM_HIP(hipMalloc(&c->dev_scratch, ss_comm::kScratchBytes));
-        COMM_NCCL(c, c->rccl.CommInitRank(&c->comm, world, id, rank));       // synchronises all ranks: everyone has read the file
-    } else if (world > 1) {
-        int rc = rank == 0 ? tcp_accept_all(c) : tcp_connect(c, port);
-        if (rc) return rc;
+        // ncclCommInitRank blocks until every rank has called it; a rank that failed earlier would leave the others there
+        // for good, so it runs under a watchdog (the helper thread is abandoned on a timeout: the process is about to fail)
+        struct InitJob { Rccl *r; ncclComm_t comm = nullptr; int world, rank, device; ncclUniqueId id; };
+        auto job = std::make_shared<InitJob>();
+        job->r = &c->rccl; job->world = world; job->rank = rank; job->device = c->device; job->id = id;
+        auto done = std::make_shared<std::promise<ncclResult_t>>();
+        std::future<ncclResult_t> fut = done->get_future();
+        std::thread([job, done]() {
+            (void)hipSetDevice(job->device);
+            done->set_value(job->r->CommInitRank(&job->comm, job->world, job->id, job->rank));
+        }).detach();
+        int verdict = SS_OK;
+        std::string why;
+        if (fut.wait_for(std::chrono::seconds(join_timeout_s())) != std::future_status::ready) { verdict = SS_ERR_DEVICE; why = "ncclCommInitRank: timed out"; }
+        else {
+            const ncclResult_t r = fut.get();
+            if (r != ncclSuccess) { verdict = SS_ERR_DEVICE; why = std::string("ncclCommInitRank: ") + c->rccl.GetErrorString(r); }
+            else c->comm = job->comm;
+        }
+        // all ranks succeed or all fail: the verdicts are summed over the join sockets
+        if (world > 1) {
+            uint64_t bad = verdict != SS_OK;
+            if (tcp_allreduce(c, &bad, 1, 0) != SS_OK || bad) { if (why.empty()) why = "ncclCommInitRank failed on another rank"; verdict = SS_ERR_DEVICE; }
+            for (int fd : c->peers) if (fd >= 0) ::close(fd);
+            c->peers.clear();
+            if (c->listen_fd >= 0) { ::close(c->listen_fd); c->listen_fd = -1; }
+        }
+        if (verdict != SS_OK) return fail(why);
     }
     if (rank == 0 && world > 1) { ::unlink(c->file.c_str()); }
     g.c = nullptr;
@@ -429,10 +512,21 @@ int ss_batch_allreduce_histograms(ss_batch *b, ss_comm *c, uint64_t *out2000)
     DeviceScope ds(ssi::batch_device(b));
     hipStream_t s = ssi::batch_stream(b);
     constexpr size_t kWords = 2000;
+    // The reduction is in place, so it must happen once per pass: a second call for the same pass (or
+    // ss_batch_corpus_gate_enqueue after ss_batch_allreduce_histograms) returns the sums already there.
+    bool &reduced = ssi::batch_corpus_reduced(b);
+    if (reduced) {
+        if (out2000) {
+            COMM_HIP(hipMemcpyAsync(out2000, hist, kWords * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+            COMM_HIP(hipStreamSynchronize(s));
+        }
+        return SS_OK;
+    }
     if (c->transport == SS_COMM_RCCL) {
         if (c->device != ssi::batch_device(b)) return SS_ERR_INVALID_ARG;
         // in place on the batch's stream, behind the kernels of ss_batch_run
         COMM_NCCL(c, c->rccl.AllReduce(hist, hist, kWords, ncclUint64, ncclSum, c->comm, s));
+        reduced = true;
         if (out2000) {
             COMM_HIP(hipMemcpyAsync(out2000, hist, kWords * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
             COMM_HIP(hipStreamSynchronize(s));
@@ -446,6 +540,7 @@ int ss_batch_allreduce_histograms(ss_batch *b, ss_comm *c, uint64_t *out2000)
     if (rc) return rc;
     COMM_HIP(hipMemcpyAsync(hist, h.data(), kWords * sizeof(uint64_t), hipMemcpyHostToDevice, s));
     COMM_HIP(hipStreamSynchronize(s));
+    reduced = true;
     if (out2000) std::memcpy(out2000, h.data(), kWords * sizeof(uint64_t));
     return SS_OK;
 }

@@ -1228,12 +1228,11 @@ hipError_t launch_fft_generic(const FftBatchParams &p, int mode, hipStream_t s)
     int log2m = 0;
     while ((1u << log2m) < m) log2m++;
     const size_t lds = (size_t)(m ? m : 1) * sizeof(float2);
-    static std::atomic<uint64_t> prepared{0};
-    if (first_use_on_device(prepared)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_generic),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        if (e != hipSuccess) { prepared = 0; return e; }
-    }
+    static DevicePrep prepared;
+    const hipError_t pe = prepare_on_device(prepared, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_generic), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    });
+    if (pe != hipSuccess) return pe;
     dim3 grid(p.n_streams * p.n_windows * fft_ch), block(256);
     hipLaunchKernelGGL(k_fft_generic, grid, block, lds, s, p, mode, log2m);
     return hipGetLastError();

@@ -12,6 +12,9 @@ namespace ssi {
 SS_HIDDEN void *batch_corpus_device(ss_batch *b);
 SS_HIDDEN hipStream_t batch_stream(ss_batch *b);
 SS_HIDDEN int batch_device(const ss_batch *b);
+// true once this pass's corpus histograms have been all-reduced (cleared by ss_batch_run): a second all-reduce of the same
+// pass would multiply every bin by the world size
+SS_HIDDEN bool &batch_corpus_reduced(ss_batch *b);
 // text ss_last_device_error() returns on this thread
 SS_HIDDEN void set_last_error(const std::string &text);
 }  // namespace ssi

@@ -3,22 +3,31 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include <atomic>
+#include <mutex>
 #include <cstddef>
 #include <cstdint>
 
 namespace ssk {
 
-// hipFuncSetAttribute applies to the current device only: a launcher remembers, per device, whether its kernel has
-// been prepared there (bit d of the mask).  Returns true when the caller still has to prepare device d.
-inline bool first_use_on_device(std::atomic<uint64_t> &mask)
+// hipFuncSetAttribute applies to the current device only: a launcher prepares its kernel once per device.  The bit of a
+// device is set only AFTER the attribute call has succeeded there, under the launcher's mutex — a second thread on the
+// same device cannot launch before the attribute exists, two threads cannot both act as "first", and a failure on one
+// device leaves the other devices' bits alone.
+struct DevicePrep {
+    std::mutex mu;
+    uint64_t done = 0;
+};
+template <class F>
+inline hipError_t prepare_on_device(DevicePrep &p, F &&prepare)
 {
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess) d = 0;
     const uint64_t bit = 1ull << (d & 63);
-    if (mask.load(std::memory_order_relaxed) & bit) return false;
-    mask.fetch_or(bit, std::memory_order_relaxed);
-    return true;
+    std::lock_guard<std::mutex> lk(p.mu);
+    if (p.done & bit) return hipSuccess;
+    const hipError_t e = prepare();
+    if (e == hipSuccess) p.done |= bit;
+    return e;
 }
 
 constexpr int kHistBins = 1000;
@@ -107,6 +116,7 @@ struct TdParams {
     uint32_t wave_window;        // number of decimation bins W
     uint32_t halo_frames;        // frames kept in front of each tile: >= longest bin, multiple of 4
     const uint64_t *frames_of;    // ragged batches: frames of each stream (nullable = n_frames for all)
+    uint32_t tp_f32;              // 1: the factor-4 true peak as the f32 MFMA product everywhere (no f16 split)
 };
 hipError_t launch_time_domain(const TdParams &p, hipStream_t s);
 // frames per sequential chunk for a channel count (the constant block's m_pow must match)
@@ -158,6 +168,9 @@ hipError_t launch_render_spectrum(const float *rows, uint32_t bin_stride, uint32
 hipError_t launch_render_waveform(const float *wave, uint64_t wave_stride, uint32_t n_points, uint32_t n_streams,
                                   uint32_t x_min, uint32_t x_max, uint32_t cols, float *out, hipStream_t s);
 hipError_t launch_mid_side(const float *interleaved, size_t frames, float *mid, float *side, hipStream_t s);
+// verification utility: out[item * out_stride] += order-independent checksum of words [item * stride_words, + words) (32-bit words)
+hipError_t launch_checksum(const void *base, uint64_t words, uint64_t stride_words, uint32_t n_items, uint64_t *out,
+                           uint32_t out_stride, hipStream_t s);
 // measurement utility: k_fft4096_ms1's loads and stores with no arithmetic (same grid, occupancy and addresses)
 hipError_t launch_fft4096_traffic(const FftBatchParams &p, hipStream_t s);
 hipError_t launch_synth(float *pcm, uint32_t n_streams, uint64_t frames, uint32_t channels,

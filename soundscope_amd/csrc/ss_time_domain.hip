@@ -748,7 +748,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
                     const uint32_t pkb = tp_now_bits > tp_prev_bits ? tp_now_bits : tp_prev_bits;
                     const uint32_t e = pkb >> 23;                          // biased exponent of the peak (sign is 0)
                     nplanar = (seg >> 2) / tp_bpg;
-                    if (e == 255u || C > 8u) nplanar = 0;                 // (16 channels: round 0 would not hold the 12 history frames)
+                    if (e == 255u || C > 8u || p.tp_f32) nplanar = 0;      // (16 channels: round 0 would not hold the 12 history frames)
                     // scale = 2^(14 - floor(log2 peak)): the scaled peak lies in [2^14, 2^15), inside the f16 range
                     uint32_t sf = 268u - e;                                // biased exponent of the scale
                     sf = sf > 254u ? 254u : sf;
@@ -1018,6 +1018,13 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
             e_run = 0.0;
             sb++;
             slot = slot + 1u == p.sub_cap ? 0u : slot + 1u;
+            // ebur128 flushes sub-normal filter state to zero at the end of every internal filter call (restated at
+            // oracle/ss_oracle.c:570-571).  add_frames cuts its input where a gating block completes: at the fourth
+            // 100 ms boundary after a reset and at every boundary after it (needed_frames = 4 s100, then s100).
+            if (sb >= 4) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) cv[q] = fabs(cv[q]) < 2.2250738585072014e-308 ? 0.0 : cv[q];
+            }
         }
         // ---- new halo: the halo_frames frames before the tile end (a contiguous copy; when the tile
         // is shorter than the halo the source reaches into the old halo).  Ascending order is safe:
@@ -1060,9 +1067,9 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
         atomicMax(reinterpret_cast<unsigned *>(&st.sample_peak[lane]), __float_as_uint(sp_run));
     }
     if (sg + 1 == p.nseg) {                              // the last segment owns the carried filter state
-        if (lane_ok && chunk == 0) {
+        if (lane_ok && chunk == 0) {             // ... flushed like at the end of every add_frames call (see the sub-block boundary above)
 #pragma unroll
-            for (int q = 0; q < 4; q++) st.v[ch][q] = cv[q];
+            for (int q = 0; q < 4; q++) st.v[ch][q] = fabs(cv[q]) < 2.2250738585072014e-308 ? 0.0 : cv[q];
         }
         if (lane < C) {
             st.acc[lane] = e_run;
@@ -1177,12 +1184,11 @@ static hipError_t td_launch(const TdParams &p, hipStream_t s)
     wave_floats = (wave_floats + 3u) & ~3u;
     const size_t lds = (size_t)wave_floats * 4 * kTdWavesPerBlock;
     auto fn = k_time_domain<FACTOR, RING, CT, WAVE>;
-    static std::atomic<uint64_t> prepared{0};
-    if (first_use_on_device(prepared)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) { prepared = 0; return e; }
-    }
+    static DevicePrep prepared;                     // one per kernel instantiation
+    const hipError_t pe = prepare_on_device(prepared, [fn] {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (pe != hipSuccess) return pe;
     const uint32_t waves = p.n_streams * p.nseg;
     const uint32_t blocks = (waves + kTdWavesPerBlock - 1) / kTdWavesPerBlock;
     if (lds > 160 * 1024) return hipErrorInvalidValue;

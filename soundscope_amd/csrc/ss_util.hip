@@ -235,6 +235,50 @@ hipError_t launch_synth(float *pcm, uint32_t n_streams, uint64_t frames, uint32_
     return hipGetLastError();
 }
 
+// ---- verification utility: order-independent 64-bit checksum of `n_items` equally sized word ranges ---------------------
+// out[item * out_stride] += sum over the item's 32-bit words of mix(word, index).  A sum, so any partition of the range
+// over threads gives the same value: two passes over the same data agree bit for bit iff (up to 2^-64) the data do.
+// Lets a stress test compare EVERY spectrum row of a 6.5 GB batch between launch modes without downloading it.
+__global__ __launch_bounds__(256) void k_checksum(const uint32_t *base, uint64_t words, uint64_t stride_words, uint64_t *out,
+                                                  uint32_t out_stride)
+{
+    const uint32_t item = blockIdx.y;
+    const uint32_t *x = base + (size_t)item * stride_words;
+    uint64_t acc = 0;
+    auto mix = [](uint32_t w, uint64_t idx) -> uint64_t {
+        uint32_t h = w + 0x9E3779B9u * (uint32_t)idx;
+        h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+        return (uint64_t)h * (uint64_t)(((uint32_t)(idx >> 3) & 0xFFFFu) | 1u);
+    };
+    const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x, nthreads = (uint64_t)gridDim.x * 256;
+    if ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
+        const uint64_t n4 = words >> 2;
+        for (uint64_t i = tid; i < n4; i += nthreads) {
+            const uint4 v = reinterpret_cast<const uint4 *>(x)[i];
+            acc += mix(v.x, 4 * i) + mix(v.y, 4 * i + 1) + mix(v.z, 4 * i + 2) + mix(v.w, 4 * i + 3);
+        }
+        for (uint64_t i = (n4 << 2) + tid; i < words; i += nthreads) acc += mix(x[i], i);
+    } else {
+        for (uint64_t i = tid; i < words; i += nthreads) acc += mix(x[i], i);
+    }
+#pragma unroll
+    for (int ofs = 32; ofs >= 1; ofs >>= 1) acc += __shfl_xor(acc, ofs, 64);
+    if ((threadIdx.x & 63u) == 0 && acc) atomicAdd(reinterpret_cast<unsigned long long *>(out + (size_t)item * out_stride), (unsigned long long)acc);
+}
+
+hipError_t launch_checksum(const void *base, uint64_t words, uint64_t stride_words, uint32_t n_items, uint64_t *out,
+                           uint32_t out_stride, hipStream_t s)
+{
+    if (!n_items || !words) return hipSuccess;
+    uint64_t per_item = (words / 4 + 255) / 256;                  // one uint4 per thread and trip at most ...
+    const uint64_t want = (8192 + n_items - 1) / n_items;          // ... but no more workgroups than fill the chip a few times
+    if (per_item > want) per_item = want;
+    if (per_item < 1) per_item = 1;
+    hipLaunchKernelGGL(k_checksum, dim3((uint32_t)per_item, n_items), dim3(256), 0, s, static_cast<const uint32_t *>(base), words,
+                       stride_words, out, out_stride);
+    return hipGetLastError();
+}
+
 // ---- measurement utility: the spectrum kernel's HBM traffic with no arithmetic -----------------------------------------
 // Same grid, same workgroup size, same LDS footprint (so the same three workgroups per CU), same addresses: every
 // workgroup walks its run of windows, loads the four new 256-frame slots of each window (8-byte loads) and stores the two

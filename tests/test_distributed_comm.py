@@ -55,3 +55,99 @@ def test_comm_single_rank_is_a_no_op():
     c.barrier()
     assert list(c.allreduce_sum_u64(np.array([5, 7], np.uint64))) == [5, 7]
     c.close()
+
+
+def _planted_file(path, port, nonce=12345):
+    with open(path, "w") as f:            # the library's own format: magic, port, id ("-" = host transport), nonce
+        f.write(f"ssc2 {port} - {nonce}\n")
+
+
+@pytest.mark.parametrize("kind", ["dead_port", "foreign_listener"])
+def test_stale_rendezvous_file_is_not_consumed(kind, tmp_path):
+    """A rendezvous file left by a crashed / earlier job must not be used: its port is dead, or whoever listens there
+    does not answer with the file's nonce.  Ranks > 0 start first (so they see the stale file), rank 0 joins 2 s later
+    and replaces it; everybody must end up in the NEW job."""
+    import socket
+    import time
+    f = str(tmp_path / "rdzv")
+    srv = None
+    if kind == "dead_port":
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()     # nobody listens there any more
+    else:
+        srv = socket.socket(); srv.bind(("127.0.0.1", 0)); srv.listen(8); port = srv.getsockname()[1]    # accepts, never answers
+    _planted_file(f, port)
+    world = 3
+    env = dict(os.environ, OMP_NUM_THREADS="1", WORLD_SIZE=str(world), SS_COMM_TIMEOUT_S="120")
+    procs = {}
+    for r in (2, 1):
+        procs[r] = subprocess.Popen([sys.executable, WORKER, str(r), str(world), f], env=env, stdout=subprocess.PIPE,
+                                    stderr=subprocess.PIPE, text=True)
+    time.sleep(2.0)
+    assert all(p.poll() is None for p in procs.values()), "a rank finished against a stale rendezvous file"
+    procs[0] = subprocess.Popen([sys.executable, WORKER, "0", str(world), f], env=env, stdout=subprocess.PIPE,
+                                stderr=subprocess.PIPE, text=True)
+    outs = {r: p.communicate(timeout=600) for r, p in procs.items()}
+    if srv is not None:
+        srv.close()
+    for r, p in procs.items():
+        assert p.returncode == 0, f"rank {r}: " + outs[r][0][-2000:] + outs[r][1][-4000:]
+    assert f"COMM_OK world={world} transport=host-tcp" in outs[0][0]
+    assert not os.path.exists(f)
+
+
+def test_rendezvous_file_is_private_and_symlink_safe(tmp_path):
+    """Rank 0 creates the file with O_EXCL | O_NOFOLLOW, mode 0600: a symlink planted at the temporary name is replaced,
+    not followed, and the published file is not group/world readable (it holds the RCCL unique id)."""
+    import stat
+    import threading
+    from soundscope_amd.distributed import Comm
+    f = str(tmp_path / "rdzv")
+    victim = tmp_path / "victim.txt"
+    victim.write_text("untouched")
+    os.symlink(str(victim), f + f".tmp.{os.getpid()}")            # what an attacker who guesses the temporary name would plant
+    seen = {}
+
+    def rank1():
+        import time
+        for _ in range(2000):
+            if os.path.exists(f):
+                seen["mode"] = stat.S_IMODE(os.stat(f).st_mode)
+                break
+            time.sleep(0.005)
+        c = Comm(1, 2, f, transport="host-tcp")
+        c.barrier(); c.close()
+
+    t = threading.Thread(target=rank1)
+    t.start()
+    c = Comm(0, 2, f, transport="host-tcp")
+    c.barrier()
+    t.join(60)
+    c.close()
+    assert victim.read_text() == "untouched"
+    assert seen.get("mode") == 0o600, seen
+    assert not os.path.exists(f)
+
+
+def test_back_to_back_inits_on_one_path(tmp_path):
+    """Two communicators created one after the other on the SAME rendezvous path (a fast rank may re-enter the second
+    init before rank 0 has removed the first file): the nonce handshake keeps the generations apart."""
+    import threading
+    from soundscope_amd.distributed import Comm
+    import numpy as np
+    f = str(tmp_path / "rdzv")
+    errs = []
+
+    def run(rank):
+        try:
+            for gen in range(6):
+                c = Comm(rank, 2, f, transport="host-tcp")
+                v = c.allreduce_sum_u64(np.array([gen * 10 + rank + 1], np.uint64))
+                assert int(v[0]) == 2 * gen * 10 + 3, (gen, v)
+                c.close()
+        except Exception as e:       # noqa: BLE001
+            errs.append((rank, repr(e)))
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in (1, 0)]
+    [t.start() for t in ts]
+    [t.join(120) for t in ts]
+    assert not errs, errs

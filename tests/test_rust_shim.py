@@ -19,7 +19,7 @@ RUST_TO_C = {
     "u32": "uint32_t", "c_int": "int", "i32": "int", "usize": "size_t", "c_double": "double", "c_float": "float",
     "*mut SsAnalyzer": "ss_analyzer *", "*const SsAnalyzer": "const ss_analyzer *",
     "*mut *mut SsAnalyzer": "ss_analyzer **", "*const c_float": "const float *", "*mut c_double": "double *",
-    "*mut usize": "size_t *", "*mut f64": "double *",
+    "*mut usize": "size_t *", "*mut f64": "double *", "*const c_char": "const char *",
 }
 
 
@@ -94,6 +94,27 @@ def test_shim_keeps_the_reference_api():
     ]:
         assert sig in src, f"missing in rust/src/analyzer.rs: {sig}"
     assert "ss_analyzer_create(2, 44100" in src                    # Analyzer::default(): 2 channels, 44.1 kHz (analyzer.rs:34-45)
+
+
+def test_get_fft_errors_map_to_the_crate_variants():
+    """status 10..15 of ss_get_fft become the SpectrumAnalyzerError variants the reference's `?`
+    would have produced (analyzer.rs:60-65), so the text the TUI prints (tui.rs:1439-1442) is the crate's own.  The header's
+    status values and the shim's match arms must agree one to one."""
+    src = open(SHIM).read()
+    hdr = open(HEADER).read()
+    want = {"SS_ERR_TOO_FEW_SAMPLES": "TooFewSamples", "SS_ERR_NAN": "NaNValuesNotSupported",
+            "SS_ERR_INFINITY": "InfinityValuesNotSupported", "SS_ERR_NOT_POW2": "SamplesLengthNotAPowerOfTwo",
+            "SS_ERR_FREQ_LIMIT": "InvalidFrequencyLimit", "SS_ERR_SCALING": "ScalingError"}
+    body = re.search(r"fn fft_err\(rc: c_int\) -> eyre::Report \{(.*?)\n\}", src, re.S).group(1)
+    for name, variant in want.items():
+        value = int(re.search(name + r"\s*=\s*(\d+)", hdr).group(1))
+        arm = re.search(r"\b%d\s*=>\s*SpectrumAnalyzerError::(\w+)" % value, body)
+        assert arm and arm.group(1) == variant, f"status {value} ({name}) must map to SpectrumAnalyzerError::{variant}"
+    assert "return Err(fft_err(rc))" in src and 'eyre!("spectrum analyzer error' not in src
+    ebu = re.search(r"fn ebu_err\(rc: c_int\) -> ebur128::Error \{(.*?)\n\}", src, re.S).group(1)
+    for name, variant in {"SS_ERR_INVALID_MODE": "InvalidMode", "SS_ERR_INVALID_CHANNEL": "InvalidChannelIndex"}.items():
+        value = int(re.search(name + r"\s*=\s*(\d+)", hdr).group(1))
+        assert re.search(r"\b%d\s*=>\s*ebur128::Error::%s" % (value, variant), ebu)
 
 
 def test_build_rs_links_the_library():
