@@ -94,24 +94,29 @@ def self_check(batch, stream, ref):
     """GPU results of the run just timed vs the oracle's for one stream, at the north_star tolerances."""
     got = batch.fft(stream)
     r = batch.results()[stream]
-    strong = ref["fft"] > -90.0
-    fft_err = float(np.abs(got[strong] - ref["fft"][strong]).max()) if strong.any() else 0.0
-    weak = ~strong
-    peak_lin = 10.0 ** (float(ref["fft"].max()) / 20.0)
-    weak_err = float(np.abs(10.0 ** (got[weak] / 20.0) - 10.0 ** (ref["fft"][weak] / 20.0)).max() / peak_lin) if weak.any() else 0.0
+    # per window row, relative to the row's own loudest bin (an f32 transform's error is scale-invariant): 0.01 dB down to
+    # 70 dB under it, 1e-4 of its amplitude below that
+    rf = ref["fft"].astype(np.float64)
+    peak = rf.max(axis=2, keepdims=True)
+    strong = rf >= peak - 70.0
+    d = np.abs(got - rf)
+    fft_err = float(d[strong].max()) if strong.any() else 0.0
+    lin = np.abs(10.0 ** ((got - peak) / 20.0) - 10.0 ** ((rf - peak) / 20.0))
+    weak_err = float(lin[~strong].max()) if (~strong).any() else 0.0
     lufs_err = abs(r.integrated_lufs - ref["integrated"]) if math.isfinite(ref["integrated"]) else (0.0 if r.integrated_lufs == ref["integrated"] else float("inf"))
     lra_err = abs(r.loudness_range - ref["lra"])
     tp_rel = max(abs(r.true_peak[c] - ref["true_peak"][c]) / max(ref["true_peak"][c], 1e-30) for c in range(2))
     wave_ok = bool(np.array_equal(batch.waveform(stream).reshape(-1), ref["wave"][:, 1].astype(np.float32)))
     ok = fft_err <= 0.01 and weak_err <= 1e-4 and lufs_err <= 0.01 and lra_err <= 0.01 and tp_rel <= 1e-4 and wave_ok
-    return {"stream": stream, "windows": int(got.shape[0]), "fft_max_err_db_above_-90dB": fft_err,
-            "fft_max_err_rel_to_peak_below": weak_err, "integrated_err_lu": lufs_err, "lra_err_lu": lra_err,
+    return {"stream": stream, "windows": int(got.shape[0]), "fft_max_err_db_within_70dB_of_row_peak": fft_err,
+            "fft_max_err_rel_to_row_peak_below": weak_err, "integrated_err_lu": lufs_err, "lra_err_lu": lra_err,
             "true_peak_rel_err": tp_rel, "decimation_bit_exact": wave_ok, "ok": bool(ok)}
 
 
-def time_config(ssa, L, rate, channels, streams, frames, fft_n, hop, tp_factor, steps, warmup=1, flags=None, tp_arith=None):
+def time_config(ssa, L, rate, channels, streams, frames, fft_n, hop, tp_factor, steps, warmup=1, flags=None, tp_arith=None, cols=0):
     """Per-kernel HIP-event times of one extra BASELINE configuration (informational lines under config.extra)."""
-    b = ssa.Batch(rate, channels, streams, frames, fft_n, hop, flags=L.SS_BATCH_ALL if flags is None else flags, true_peak_factor=tp_factor)
+    b = ssa.Batch(rate, channels, streams, frames, fft_n, hop, flags=L.SS_BATCH_ALL if flags is None else flags, true_peak_factor=tp_factor,
+                  spectrum_columns=cols)
     b.synthesize(0x5EED0000, 0)
     if tp_arith is not None:
         b.set_true_peak_arith(tp_arith)
@@ -132,7 +137,7 @@ def time_config(ssa, L, rate, channels, streams, frames, fft_n, hop, tp_factor, 
     gpu_ms = sum(kern.values())
     samples = streams * frames * channels
     in_bytes = samples * 4
-    out_bytes = streams * lay.n_windows * lay.fft_channels * lay.n_bins * 4
+    out_bytes = streams * lay.n_windows * lay.fft_channels * (cols if cols else lay.n_bins) * 4
     res = {"ms_per_pass_wall": round(wall_ms, 4), "kernel_ms": kern, "gpu_ms": round(gpu_ms, 4),
            "samples_per_s": samples / (gpu_ms * 1e-3) if gpu_ms > 0 else None,
            "windows_per_stream": lay.n_windows, "fft_channels": lay.fft_channels, "bins": lay.n_bins,
@@ -391,6 +396,12 @@ def main():
                 # the headline step with the true peak at the reference's f32 width (v_mfma_f32_16x16x4_f32 instead of the f16x3 split)
                 e = time_config(ssa, L, args.rate, 2, count, frames, args.fft_n, args.hop, 0, steps=5, tp_arith=L.SS_TP_ARITH_F32)
                 e["workload"] = f"config 3, full path, true peak in f32 MFMA arithmetic (ss_batch_set_true_peak_arith): {count} streams x {args.seconds:g} s"
+                extra.append(e)
+                # the headline step in columns-only mode (N3 fused into the spectrum epilogue): no row is stored, 160 chart columns
+                # per row leave the chip — the compute-bound face of the spectrum kernel (its fp32 fraction is the figure to read)
+                e = time_config(ssa, L, args.rate, 2, count, frames, args.fft_n, args.hop, 0, steps=5, cols=160)
+                e["workload"] = (f"config 3, full path, columns-only spectrum (SS_BATCH_FFT_COLUMNS, 160 columns, reference gain): {count} streams x "
+                                 f"{args.seconds:g} s; algorithmic bytes = 4 B per input sample + 160 x 2 x 4 B per window")
                 extra.append(e)
                 # config 2: one stream (10 s and the 600 s steady-state variant)
                 for secs in (10, 600):

@@ -187,7 +187,13 @@ enum {
     SS_BATCH_LUFS = 2u,      /* K-weighting, gating blocks, histograms, I, LRA    */
     SS_BATCH_TRUE_PEAK = 4u, /* sample peak + oversampled true peak               */
     SS_BATCH_WAVEFORM = 8u,  /* min-max decimation of the interleaved buffer      */
-    SS_BATCH_ALL = 15u
+    SS_BATCH_ALL = 15u,
+    /* with SS_BATCH_FFT: columns-only spectrum.  The render-side reduction (below: gain, chart bounds, chart columns) runs
+     * INSIDE the spectrum kernel's epilogue, on the window's spectrum while it is still in LDS: the full rows are never
+     * stored (nor allocated: 6.5 GB at the bench shape) and only `spectrum_columns` values per row leave the chip — what a
+     * terminal can show.  Results equal ss_batch_render_spectrum's bit for bit.  Stereo, fft_n = 4096, hop 1024 only
+     * (SS_ERR_UNSUPPORTED otherwise); ss_batch_download_fft is not available (SS_ERR_INVALID_MODE). */
+    SS_BATCH_FFT_COLUMNS = 16u
 };
 
 typedef struct ss_batch_config {
@@ -199,7 +205,7 @@ typedef struct ss_batch_config {
     uint32_t hop_frames;        /* 1024 in the reference (audio_player.rs:65) */
     uint32_t flags;             /* SS_BATCH_* */
     int32_t true_peak_factor;   /* 0 = ebur128 rule, 2 / 4 = forced */
-    uint32_t reserved;
+    uint32_t spectrum_columns;  /* SS_BATCH_FFT_COLUMNS: chart columns per spectrum row, 1 .. 512 (otherwise 0) */
     uint64_t frames_per_stream;
     double waveform_window;     /* seconds; <= 0 => frames_per_stream / sample_rate */
 } ss_batch_config;
@@ -386,6 +392,11 @@ enum { SS_GAIN_FIXED = 0,       /* gain_db as given                             
        SS_GAIN_REFERENCE = 1 }; /* per stream FFT_TARGET_LUFS(-13) - integrated as f32 (tui.rs:1234) */
 /* after ss_batch_run: [stream][window][fft_channel][cols] f32 into a device buffer of the batch */
 int ss_batch_render_spectrum(ss_batch *b, uint32_t cols, int gain_mode, float gain_db);
+/* SS_BATCH_FFT_COLUMNS batches: the gain of the fused reduction, for the passes that follow.  Default: SS_GAIN_REFERENCE
+ * when the batch also runs the meter (SS_BATCH_LUFS: the pass then runs the time-domain chain first — the gain needs
+ * every stream's integrated loudness), otherwise SS_GAIN_FIXED with 0 dB.  ss_batch_download_spectrum_columns reads
+ * the result. */
+int ss_batch_set_columns_gain(ss_batch *b, int gain_mode, float gain_db);
 int ss_batch_download_spectrum_columns(ss_batch *b, uint32_t stream, float *out, size_t cap_floats);
 /* [stream][cols][2] f32 (min, max) of the decimation bins x_min <= i < x_max */
 int ss_batch_render_waveform(ss_batch *b, uint32_t cols, uint32_t x_min, uint32_t x_max);

@@ -39,7 +39,7 @@ SYMBOLS = [
     "ss_comm_init", "ss_comm_init_from_env", "ss_comm_destroy", "ss_comm_rank", "ss_comm_size",
     "ss_comm_transport_name", "ss_comm_barrier", "ss_comm_allreduce_u64_sum", "ss_comm_allreduce_f64_max",
     "ss_batch_allreduce_histograms", "ss_batch_traffic_floor",
-    "ss_batch_corpus_gate_enqueue", "ss_batch_corpus_gate_read", "ss_batch_checksums", "ss_inspect_filter_state", "ss_batch_set_true_peak_arith",
+    "ss_batch_corpus_gate_enqueue", "ss_batch_corpus_gate_read", "ss_batch_checksums", "ss_inspect_filter_state", "ss_batch_set_true_peak_arith", "ss_batch_set_columns_gain",
     "ss_inspect_kweight", "ss_inspect_true_peak", "ss_inspect_hann", "ss_inspect_bins", "ss_inspect_histogram",
 ]
 
@@ -49,6 +49,7 @@ SS_ERR_TOO_FEW_SAMPLES, SS_ERR_NAN, SS_ERR_INFINITY, SS_ERR_NOT_POW2, SS_ERR_FRE
 SS_ERR_CAPACITY, SS_ERR_UNSUPPORTED, SS_ERR_INVALID_ARG, SS_ERR_DEVICE = 20, 21, 22, 30
 
 SS_BATCH_FFT, SS_BATCH_LUFS, SS_BATCH_TRUE_PEAK, SS_BATCH_WAVEFORM, SS_BATCH_ALL = 1, 2, 4, 8, 15
+SS_BATCH_FFT_COLUMNS = 16
 SS_PCM_U8, SS_PCM_S16, SS_PCM_S24, SS_PCM_S32, SS_PCM_F32, SS_PCM_F64 = 1, 2, 3, 4, 5, 6
 SS_GAIN_FIXED, SS_GAIN_REFERENCE = 0, 1
 SS_COMM_RCCL, SS_COMM_HOST_TCP = 0, 1
@@ -59,7 +60,7 @@ SS_KERNEL_FFT, SS_KERNEL_TIME_DOMAIN, SS_KERNEL_FINALIZE, SS_KERNEL_WAVEFORM, SS
 class BatchConfig(C.Structure):
     _fields_ = [("sample_rate", C.c_uint32), ("channels", C.c_uint32), ("n_streams", C.c_uint32),
                 ("fft_n", C.c_uint32), ("hop_frames", C.c_uint32), ("flags", C.c_uint32),
-                ("true_peak_factor", C.c_int32), ("reserved", C.c_uint32),
+                ("true_peak_factor", C.c_int32), ("spectrum_columns", C.c_uint32),
                 ("frames_per_stream", C.c_uint64), ("waveform_window", C.c_double)]
 
 
@@ -204,6 +205,7 @@ def _bind(lib):
         "ss_batch_checksums": (C.c_int, [vp, u64p, C.c_uint32]),
         "ss_inspect_filter_state": (C.c_int, [vp, C.c_uint32, f64p]),
         "ss_batch_set_true_peak_arith": (C.c_int, [vp, C.c_int]),
+        "ss_batch_set_columns_gain": (C.c_int, [vp, C.c_int, C.c_float]),
         "ss_inspect_kweight": (C.c_int, [C.c_uint32, f64p, f64p]),
         "ss_inspect_true_peak": (C.c_int, [C.c_int, f32p, C.c_uint32, C.POINTER(C.c_uint32)]),
         "ss_inspect_hann": (C.c_int, [C.c_uint32, f32p]),

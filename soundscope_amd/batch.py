@@ -15,8 +15,13 @@ from .analyzer import _check
 class Batch:
     def __init__(self, sample_rate=48000, channels=2, n_streams=1, frames_per_stream=480000,
                  fft_n=4096, hop_frames=1024, flags=L.SS_BATCH_ALL, true_peak_factor=0,
-                 waveform_window=0.0):
-        cfg = L.BatchConfig(sample_rate, channels, n_streams, fft_n, hop_frames, flags, true_peak_factor, 0,
+                 waveform_window=0.0, spectrum_columns=0):
+        """spectrum_columns > 0 (with L.SS_BATCH_FFT_COLUMNS in flags, added here if missing): columns-only spectrum — the
+        render-side reduction runs inside the spectrum kernel and only that many chart columns per row are kept."""
+        if spectrum_columns:
+            flags |= L.SS_BATCH_FFT_COLUMNS
+            self._render_cols = int(spectrum_columns)
+        cfg = L.BatchConfig(sample_rate, channels, n_streams, fft_n, hop_frames, flags, true_peak_factor, int(spectrum_columns),
                             frames_per_stream, waveform_window)
         self.cfg = cfg
         self._h = C.c_void_p()
@@ -165,6 +170,11 @@ class Batch:
         mode = L.SS_GAIN_REFERENCE if gain_db is None else L.SS_GAIN_FIXED
         _check(L.lib().ss_batch_render_spectrum(self._h, cols, mode, 0.0 if gain_db is None else float(gain_db)))
         self._render_cols = cols
+
+    def set_columns_gain(self, gain_db=None):
+        """columns-only batches: None = the reference's per-file rule -13 - integrated (needs the meter pass), else a fixed gain"""
+        mode = L.SS_GAIN_REFERENCE if gain_db is None else L.SS_GAIN_FIXED
+        _check(L.lib().ss_batch_set_columns_gain(self._h, mode, 0.0 if gain_db is None else float(gain_db)))
 
     def spectrum_columns(self, stream):
         lay = self.layout

@@ -44,6 +44,11 @@ struct ss_batch {
     DevBuf<float> render_spec, render_wave;
     DevBuf<uint32_t> col_start;
     uint32_t render_cols = 0, render_wave_cols = 0;
+    // columns-only spectrum (SS_BATCH_FFT_COLUMNS): the reduction fused into the spectrum kernel's epilogue
+    bool columns_only = false;
+    int columns_gain_mode = SS_GAIN_FIXED;
+    float columns_gain_db = 0.0f;
+    DevBuf<uint16_t> bin_col;       // chart column of every retained bin (0xFFFF for the row padding)
     // opt-in (SS_BATCH_OVERLAP=1): the spectrum kernel on a second stream beside the time-domain chain
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -66,6 +71,14 @@ bool &batch_corpus_reduced(ss_batch *b) { return b->corpus_reduced; }
 }  // namespace ssi
 
 namespace {
+
+// chart column of a bin: floor(chart_x / 100 * cols), the last column closed on the right (include/soundscope_hip.h)
+uint32_t spectrum_column_of(double chart_x, uint32_t cols)
+{
+    double f = std::floor(chart_x / 100.0 * (double)cols);
+    if (f < 0) f = 0;
+    return f >= (double)cols ? cols - 1 : (uint32_t)f;
+}
 
 int batch_collect_timing(ss_batch *b)
 {
@@ -91,6 +104,8 @@ int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
     if (require_device()) return SS_ERR_DEVICE;
     if (cfg->n_streams == 0 || cfg->frames_per_stream == 0) return SS_ERR_INVALID_ARG;
     if ((cfg->flags & SS_BATCH_ALL) == 0) return SS_ERR_INVALID_ARG;
+    const bool columns_only = (cfg->flags & SS_BATCH_FFT_COLUMNS) != 0;
+    if (columns_only && (!(cfg->flags & SS_BATCH_FFT) || cfg->spectrum_columns == 0 || cfg->spectrum_columns > 512)) return SS_ERR_INVALID_ARG;
     // destroyed (streams and events included) on every early return
     std::unique_ptr<ss_batch, decltype(&ss_batch_destroy)> b(new ss_batch(), &ss_batch_destroy);
     b->device = current_device();
@@ -154,8 +169,23 @@ int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
 #define SS_FFT_ROW_ALIGN 4u
 #endif
         L.fft_bin_stride = (L.n_bins + (SS_FFT_ROW_ALIGN - 1u)) & ~(SS_FFT_ROW_ALIGN - 1u);
-        L.fft_bytes = (uint64_t)cfg->n_streams * L.n_windows * L.fft_channels * L.fft_bin_stride * sizeof(float);
-        HIPCHK(b->fft.alloc((size_t)(L.fft_bytes / sizeof(float))));
+        if (columns_only) {
+            // the fused reduction lives in the epilogue of k_fft4096_ms1
+            if (!(b->fft_fast && hop == 1024)) return SS_ERR_UNSUPPORTED;
+            const uint32_t cols = cfg->spectrum_columns;
+            std::vector<uint16_t> bc(L.fft_bin_stride, (uint16_t)0xFFFF);
+            for (uint32_t i = 0; i < L.n_bins; i++) bc[i] = (uint16_t)spectrum_column_of(b->bt->chart_x[i], cols);
+            HIPCHK(b->bin_col.upload(bc));
+            const uint64_t rows = (uint64_t)cfg->n_streams * L.n_windows * L.fft_channels;
+            HIPCHK(b->render_spec.alloc(rows * cols));
+            b->render_cols = cols;
+            b->columns_only = true;
+            b->columns_gain_mode = (cfg->flags & SS_BATCH_LUFS) ? SS_GAIN_REFERENCE : SS_GAIN_FIXED;
+            L.fft_bytes = rows * cols * sizeof(float);
+        } else {
+            L.fft_bytes = (uint64_t)cfg->n_streams * L.n_windows * L.fft_channels * L.fft_bin_stride * sizeof(float);
+            HIPCHK(b->fft.alloc((size_t)(L.fft_bytes / sizeof(float))));
+        }
     }
     if (cfg->flags & (SS_BATCH_LUFS | SS_BATCH_TRUE_PEAK)) {
         b->tp_factor = (cfg->flags & SS_BATCH_TRUE_PEAK)
@@ -454,7 +484,10 @@ int ss_batch_run(ss_batch *b)
     // Mode 2 (tail overlap): the time-domain kernel runs first and alone; the spectrum kernel starts behind it on stream2
     // while the short latency-bound tail of the chain (gating / histograms per stream, a standalone decimation) runs on
     // the main stream beside it.
-    const int mode = tm ? 0 : b->overlap;
+    // columns-only spectrum with the reference's per-file gain: the gain is -13 - integrated of each stream, so the whole
+    // time-domain chain (kernel + gating / histograms) runs first and the spectrum kernel last, on the one stream
+    const bool spectrum_last = b->columns_only && b->columns_gain_mode == SS_GAIN_REFERENCE;
+    const int mode = (tm || spectrum_last) ? 0 : b->overlap;
     const bool ov = mode != 0;
     hipStream_t fft_stream = ov ? b->stream2 : b->stream;
     if (mode == 1) {
@@ -473,6 +506,11 @@ int ss_batch_run(ss_batch *b)
         p.n = c.fft_n; p.first_bin = L.first_bin; p.n_bins = L.n_bins; p.bin_stride = L.fft_bin_stride;
         p.windows_per_block = b->windows_per_block;
         p.windows_of = b->ragged ? b->windows_d.p : nullptr;
+        if (b->columns_only) {
+            p.out_cols = b->render_spec.p; p.bin_col = b->bin_col.p; p.cols = b->render_cols;
+            p.integrated = b->columns_gain_mode == SS_GAIN_REFERENCE ? b->integrated.p : nullptr;
+            p.gain_db = b->columns_gain_db;
+        }
         if (b->fft_fast || b->fft_pairw) {
             p.db_offset = (float)(10.0 * std::log10(4.0 / ((double)c.fft_n * (double)c.fft_n)));
             p.offpink = b->bt->offpink4096_dev.p;
@@ -509,7 +547,7 @@ int ss_batch_run(ss_batch *b)
     HIPCHK(rec(2 * SS_KERNEL_FFT + 1));
     return SS_OK;
     };
-    if (mode != 2) { rc = launch_spectrum(); if (rc) return rc; }
+    if (mode != 2 && !spectrum_last) { rc = launch_spectrum(); if (rc) return rc; }
 
     const bool td = (c.flags & (SS_BATCH_LUFS | SS_BATCH_TRUE_PEAK)) != 0;
     HIPCHK(rec(2 * SS_KERNEL_TIME_DOMAIN));
@@ -563,6 +601,7 @@ int ss_batch_run(ss_batch *b)
         HIPCHK(ssk::launch_waveform(p, b->stream));
     }
     HIPCHK(rec(2 * SS_KERNEL_WAVEFORM + 1));
+    if (spectrum_last) { rc = launch_spectrum(); if (rc) return rc; }
     if (ov) {                                  // join: later work on the main stream (downloads, the next pass) sees the spectrum
         HIPCHK(hipEventRecord(b->ev_join, b->stream2));
         HIPCHK(hipStreamWaitEvent(b->stream, b->ev_join, 0));
@@ -745,6 +784,7 @@ int ss_batch_download_fft(ss_batch *b, uint32_t stream, float *out, size_t cap)
 {
     SS_ON_DEVICE(b);
     if (!b || !out || stream >= b->cfg.n_streams) return SS_ERR_INVALID_ARG;
+    if (b->columns_only) return SS_ERR_INVALID_MODE;          // the rows were never stored: ss_batch_download_spectrum_columns
     const size_t rows = (size_t)b->lay.n_windows * b->lay.fft_channels;
     const size_t per = rows * b->lay.n_bins;
     if (cap < per) return SS_ERR_CAPACITY;
@@ -854,7 +894,7 @@ int ss_batch_render_spectrum(ss_batch *b, uint32_t cols, int gain_mode, float ga
     if (!b || cols == 0 || cols > 65536 || (gain_mode != SS_GAIN_FIXED && gain_mode != SS_GAIN_REFERENCE))
         return SS_ERR_INVALID_ARG;
     const ss_batch_layout &L = b->lay;
-    if (!(b->cfg.flags & SS_BATCH_FFT) || !L.n_windows || !L.n_bins) return SS_ERR_INVALID_MODE;
+    if (!(b->cfg.flags & SS_BATCH_FFT) || !L.n_windows || !L.n_bins || b->columns_only) return SS_ERR_INVALID_MODE;   // (columns-only: no rows to reduce)
     if (gain_mode == SS_GAIN_REFERENCE && !(b->cfg.flags & SS_BATCH_LUFS)) return SS_ERR_INVALID_MODE;
     // column of a bin: floor(chart_x / 100 * cols), the last column closed on the right; chart_x ascends
     std::vector<uint32_t> start(cols + 1, L.n_bins);
@@ -862,9 +902,7 @@ int ss_batch_render_spectrum(ss_batch *b, uint32_t cols, int gain_mode, float ga
         uint32_t c = 0;
         start[0] = 0;
         for (uint32_t i = 0; i < L.n_bins; i++) {
-            double f = std::floor(b->bt->chart_x[i] / 100.0 * (double)cols);
-            if (f < 0) f = 0;
-            uint32_t ci = f >= (double)cols ? cols - 1 : (uint32_t)f;
+            const uint32_t ci = spectrum_column_of(b->bt->chart_x[i], cols);
             while (c < ci) start[++c] = i;
         }
         while (c < cols) start[++c] = L.n_bins;
@@ -879,6 +917,15 @@ int ss_batch_render_spectrum(ss_batch *b, uint32_t cols, int gain_mode, float ga
                                        b->col_start.p, cols,
                                        gain_mode == SS_GAIN_REFERENCE ? b->integrated.p : nullptr, gain_db,
                                        b->render_spec.p, b->stream));
+    return SS_OK;
+}
+
+int ss_batch_set_columns_gain(ss_batch *b, int gain_mode, float gain_db)
+{
+    if (!b || !b->columns_only || (gain_mode != SS_GAIN_FIXED && gain_mode != SS_GAIN_REFERENCE)) return SS_ERR_INVALID_ARG;
+    if (gain_mode == SS_GAIN_REFERENCE && !(b->cfg.flags & SS_BATCH_LUFS)) return SS_ERR_INVALID_MODE;
+    b->columns_gain_mode = gain_mode;
+    b->columns_gain_db = gain_db;
     return SS_OK;
 }
 

@@ -15,6 +15,9 @@
 #ifndef SS_FFT16K_LATE_HOP
 #define SS_FFT16K_LATE_HOP 1   // k_fft16k_run: the next hop's loads behind the first radix pass (A/B: -3.5 %)
 #endif
+#ifndef SS_FFT16K_SKEW
+#define SS_FFT16K_SKEW 0       // k_fft16k_run: 1 = the two halves run skewed by one phase (one half's LDS exchange flies under the other's butterflies): measured 1 % SLOWER (profiles/r03_ab_fft16k_skew.txt)
+#endif
 #ifndef SS_FFT_NT_STORE
 #define SS_FFT_NT_STORE 0
 #endif
@@ -168,9 +171,19 @@ constexpr int kPlane = 16 * kRow;   // 288 complex per outer index; 16 planes = 
 // owns groups of FOUR consecutive retained bins (g = t, t + 256), so both output rows are written
 // with 16-byte stores (rows are padded to a multiple of 4 floats): the 4-byte-per-lane stores of
 // a stride-256 ownership were store-issue bound (1.6 ms of 4.7 ms at the config-3 size).
+// LDS_TABLE: `offpink` is the workgroup's LDS copy of the table (k_fft4096_ms1 / k_fft4096_pairw stage it once per run of
+// windows): the rows are read right where they are used instead of being requested from global memory a whole epilogue
+// ahead (eight registers held across it, and as many vector-memory requests per window as the samples themselves).
+// COLS: nothing is stored — every dB value is gained, clamped to the chart's [-100, 0] dB and folded into its chart column
+// in LDS (tui.rs:49-51, :801-821; the column rule is the library's, include/soundscope_hip.h).  A value v <= 0 travels as
+// the bit pattern of 0 - v, which orders like an unsigned integer, so "max v" is one ds_min_u32 per run of bins that share
+// a column (a lane's four consecutive bins usually do); colbuf[row * cols + c] starts at 0xFFFFFFFF = "no bin" = NaN.
+template <bool LDS_TABLE = false, bool COLS = false>
 __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t first_bin, uint32_t n_bins,
                                                  float db_offset, const float *__restrict__ offpink,
-                                                 float *o_mid, float *o_side, bool store_side = true)
+                                                 float *o_mid, float *o_side, bool store_side = true,
+                                                 uint32_t *colbuf = nullptr, const uint16_t *bincol = nullptr,
+                                                 uint32_t cols = 0, float gain = 0.0f)
 {
     const uint32_t ngroups = (n_bins + 3) >> 2;
     // dB = 10 log10(2) * log2(q) + (db_offset + pink[bin]); an exact zero reads -150 (+ pink): the log operand is
@@ -183,20 +196,30 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
     // per-phase clock profile (-DSS_FFT_PROF) this order takes a fifth off the epilogue's wave time; the kernel time does
     // not move (the other two workgroups of the CU cover the wait), it is kept because it also frees two spilled registers.
     constexpr float kDb = 3.01029995663981195f;
-    const float lg0 = (-150.0f - db_offset) / kDb;
+    // (wave-uniform, but a VALU division: pinned to a scalar register instead of a vector register held across the window loop)
+    const float lg0 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint((-150.0f - db_offset) / kDb)));
     float4 op[2];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         const uint32_t g = (uint32_t)t + 256u * i;
         op[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g < ngroups) op[i] = *reinterpret_cast<const float4 *>(offpink + 4 * g);   // table padded to the row stride
+        // byte offset recomputed per window (opaque to the optimiser): hoisted out of the window loop the two 64-bit row
+        // addresses cost four vector registers for its whole length — this kernel sits at the three-waves-per-SIMD edge
+        uint32_t boff = 16u * g;
+        asm volatile("" : "+v"(boff));
+        if (!LDS_TABLE && g < ngroups) op[i] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(offpink) + boff);   // table padded to the row stride
     }
     float rm[2][4], rs[2][4];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         const uint32_t g = (uint32_t)t + 256u * i;
         if (g < ngroups) {
-            const uint32_t k0 = first_bin + 4 * g;
+            uint32_t k0 = first_bin + 4 * g;
+            // The sixteen LDS addresses of a thread's two groups are window-loop invariants the compiler likes to keep in
+            // registers; k_fft4096_ms1 sits at the three-waves-per-SIMD limit, and two of them used to end up in scratch
+            // (reloaded at the top of every epilogue).  The second group's index is opaque per window instead: its eight
+            // addresses are recomputed (a few integer instructions each) and nothing is spilled.
+            if ((LDS_TABLE || COLS) && i == 1) asm volatile("" : "+v"(k0));
             float qm[4], qs[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
@@ -209,6 +232,7 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
                 qm[e] = fmaf(m2.x, m2.x, m2.y * m2.y);
                 qs[e] = fmaf(s2.x, s2.x, s2.y * s2.y);
             }
+            if (LDS_TABLE) op[i] = reinterpret_cast<const float4 *>(offpink)[g];
             const float opv[4] = {op[i].x, op[i].y, op[i].z, op[i].w};
             const float qmin = fminf(fminf(fminf(qm[0], qm[1]), fminf(qm[2], qm[3])), fminf(fminf(qs[0], qs[1]), fminf(qs[2], qs[3])));
             if (__builtin_expect(__ballot(qmin == 0.0f) == 0ull, 1)) {
@@ -228,6 +252,38 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
 #pragma unroll
             for (int e = 0; e < 4; e++) { rm[i][e] = 0.0f; rs[i][e] = 0.0f; }
         }
+    }
+    if (COLS) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint32_t g = (uint32_t)t + 256u * i;
+            if (g < ngroups) {
+                const uint2 cw = reinterpret_cast<const uint2 *>(bincol)[g];          // four u16 column indices (0xFFFF: padding)
+                const uint32_t c[4] = {cw.x & 0xFFFFu, cw.x >> 16, cw.y & 0xFFFFu, cw.y >> 16};
+#pragma unroll
+                for (int row = 0; row < 2; row++) {
+                    uint32_t key[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float v = fminf(fmaxf((row ? rs[i][e] : rm[i][e]) + gain, -100.0f), 0.0f);
+                        key[e] = __float_as_uint(0.0f - v);
+                    }
+                    uint32_t *cb = colbuf + row * cols;
+                    uint32_t m = key[0], cc = c[0];
+#pragma unroll
+                    for (int e = 1; e < 4; e++) {
+                        if (c[e] != cc) {
+                            if (cc != 0xFFFFu) atomicMin(cb + cc, m);
+                            m = key[e]; cc = c[e];
+                        } else {
+                            m = key[e] < m ? key[e] : m;
+                        }
+                    }
+                    if (cc != 0xFFFFu) atomicMin(cb + cc, m);
+                }
+            }
+        }
+        return;
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_sched_barrier(0);          // the stores stay behind everything above
@@ -252,6 +308,58 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
         }
     }
 }
+
+// The two rows of a window ride ONE complex transform, whose rounding noise (about -134 dB under the louder row) stands in
+// a row whose signal was EXACTLY zero over the whole window — where the reference, which transforms each signal on its own,
+// reports its floor: a buffer of zeros has magnitude 0 in every bin, hence -150 dB (analyzer.rs:20-22).  Dual-mono files
+// (L == R: the side signal is zero) and digital silence in front of a programme (the window pairs of k_fft4096_pairw) are
+// the everyday cases.  The kernels keep a wave-uniform "some sample is non-zero" bit per hop and signal; a window whose row
+// is empty takes this rare path BEHIND the ordinary epilogue and overwrites that row with the floor, -150 dB + pink
+// (exactly what the epilogue writes for a zero magnitude).  Kept out of the epilogue itself: the hot path's registers.
+__device__ __forceinline__ void fft4096_floor_rows(int t, uint32_t n_bins, float db_offset, const float *__restrict__ offpink,
+                                                float *o_first, float *o_second, bool first_zero, bool second_zero)
+{
+    constexpr float kDb = 3.01029995663981195f;
+    const float lg0 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint((-150.0f - db_offset) / kDb)));
+    const uint32_t ngroups = (n_bins + 3) >> 2;
+    __builtin_amdgcn_s_waitcnt(0);                  // the ordinary stores of these rows have left the wave: these come after them
+    for (uint32_t g = (uint32_t)t; g < ngroups; g += 256u) {
+        const float4 op = *reinterpret_cast<const float4 *>(offpink + 4 * g);
+        const float4 v = make_float4(fmaf(lg0, kDb, op.x), fmaf(lg0, kDb, op.y), fmaf(lg0, kDb, op.z), fmaf(lg0, kDb, op.w));
+        if (first_zero) reinterpret_cast<float4 *>(o_first)[g] = v;
+        if (second_zero) reinterpret_cast<float4 *>(o_second)[g] = v;
+    }
+}
+
+// the same for the columns-only mode: the empty row's columns are REPLACED by the floor's (a barrier separates this from
+// the epilogue's atomics; every column of the row is rewritten from scratch by a plain store, then the floor values — a
+// monotone function of the bin's pink compensation — are folded in like any other row)
+__device__ __forceinline__ void fft4096_floor_columns(int t, uint32_t n_bins, float db_offset, const float *__restrict__ offpink,
+                                                      uint32_t *colbuf, const uint16_t *bincol, uint32_t cols, float gain,
+                                                      bool first_zero, bool second_zero)
+{
+    constexpr float kDb = 3.01029995663981195f;
+    const float lg0 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint((-150.0f - db_offset) / kDb)));
+    __syncthreads();
+    for (uint32_t c = (uint32_t)t; c < cols; c += 256u) {
+        if (first_zero) colbuf[c] = 0xFFFFFFFFu;
+        if (second_zero) colbuf[cols + c] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    for (uint32_t k = (uint32_t)t; k < n_bins; k += 256u) {
+        const uint32_t c = bincol[k];
+        const float v = fminf(fmaxf(fmaf(lg0, kDb, offpink[k]) + gain, -100.0f), 0.0f);
+        const uint32_t key = __float_as_uint(0.0f - v);
+        if (first_zero) atomicMin(colbuf + c, key);
+        if (second_zero) atomicMin(colbuf + cols + c, key);
+    }
+}
+
+// "is this signal exactly zero over the window?" — bit patterns without the sign (a -0.0 is a zero, a NaN is not)
+__device__ __forceinline__ uint32_t absbits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+// wave-uniform: some lane holds a non-zero pattern
+__device__ __forceinline__ bool wave_any(uint32_t v) { return __ballot(v != 0u) != 0ull; }
+__device__ __forceinline__ uint32_t lds_uniform(const uint32_t *p) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)*p); }
 
 // HS = hop / 256.  A workgroup iteration transforms TWO consecutive windows: they share the
 // sliding sample registers (16 + HS slots) and every per-thread constant, and every barrier
@@ -280,6 +388,7 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
     // multiples of 4, so every 16-lane read group hits 16 distinct 4-bank slots)
 #define X2W(kb, ka_, tb_) ((kb) * kPlane + (ka_) * kRow + (tb_))
     __shared__ __attribute__((aligned(16))) v2f tw2s[256];                //  2048 B
+    __shared__ uint32_t zflag[2][4];      // [iteration parity][window 0 mid, side, window 1 mid, side]: some sample is non-zero
 
     const int t = threadIdx.x;
     const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
@@ -319,8 +428,24 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
         df[j] = v.x - v.y;
     }
 
+    if (t < 8) (&zflag[0][0])[t] = 0u;
+    __syncthreads();
     for (uint32_t w = w_begin; w < w_end; w += 2) {
         const bool two = (w + 1 < w_end);
+        const uint32_t par = ((w - w_begin) >> 1) & 1u;
+        {   // zero-row flags of this pair (read in the epilogue, behind barriers); the other parity's are cleared for the next
+            uint32_t a0 = 0, d0 = 0, a1 = 0, d1 = 0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) { a0 |= absbits(sm[j]); d0 |= absbits(df[j]); a1 |= absbits(sm[j + HS]); d1 |= absbits(df[j + HS]); }
+            const bool w0 = wave_any(a0), w1 = wave_any(d0), w2 = wave_any(a1), w3 = wave_any(d1);
+            if ((t & 63) == 0) {
+                if (w0) zflag[par][0] = 1u;
+                if (w1) zflag[par][1] = 1u;
+                if (w2) zflag[par][2] = 1u;
+                if (w3) zflag[par][3] = 1u;
+            }
+            if (t == 64) { zflag[par ^ 1u][0] = 0u; zflag[par ^ 1u][1] = 0u; zflag[par ^ 1u][2] = 0u; zflag[par ^ 1u][3] = 0u; }
+        }
         // prefetch the 2*HS new slots of the next pair (consumed after the epilogue)
         float2 nx[2 * HS];
         const bool more = (w + 2 < w_end), more2 = (w + 3 < w_end);
@@ -385,6 +510,14 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
         fft4096_epilogue(xbuf[0], t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride);
         if (two) fft4096_epilogue(xbuf[1], t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid + out_win_stride,
                                   o_mid + out_win_stride + p.bin_stride);
+        {
+            const uint32_t z0 = lds_uniform(&zflag[par][0]), z1 = lds_uniform(&zflag[par][1]);
+            const uint32_t z2 = lds_uniform(&zflag[par][2]), z3 = lds_uniform(&zflag[par][3]);
+            if (__builtin_expect((z0 & z1) == 0u, 0))
+                fft4096_floor_rows(t, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride, z0 == 0u, z1 == 0u);
+            if (__builtin_expect(two && (z2 & z3) == 0u, 0))
+                fft4096_floor_rows(t, p.n_bins, p.db_offset, p.offpink, o_mid + out_win_stride, o_mid + out_win_stride + p.bin_stride, z2 == 0u, z3 == 0u);
+        }
         // ---- slide the sample registers by two hops
         if (more) {
 #pragma unroll
@@ -434,11 +567,20 @@ __device__ unsigned long long g_fft_prof[16];
 #define SS_FPROF_MARK(i)
 #define SS_FPROF_END
 #endif
-template <int HS, bool TW6>
+template <int HS, bool TW6, bool COLS>
 __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchParams p)
 {
     __shared__ __attribute__((aligned(16))) v2f xbuf[16 * kPlane];        // 36864 B
     __shared__ __attribute__((aligned(16))) v2f tw2s[256];                //  2048 B
+    // zero-row detection (see fft4096_floor_rows): [window parity][mid, side][wave] = the window for which that wave's slice of
+    // the signal was all zero.  Only waves whose own slice IS zero ever write or read here — the ordinary window costs a few
+    // ORs, two ballots and scalar arithmetic, no LDS traffic and no barrier.
+    __shared__ uint32_t zslot[2][2][4];
+    // 8192 B: db_offset + pink per retained bin (n_bins <= 2047 at N = 4096).  Columns-only mode (COLS) uses the room for the
+    // bins' chart columns (u16 each) and the two rows' column accumulators instead, and reads the table from global memory.
+    __shared__ __attribute__((aligned(16))) float offp[2048];
+    uint16_t *bincol = reinterpret_cast<uint16_t *>(offp);                //  4096 B
+    uint32_t *colbuf = reinterpret_cast<uint32_t *>(offp) + 1024;         //  4096 B: [mid, side][cols <= 512]
 #if SS_FFT_E1ROW      /* first exchange in the row layout of the second one: the reader's 16 values are contiguous (8 x ds_read_b128) */
 #define X1W(ka, tb_, ta_) ((ka) * kPlane + (tb_) * kRow + (ta_))
 #else
@@ -469,6 +611,25 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
         for (int ka = 1; ka < 16; ka++) tw1[ka] = twn[t * ka];
     }
     tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[t];
+    if (COLS) {
+        for (uint32_t g = (uint32_t)t; 4u * g < p.bin_stride; g += 256u)
+            reinterpret_cast<uint2 *>(bincol)[g] = reinterpret_cast<const uint2 *>(p.bin_col)[g];
+        for (uint32_t c = (uint32_t)t; c < 2u * p.cols; c += 256u) colbuf[c] = 0xFFFFFFFFu;
+    } else {
+        for (uint32_t g = (uint32_t)t; 4u * g < p.bin_stride; g += 256u)
+            reinterpret_cast<float4 *>(offp)[g] = reinterpret_cast<const float4 *>(p.offpink)[g];
+    }
+    // columns-only mode: gain of this stream, and where a finished window's columns go (flushed one window late, behind the
+    // loop-end barrier that closes its epilogue's atomics, by the threads that idle least: all of them, one column pair each)
+    const float cgain = COLS ? (p.integrated ? -13.0f - (float)p.integrated[stream] : p.gain_db) : 0.0f;
+    auto flush_columns = [&](uint32_t wdone) {
+        float *oc = p.out_cols + ((size_t)stream * p.n_windows + wdone) * 2u * p.cols;
+        for (uint32_t c = (uint32_t)t; c < 2u * p.cols; c += 256u) {
+            const uint32_t k = colbuf[c];
+            colbuf[c] = 0xFFFFFFFFu;
+            oc[c] = k == 0xFFFFFFFFu ? __builtin_nanf("") : 0.0f - __uint_as_float(k);
+        }
+    };
     const int tb = t & 15, hi = t >> 4;
     const int tsw = SPEC_POS(t);
     const size_t out_win_stride = (size_t)2 * p.bin_stride;
@@ -480,11 +641,40 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
         sm[j] = v.x + v.y;
         df[j] = v.x - v.y;
     }
+    // zero-row detection (see fft4096_epilogue).  Per hop of HS slots: "some lane of this wave holds a non-zero sample", a
+    // wave-uniform bit, so the window's 16 / HS hop bits per signal live in ONE scalar register (bits 0.. mid, bits 8.. side)
+    // and a slide costs 2 HS ORs and two ballots for the new hop — no vector registers are held for it.
+    constexpr int NH = 16 / HS;
+    uint32_t hopmask = 0u;
+#pragma unroll
+    for (int g = 0; g < NH; g++) {
+        uint32_t m = 0u, d = 0u;
+#pragma unroll
+        for (int q = 0; q < HS; q++) { m |= absbits(sm[g * HS + q]); d |= absbits(df[g * HS + q]); }
+        hopmask |= (wave_any(m) ? 1u : 0u) << g;
+        hopmask |= (wave_any(d) ? 1u : 0u) << (8 + g);
+    }
+    if (t < 16) (&zslot[0][0][0])[t] = 0xFFFFFFFFu;
     __syncthreads();
+    const uint32_t wvid = (uint32_t)__builtin_amdgcn_readfirstlane(t >> 6);
+    // a wave publishes "my slice of window wnext is empty" (bit 0: mid, bit 1: side) at the slide of the window before it
+    auto publish_zero = [&](uint32_t zbits, uint32_t parity, uint32_t wnext) {
+        if (__builtin_expect(zbits != 0u, 0)) {
+            if ((t & 63) == 0) {
+                if (zbits & 1u) zslot[parity][0][wvid] = wnext;
+                if (zbits & 2u) zslot[parity][1][wvid] = wnext;
+            }
+        }
+    };
+    auto zero_bits = [&]() -> uint32_t { return ((hopmask & 0xFFu) == 0u ? 1u : 0u) | ((hopmask & 0xFF00u) == 0u ? 2u : 0u); };
+    publish_zero(zero_bits(), 0u, w_begin);
     SS_FPROF_DECL
     for (uint32_t w = w_begin; w < w_end; ++w) {
         float2 nx[HS];
         const bool more = (w + 1 < w_end);
+        const uint32_t par = (w - w_begin) & 1u;
+        if (COLS && w != w_begin) flush_columns(w - 1);      // (its next atomics are four barriers away)
+        const uint32_t curz = zero_bits();                   // this wave's slice of THIS window (hopmask moves on at the slide)
 #if !SS_FFT_LATE_HOP
 #pragma unroll
         for (int q = 0; q < HS; q++) {
@@ -560,16 +750,35 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
         if (more) {
 #pragma unroll
             for (int j = 0; j < 16 - HS; j++) { sm[j] = sm[j + HS]; df[j] = df[j + HS]; }
+            uint32_t nm = 0u, nd = 0u;
 #pragma unroll
-            for (int q = 0; q < HS; q++) { sm[16 - HS + q] = nx[q].x + nx[q].y; df[16 - HS + q] = nx[q].x - nx[q].y; }
+            for (int q = 0; q < HS; q++) {
+                sm[16 - HS + q] = nx[q].x + nx[q].y; df[16 - HS + q] = nx[q].x - nx[q].y;
+                nm |= absbits(sm[16 - HS + q]); nd |= absbits(df[16 - HS + q]);
+            }
+            hopmask = ((hopmask >> 1) & 0x7F7Fu) | ((wave_any(nm) ? 1u : 0u) << (NH - 1)) | ((wave_any(nd) ? 1u : 0u) << (8 + NH - 1));
+            publish_zero(zero_bits(), par ^ 1u, w + 1);
         }
         float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
-        fft4096_epilogue(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride);
+        if (COLS) fft4096_epilogue<false, true>(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, nullptr, nullptr, true, colbuf, bincol, p.cols, cgain);
+        else fft4096_epilogue<true>(xbuf, t, p.first_bin, p.n_bins, p.db_offset, offp, o_mid, o_mid + p.bin_stride);
+        if (__builtin_expect(curz != 0u, 0)) {
+            // my slice is empty: is everybody's?  (every wave of an empty row arrives here and reads the same four slots)
+            bool z0 = false, z1 = false;
+            if (curz & 1u) { const uint4 q = *reinterpret_cast<const uint4 *>(zslot[par][0]); z0 = q.x == w && q.y == w && q.z == w && q.w == w; }
+            if (curz & 2u) { const uint4 q = *reinterpret_cast<const uint4 *>(zslot[par][1]); z1 = q.x == w && q.y == w && q.z == w && q.w == w; }
+            z0 = __builtin_amdgcn_readfirstlane(z0) != 0; z1 = __builtin_amdgcn_readfirstlane(z1) != 0;
+            if (z0 || z1) {
+                if (!COLS) fft4096_floor_rows(t, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride, z0, z1);
+                else fft4096_floor_columns(t, p.n_bins, p.db_offset, p.offpink, colbuf, bincol, p.cols, cgain, z0, z1);
+            }
+        }
         SS_FPROF_MARK(10);
         __syncthreads();
         SS_FPROF_MARK(11);
     }
     SS_FPROF_END;
+    if (COLS) flush_columns(w_end - 1);                     // (the loop's last barrier closed the last epilogue)
 #undef X1W
 #undef X2W
 }
@@ -582,6 +791,7 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_pairw(FftBatchPa
 {
     __shared__ __attribute__((aligned(16))) v2f xbuf[16 * kPlane];        // 36864 B
     __shared__ __attribute__((aligned(16))) v2f tw2s[256];                //  2048 B
+    __shared__ uint32_t zflag[2][2];      // [pair parity][first, second window]: some sample of the window is non-zero
 #define X1W(ka, tb_, ta_) ((ka) * kX1Stride + (tb_) + 16 * (ta_))
 #define X2W(kb, ka_, tb_) ((kb) * kPlane + (ka_) * kRow + (tb_))
     const int t = threadIdx.x;
@@ -620,11 +830,27 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_pairw(FftBatchPa
     const bool two0 = (2u * pp_begin + 1u < n_win);
 #pragma unroll
     for (int j = 0; j < 20; j++) raw[j] = (j < 16 || two0) ? src[(size_t)(t + 256 * j) * C] : 0.0f;
+    // zero-row detection (see fft4096_epilogue and k_fft4096_ms1): one wave-uniform bit per hop of four slots; the first
+    // window is hops 0..3, the second hops 1..4
+    uint32_t hopmask = 0u;
+#pragma unroll
+    for (int g = 0; g < 5; g++)
+        hopmask |= (wave_any(absbits(raw[4 * g]) | absbits(raw[4 * g + 1]) | absbits(raw[4 * g + 2]) | absbits(raw[4 * g + 3])) ? 1u : 0u) << g;
+    if (t < 4) (&zflag[0][0])[t] = 0u;
     __syncthreads();
     for (uint32_t pp = pp_begin; pp < pp_end; ++pp) {
         const bool two = (2u * pp + 1u < n_win);
         const bool more = (pp + 1 < pp_end);
         const bool more2 = more && (2u * pp + 3u < n_win);
+        const uint32_t par = (pp - pp_begin) & 1u;
+        {
+            const bool wa = (hopmask & 0x0Fu) != 0u, wb = (hopmask & 0x1Eu) != 0u;
+            if ((t & 63) == 0) {
+                if (wa) zflag[par][0] = 1u;
+                if (wb) zflag[par][1] = 1u;
+            }
+            if (t == 64) { zflag[par ^ 1u][0] = 0u; zflag[par ^ 1u][1] = 0u; }      // (uniform addresses: nothing per-lane to keep in a register)
+        }
         float nx[8];
         const float *nsrc = src + ((size_t)(pp - pp_begin) * 2048u + t) * C;
 #pragma unroll
@@ -670,11 +896,18 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_pairw(FftBatchPa
         SS_PRIO_EPI();
         float *o_first = outp + (size_t)(pp - pp_begin) * 2u * row_stride;
         fft4096_epilogue(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_first, o_first + row_stride, two);
+        {
+            const uint32_t z0 = lds_uniform(&zflag[par][0]), z1 = lds_uniform(&zflag[par][1]);
+            if (__builtin_expect((z0 & z1) == 0u, 0))
+                fft4096_floor_rows(t, p.n_bins, p.db_offset, p.offpink, o_first, o_first + row_stride, z0 == 0u, two && z1 == 0u);
+        }
         if (more) {
 #pragma unroll
             for (int j = 0; j < 12; j++) raw[j] = raw[j + 8];
 #pragma unroll
             for (int q = 0; q < 8; q++) raw[12 + q] = nx[q];
+            hopmask = (hopmask >> 2) | ((wave_any(absbits(nx[0]) | absbits(nx[1]) | absbits(nx[2]) | absbits(nx[3])) ? 1u : 0u) << 3) |
+                      ((wave_any(absbits(nx[4]) | absbits(nx[5]) | absbits(nx[6]) | absbits(nx[7])) ? 1u : 0u) << 4);
         }
         __syncthreads();
     }
@@ -699,6 +932,7 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms_anyhop(FftBatc
 {
     __shared__ __attribute__((aligned(16))) v2f xbuf[16 * kX1Stride];
     __shared__ __attribute__((aligned(16))) v2f tw2s[256];
+    __shared__ uint32_t zflag[2][2];      // [window parity][mid, side]: some sample of the window's signal is non-zero
     const int t = threadIdx.x;
     const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
     const uint32_t stream = blockIdx.x / groups;
@@ -714,13 +948,27 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms_anyhop(FftBatc
     const int tb = t & 15, hi = t >> 4;
     const size_t out_win_stride = (size_t)2 * p.bin_stride;
     float *outp = p.out + ((size_t)stream * p.n_windows + w_begin) * out_win_stride;
+    if (t < 4) (&zflag[0][0])[t] = 0u;
+    __syncthreads();
     for (uint32_t w = w_begin; w < w_end; ++w) {
         v2f z[16];
+        uint32_t am = 0u, ad = 0u;
+        const uint32_t par = (w - w_begin) & 1u;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const float2 v = src[(size_t)(w - w_begin) * p.hop + t + 256 * j];
             const float hwj = p.half_window[t + 256 * j];
-            z[j] = v2f{(v.x + v.y) * hwj, (v.x - v.y) * hwj};
+            const float sv = v.x + v.y, dv = v.x - v.y;
+            am |= absbits(sv); ad |= absbits(dv);
+            z[j] = v2f{sv * hwj, dv * hwj};
+        }
+        {
+            const bool wm = wave_any(am), wd = wave_any(ad);
+            if ((t & 63) == 0) {
+                if (wm) zflag[par][0] = 1u;
+                if (wd) zflag[par][1] = 1u;
+            }
+            if (t == 64) { zflag[par ^ 1u][0] = 0u; zflag[par ^ 1u][1] = 0u; }      // (uniform addresses: nothing per-lane to keep in a register)
         }
         fft16(z);
         __syncthreads();
@@ -745,6 +993,11 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms_anyhop(FftBatc
         __syncthreads();
         float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
         fft4096_epilogue(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride);
+        {
+            const uint32_t z0 = lds_uniform(&zflag[par][0]), z1 = lds_uniform(&zflag[par][1]);
+            if (__builtin_expect((z0 & z1) == 0u, 0))
+                fft4096_floor_rows(t, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride, z0 == 0u, z1 == 0u);
+        }
     }
 }
 
@@ -932,6 +1185,12 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
     const v2f hc0 = {-0.5f * wa.x, -0.5f * wb.x}, hs0 = {-0.5f * wa.y, -0.5f * wb.y};   // -1/2 cos a_e, +1/2 sin a_e
     const v2f hc1 = {-0.5f * wc.x, -0.5f * wd.x}, hs1 = {-0.5f * wc.y, -0.5f * wd.y};
     const v2f half = {0.5f, 0.5f};
+    // ... except for the two EDGE slots (0 and 15), whose weights are small: rebuilt in f32 they are within 2.4e-7 of the
+    // crate's table, which is nothing for a weight of 0.5 but 1e-4 of a weight of 2e-3 — and a window whose only loud
+    // samples sit in its last hop (the first window after a near-silent passage) has nothing but such weights under its
+    // energy: 0.012 dB against the oracle there.  Those eight weights come from the table itself (bit-equal to the crate's).
+    const v2f we0a = {p.window[n0], p.window[n0 + 1]}, we0b = {p.window[n0 + 2], p.window[n0 + 3]};
+    const v2f we15a = {p.window[15360u + n0], p.window[15360u + n0 + 1]}, we15b = {p.window[15360u + n0 + 2], p.window[15360u + n0 + 3]};
     v2f twg[16];
     twg[1] = tw4k[t]; twg[2] = tw4k[2 * t]; twg[3] = tw4k[3 * t];
     twg[4] = tw4k[4 * t]; twg[8] = tw4k[8 * t]; twg[12] = tw4k[12 * t];
@@ -948,23 +1207,83 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
 #if !SS_FFT16K_LATE_HOP
         if (more) ld4((size_t)(w + 1 - w_begin) * 1024u + n0 + 1024u * 15u, nx0, nx1);
 #endif
+        v2f z0[16], z1[16];
+        // cos(j pi/8), sin(j pi/8): the Hann weight of slot j is 1/2 - 1/2 (cos a cj - sin a sj)
+        constexpr float cj[16] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.0f,
+                                  -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.0f,
+                                  -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f, 0.0f,
+                                  0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f};
+        constexpr float sj[16] = {0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f, 1.0f,
+                                  0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.0f,
+                                  -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.0f,
+                                  -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f};
+#if SS_FFT16K_SKEW
+        // The two halves are independent problems and run SKEWED by one phase: while one half's exchange is in flight
+        // through LDS (its reads issued right behind a barrier), the other half's butterflies and twiddles issue on the
+        // VALU, so no read is waited for with nothing to do (in lockstep — both halves reading between the same two
+        // barriers — the kernel's VALU-busy and LDS-busy fractions simply added up: 53 % + 46 %).  Same seven barriers per
+        // window.  Every barrier orders one half's writes before its reads AND retires the other half's reads (a wave
+        // waits for its own LDS reads before it signals), which frees that buffer for the next pass's writes.
+#pragma unroll
+        for (int j = 0; j < 16; j++) z0[j] = raw0[j] * (j == 0 ? we0a : (j == 15 ? we15a : half + hc0 * cj[j] + hs0 * sj[j]));
+        fft16(z0);
+#pragma unroll
+        for (int ka = 1; ka < 16; ka++) {
+            if (ka & 3) z0[R16(ka)] = pk_cmul(z0[R16(ka)], twg[ka & 3]);
+            if (ka & 12) z0[R16(ka)] = pk_cmul(z0[R16(ka)], twg[ka & 12]);
+        }
+        // (loop-end barrier of the previous window sits HERE: everything above touches no LDS, so a wave that has finished
+        // its share of the previous epilogue starts this window while the others are still reading the spectra)
+        if (w != w_begin) __syncthreads();
+#pragma unroll
+        for (int ka = 0; ka < 16; ka++) xbuf2[0][X1W(ka, tb, hi)] = z0[R16(ka)];
+        __syncthreads();                                        // B1: half 0, exchange 1 written
+#pragma unroll
+        for (int ta = 0; ta < 16; ta++) z0[ta] = xbuf2[0][X1W(hi, tb, ta)];
+#pragma unroll
+        for (int j = 0; j < 16; j++) z1[j] = raw1[j] * (j == 0 ? we0b : (j == 15 ? we15b : half + hc1 * cj[j] + hs1 * sj[j]));
+        fft16(z1);
+        xbuf2[1][X1W(0, tb, hi)] = z1[R16(0)];
+#pragma unroll
+        for (int ka = 1; ka < 16; ka++) {
+            v2f v = z1[R16(ka)];
+            if (ka & 3) v = pk_cmul(v, twg[ka & 3]);
+            if (ka & 12) v = pk_cmul(v, twg[ka & 12]);
+            xbuf2[1][X1W(ka, tb, hi)] = v;
+        }
+        if (more) ld4((size_t)(w + 1 - w_begin) * 1024u + n0 + 1024u * 15u, nx0, nx1);
+        __syncthreads();                                        // B2: half 1, exchange 1 written; half 0's reads retired
+#pragma unroll
+        for (int ta = 0; ta < 16; ta++) z1[ta] = xbuf2[1][X1W(hi, tb, ta)];
+        fft16(z0);
+        xbuf2[0][X2W(0, hi, tb)] = z0[R16(0)];
+#pragma unroll
+        for (int kb = 1; kb < 16; kb++) xbuf2[0][X2W(kb, hi, tb)] = pk_cmul(z0[R16(kb)], tw2s[tb * kb]);
+        __syncthreads();                                        // B3: half 0, exchange 2 written; half 1's reads retired
+#pragma unroll
+        for (int qq = 0; qq < 16; qq++) z0[qq] = xbuf2[0][X2W(hi, tb, qq)];
+        fft16(z1);
+        xbuf2[1][X2W(0, hi, tb)] = z1[R16(0)];
+#pragma unroll
+        for (int kb = 1; kb < 16; kb++) xbuf2[1][X2W(kb, hi, tb)] = pk_cmul(z1[R16(kb)], tw2s[tb * kb]);
+        __syncthreads();                                        // B4: half 1, exchange 2 written; half 0's reads retired
+#pragma unroll
+        for (int qq = 0; qq < 16; qq++) z1[qq] = xbuf2[1][X2W(hi, tb, qq)];
+        fft16(z0);
+#pragma unroll
+        for (int kc = 0; kc < 16; kc++) xbuf2[0][kc * 256 + tsw] = z0[R16(kc)];   // Z_q[k] at SPEC_POS(k)
+        __syncthreads();                                        // B5: half 1's reads retired (its buffer takes the publish next)
+        fft16(z1);
+#pragma unroll
+        for (int kc = 0; kc < 16; kc++) xbuf2[1][kc * 256 + tsw] = z1[R16(kc)];
+        __syncthreads();                                        // B6: both spectra published
+#else
         // the two halves are independent problems: every barrier phase carries both (half the barriers
         // per transform, two instruction streams to cover LDS latency)
-        v2f z0[16], z1[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-            // cos(j pi/8), sin(j pi/8)
-            constexpr float cj[16] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.0f,
-                                      -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.0f,
-                                      -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f, 0.0f,
-                                      0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f};
-            constexpr float sj[16] = {0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f, 1.0f,
-                                      0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.0f,
-                                      -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.0f,
-                                      -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f};
-            // w = 1/2 - 1/2 (cos a cj - sin a sj)
-            z0[j] = raw0[j] * (half + hc0 * cj[j] + hs0 * sj[j]);
-            z1[j] = raw1[j] * (half + hc1 * cj[j] + hs1 * sj[j]);
+            z0[j] = raw0[j] * (j == 0 ? we0a : (j == 15 ? we15a : half + hc0 * cj[j] + hs0 * sj[j]));
+            z1[j] = raw1[j] * (j == 0 ? we0b : (j == 15 ? we15b : half + hc1 * cj[j] + hs1 * sj[j]));
         }
         fft16(z0);
         xbuf2[0][X1W(0, tb, hi)] = z0[R16(0)];
@@ -1010,6 +1329,8 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
 #pragma unroll
         for (int kc = 0; kc < 16; kc++) xbuf2[1][kc * 256 + tsw] = z1[R16(kc)];
         __syncthreads();
+
+#endif
 
         // ---- epilogue.  Iteration `it` covers 1024 retained bins, wave wv the 256 of them starting at
         // 1024 it + 256 wv.  Reading: lane l takes bins +l, +64+l, +128+l, +192+l, so every LDS read of the two
@@ -1082,7 +1403,9 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
             for (int j = 0; j < 15; j++) { raw0[j] = raw0[j + 1]; raw1[j] = raw1[j + 1]; }
             raw0[15] = nx0; raw1[15] = nx1;
         }
+#if !SS_FFT16K_SKEW
         __syncthreads();                    // epilogue reads are done before the next window's pass-1 writes
+#endif
     }
 #undef X1W
 #undef X2W
@@ -1137,7 +1460,8 @@ hipError_t launch_fft4096_ms(const FftBatchParams &p, hipStream_t s)
 #if defined(SS_FFT_PAIR)
     if (p.hop == 1024) hipLaunchKernelGGL(k_fft4096_ms<4>, grid, block, 0, s, p);
 #else
-    if (p.hop == 1024) hipLaunchKernelGGL((k_fft4096_ms1<4, true>), grid, block, 0, s, p);
+    if (p.hop == 1024 && p.out_cols) hipLaunchKernelGGL((k_fft4096_ms1<4, true, true>), grid, block, 0, s, p);
+    else if (p.hop == 1024) hipLaunchKernelGGL((k_fft4096_ms1<4, true, false>), grid, block, 0, s, p);
 #endif
     else if (p.hop == 512) hipLaunchKernelGGL(k_fft4096_ms<2>, grid, block, 0, s, p);
     else if (p.hop == 2048) hipLaunchKernelGGL(k_fft4096_ms<8>, grid, block, 0, s, p);

@@ -58,6 +58,13 @@ struct FftBatchParams {
     float db_offset;             // 10*log10(4/N^2) (4096) or 20*log10(4/N) (generic)
     uint32_t publish_mask;       // 4096 kernels: bit kc set when bins [256kc, 256kc+255] hold a retained bin or a mirror
     const uint32_t *windows_of;   // ragged batches: windows of each stream (nullable = n_windows for all)
+    // columns-only spectrum (N3 fused into the epilogue; N = 4096 stereo at hop 1024): the rows are never stored, each
+    // is reduced to `cols` chart columns of max(clamp(dB + gain, -100, 0)) — out_cols[stream][window][mid, side][cols]
+    float *out_cols;             // nullptr: ordinary rows into `out`
+    const uint16_t *bin_col;     // bin_stride entries: chart column of every retained bin, 0xFFFF for the row padding
+    const double *integrated;    // per stream: gain = -13 - (float)integrated (tui.rs:1234); nullptr: gain_db for all
+    uint32_t cols;               // 1 .. 512
+    float gain_db;
 };
 
 // mid/side packed N=4096 kernel (stereo only).  hop must be a multiple of 256.

@@ -76,13 +76,17 @@ def test_analyzer_reinit():
 
 @pytest.mark.parametrize("sr", [44100, 48000, 96000])
 def test_analyze_microphone_input(sr):
-    """tui.rs:2272-2368: a 30*sr-sample 500 Hz ring through analyze_microphone_input; the bin the reference
-    looks at (index 500/(sr/2) * len) is below -20 dB and the charts are filled."""
+    """tui.rs:2272-2368 as the reference runs them: `create_test_app` builds the capture ring with a capacity of
+    44100 * 30 samples (tui.rs:2199) and leaves the device analyzer at Analyzer::default() — 2 channels, 44 100 Hz
+    (analyzer.rs:34-45) — for all three tests; the test then enqueues sr * 30 samples of a 500 Hz tone generated at `sr`,
+    so for 48 k and 96 k the ring keeps the LAST 44100 * 30 of them.  analyze_microphone_input (tui.rs:1427-1480) slices
+    with the analyzer's 44 100; the bin the test looks at (index 500 / (sr / 2) * len) must read below -20 dB."""
     i = np.arange(sr * 30, dtype=np.float32)
-    ring = np.sin(i * F(500.0) * F(2.0) * F(np.pi) / F(sr)).astype(np.float32)
-    sess = ssa.CaptureSession(2, sr)
+    tone = np.sin(i * F(500.0) * F(2.0) * F(np.pi) / F(sr)).astype(np.float32)
+    ring = tone[-44100 * 30:]                                   # AllocRingBuffer::new(44100 * 30): oldest first, newest kept
+    sess = ssa.CaptureSession(2, 44100)                         # device_analyzer: Analyzer::default()
     res = sess.analyze_microphone_input(ring)
-    assert res.mid_status == 0 and sess.mid_fft.shape[0] > 0
+    assert res.mid_status == 0 and sess.mid_fft.shape[0] > 0    # assert!(!app.fft_data.mid_fft.is_empty())
     idx = int(round(500.0 / (sr / 2.0) * sess.mid_fft.shape[0]))
     assert idx < sess.mid_fft.shape[0] and sess.mid_fft[idx, 1] < -20.0
     assert sess.microphone_input_chart.shape == (30000, 2)

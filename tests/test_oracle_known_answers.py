@@ -310,19 +310,23 @@ def test_reference_test_analyzer_reinit(oracle):
 
 @pytest.mark.parametrize("sr", [44100, 48000, 96000])
 def test_reference_mic_driver_tests(oracle, sr):
-    """tui.rs:2272-2368 restated: ring buffer of 30*sr samples of a 500 Hz tone treated as
-    interleaved stereo; the analyzer stays at its default 44 100 Hz (tui.rs:1427-1453)."""
+    """tui.rs:2272-2368 restated one to one: the capture ring has a capacity of 44100 * 30 samples (tui.rs:2199), the test
+    enqueues sr * 30 samples of a 500 Hz tone generated at `sr` (so the ring keeps the LAST 44100 * 30), the samples are
+    treated as interleaved stereo, and the analyzer stays at its default 44 100 Hz (tui.rs:1427-1453)."""
+    from oracle.app_driver import CaptureApp
     i = np.arange(sr * 30, dtype=np.float32)
-    buf = np.sin(i * np.float32(500.0) * np.float32(2.0) * np.float32(np.pi) / np.float32(sr)).astype(np.float32)
-    mid, _ = oracle.mid_side(buf)
-    dev_sr = 44100
-    lb = 15 * dev_sr - 2 ** 14
-    if 15 * dev_sr > mid.size:
-        pytest.skip("slice out of range")
-    fft = oracle.get_fft(dev_sr, mid[lb:15 * dev_sr])
-    assert fft.shape[0] > 0
-    idx = int(round(500.0 / (sr / 2.0) * fft.shape[0]))
-    assert idx < fft.shape[0] and fft[idx, 1] < -20.0
+    tone = np.sin(i * np.float32(500.0) * np.float32(2.0) * np.float32(np.pi) / np.float32(sr)).astype(np.float32)
+    ring = tone[-44100 * 30:]
+    app = CaptureApp(2, 44100)
+    r = app.analyze_microphone_input(ring)
+    assert r["mid_status"] == 0 and app.mid_fft.shape[0] > 0
+    idx = int(round(500.0 / (sr / 2.0) * app.mid_fft.shape[0]))
+    assert idx < app.mid_fft.shape[0] and app.mid_fft[idx, 1] < -20.0
+    assert app.microphone_input_chart.shape == (30000, 2)
+    # the slice the driver takes: mid[15 * 44100 - 16384 .. 15 * 44100] of the 661 500 mid samples
+    mid, _ = oracle.mid_side(ring)
+    assert mid.size == 15 * 44100
+    assert np.array_equal(app.mid_fft, oracle.get_fft(44100, mid[15 * 44100 - 2 ** 14:15 * 44100]))
 
 
 def test_get_fft_errors(oracle):
