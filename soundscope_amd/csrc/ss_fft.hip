@@ -6,20 +6,8 @@
 #include "ss_kernels.h"
 #include <cstdlib>
 
-#ifndef SS_FFT_E1ROW
-#define SS_FFT_E1ROW 1      // k_fft4096_ms1 and k_fft16k_run: the first exchange uses the row layout of the second (A/B: -1 % and -2 %)
-#endif
-#ifndef SS_FFT_LATE_HOP
-#define SS_FFT_LATE_HOP 1      // the next hop's loads are issued behind the first radix pass (A/B: -1.4 %); 2 = behind the second (worse)
-#endif
-#ifndef SS_FFT16K_LATE_HOP
-#define SS_FFT16K_LATE_HOP 1   // k_fft16k_run: the next hop's loads behind the first radix pass (A/B: -3.5 %)
-#endif
-#ifndef SS_FFT16K_SKEW
-#define SS_FFT16K_SKEW 0       // k_fft16k_run: 1 = the two halves run skewed by one phase (one half's LDS exchange flies under the other's butterflies): measured 1 % SLOWER (profiles/r03_ab_fft16k_skew.txt)
-#endif
-#ifndef SS_FFT_NT_STORE
-#define SS_FFT_NT_STORE 0
+#ifndef SS_FFT_TW2K
+#define SS_FFT_TW2K 1          // second-pass twiddle table as [kb][tb], batched reads shared by both halves (k_fft16k_run) / requested early (k_fft4096_ms1)
 #endif
 #ifndef SS_FFT_WAVES
 #define SS_FFT_WAVES 2   // min waves per SIMD the N=4096 pair kernel is register-allocated for
@@ -215,11 +203,11 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
         const uint32_t g = (uint32_t)t + 256u * i;
         if (g < ngroups) {
             uint32_t k0 = first_bin + 4 * g;
-            // The sixteen LDS addresses of a thread's two groups are window-loop invariants the compiler likes to keep in
-            // registers; k_fft4096_ms1 sits at the three-waves-per-SIMD limit, and two of them used to end up in scratch
-            // (reloaded at the top of every epilogue).  The second group's index is opaque per window instead: its eight
-            // addresses are recomputed (a few integer instructions each) and nothing is spilled.
-            if ((LDS_TABLE || COLS) && i == 1) asm volatile("" : "+v"(k0));
+            // The sixteen LDS addresses of a thread's two groups are window-loop invariants the compiler keeps in registers;
+            // the columns-only instantiation sits at the three-waves-per-SIMD limit, where two of them end up in scratch
+            // (reloaded at the top of every epilogue).  There the second group's index is opaque per window instead: its
+            // eight addresses are recomputed (a few integer instructions each) and nothing is spilled.
+            if (COLS && i == 1) asm volatile("" : "+v"(k0));
             float qm[4], qs[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
@@ -292,19 +280,8 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
     for (int i = 0; i < 2; i++) {
         const uint32_t g = (uint32_t)t + 256u * i;
         if (g < ngroups) {
-#if defined(SS_ABL) && SS_ABL == 1      /* ablation: no output stores */
-            asm volatile("" ::"v"(rm[i][0]), "v"(rm[i][1]), "v"(rm[i][2]), "v"(rm[i][3]), "v"(rs[i][0]), "v"(rs[i][1]), "v"(rs[i][2]), "v"(rs[i][3]));
-            (void)o_mid; (void)o_side;
-#else
-#if SS_FFT_NT_STORE
-            typedef float f4v __attribute__((ext_vector_type(4)));
-            __builtin_nontemporal_store(f4v{rm[i][0], rm[i][1], rm[i][2], rm[i][3]}, reinterpret_cast<f4v *>(o_mid) + g);
-            if (store_side) __builtin_nontemporal_store(f4v{rs[i][0], rs[i][1], rs[i][2], rs[i][3]}, reinterpret_cast<f4v *>(o_side) + g);
-#else
             reinterpret_cast<float4 *>(o_mid)[g] = make_float4(rm[i][0], rm[i][1], rm[i][2], rm[i][3]);
             if (store_side) reinterpret_cast<float4 *>(o_side)[g] = make_float4(rs[i][0], rs[i][1], rs[i][2], rs[i][3]);
-#endif
-#endif
         }
     }
 }
@@ -365,16 +342,6 @@ __device__ __forceinline__ uint32_t lds_uniform(const uint32_t *p) { return (uin
 // sliding sample registers (16 + HS slots) and every per-thread constant, and every barrier
 // phase carries two independent radix-16 problems (half the barriers per window, twice the
 // instruction-level parallelism to cover LDS latency).
-#if defined(SS_ABL) && SS_ABL == 4      /* ablation: no butterflies */
-#define SS_FFT16(z) asm volatile("" : "+v"(z[0]), "+v"(z[5]), "+v"(z[10]), "+v"(z[15]))
-#else
-#define SS_FFT16(z) fft16(z)
-#endif
-#if defined(SS_ABL) && SS_ABL == 5      /* ablation: no barriers (racy, timing only) */
-#define SS_SYNC() __builtin_amdgcn_wave_barrier()
-#else
-#define SS_SYNC() __syncthreads()
-#endif
 template <int HS>
 __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams p)
 {
@@ -463,48 +430,48 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
 #pragma unroll
         for (int j = 0; j < 16; j++) z0[j] = v2f{sm[j] * hw[j], df[j] * hw[j]};
         // ---- pass 1 (the loop-end barrier has retired the previous pair's epilogue reads)
-        SS_FFT16(z0);
+        fft16(z0);
         xbuf[0][X1W(0, tb, hi)] = z0[R16(0)];
 #pragma unroll
         for (int ka = 1; ka < 16; ka++) xbuf[0][X1W(ka, tb, hi)] = pk_cmul(z0[R16(ka)], tw1[ka]);
 #pragma unroll
         for (int j = 0; j < 16; j++) z1[j] = v2f{sm[j + HS] * hw[j], df[j + HS] * hw[j]};
-        SS_FFT16(z1);
+        fft16(z1);
         xbuf[1][X1W(0, tb, hi)] = z1[R16(0)];
 #pragma unroll
         for (int ka = 1; ka < 16; ka++) xbuf[1][X1W(ka, tb, hi)] = pk_cmul(z1[R16(ka)], tw1[ka]);
-        SS_SYNC();
+        __syncthreads();
         // ---- pass 2 (thread = tb + 16 ka)
 #pragma unroll
         for (int ta = 0; ta < 16; ta++) {
             z0[ta] = xbuf[0][X1W(hi, tb, ta)];
             z1[ta] = xbuf[1][X1W(hi, tb, ta)];
         }
-        SS_SYNC();
-        SS_FFT16(z0);
+        __syncthreads();
+        fft16(z0);
         xbuf[0][X2W(0, hi, tb)] = z0[R16(0)];
 #pragma unroll
         for (int kb = 1; kb < 16; kb++) xbuf[0][X2W(kb, hi, tb)] = pk_cmul(z0[R16(kb)], tw2s[tb * kb]);
-        SS_FFT16(z1);
+        fft16(z1);
         xbuf[1][X2W(0, hi, tb)] = z1[R16(0)];
 #pragma unroll
         for (int kb = 1; kb < 16; kb++) xbuf[1][X2W(kb, hi, tb)] = pk_cmul(z1[R16(kb)], tw2s[tb * kb]);
-        SS_SYNC();
+        __syncthreads();
         // ---- pass 3 (thread = ka + 16 kb): ka = tb, kb = hi
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             z0[q] = xbuf[0][X2W(hi, tb, q)];
             z1[q] = xbuf[1][X2W(hi, tb, q)];
         }
-        SS_SYNC();
-        SS_FFT16(z0);
+        __syncthreads();
+        fft16(z0);
         // ---- publish the whole spectrum in (swizzled) natural order: Z[t + 256 kc] at SPEC_POS(k)
 #pragma unroll
         for (int kc = 0; kc < 16; kc++) xbuf[0][kc * 256 + tsw] = z0[R16(kc)];
-        SS_FFT16(z1);
+        fft16(z1);
 #pragma unroll
         for (int kc = 0; kc < 16; kc++) xbuf[1][kc * 256 + tsw] = z1[R16(kc)];
-        SS_SYNC();
+        __syncthreads();
         // ---- epilogue: groups of four consecutive bins per thread, 16-byte stores
         float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
         fft4096_epilogue(xbuf[0], t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride);
@@ -527,7 +494,7 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
                 if (NS - 2 * HS + q >= 0) { sm[NS - 2 * HS + q] = nx[q].x + nx[q].y; df[NS - 2 * HS + q] = nx[q].x - nx[q].y; }
             }
         }
-        SS_SYNC();                             // epilogue reads are done before the next pair's pass-1 writes
+        __syncthreads();                             // epilogue reads are done before the next pair's pass-1 writes
     }
 }
 #undef X1W
@@ -551,11 +518,6 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
 #define SS_PRIO_HI()
 #define SS_PRIO_LO()
 #endif
-#if defined(SS_FFT_PRIO_EPI)
-#define SS_PRIO_EPI() 
-#else
-#define SS_PRIO_EPI() SS_PRIO_LO()
-#endif
 // Development build (-DSS_FFT_PROF): per-phase shader-clock totals of k_fft4096_ms1 over all waves (tools/probe_fft_phases.py)
 #ifdef SS_FFT_PROF
 __device__ unsigned long long g_fft_prof[16];
@@ -567,6 +529,12 @@ __device__ unsigned long long g_fft_prof[16];
 #define SS_FPROF_MARK(i)
 #define SS_FPROF_END
 #endif
+#ifndef SS_MS1_ZROW
+#define SS_MS1_ZROW 1      /* temporary A/B switches */
+#endif
+#ifndef SS_MS1_LDSTAB
+#define SS_MS1_LDSTAB 1
+#endif
 template <int HS, bool TW6, bool COLS>
 __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchParams p)
 {
@@ -575,17 +543,13 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
     // zero-row detection (see fft4096_floor_rows): [window parity][mid, side][wave] = the window for which that wave's slice of
     // the signal was all zero.  Only waves whose own slice IS zero ever write or read here — the ordinary window costs a few
     // ORs, two ballots and scalar arithmetic, no LDS traffic and no barrier.
-    __shared__ uint32_t zslot[2][2][4];
+    __shared__ __attribute__((aligned(16))) uint32_t zslot[2][2][4];
     // 8192 B: db_offset + pink per retained bin (n_bins <= 2047 at N = 4096).  Columns-only mode (COLS) uses the room for the
     // bins' chart columns (u16 each) and the two rows' column accumulators instead, and reads the table from global memory.
     __shared__ __attribute__((aligned(16))) float offp[2048];
     uint16_t *bincol = reinterpret_cast<uint16_t *>(offp);                //  4096 B
     uint32_t *colbuf = reinterpret_cast<uint32_t *>(offp) + 1024;         //  4096 B: [mid, side][cols <= 512]
-#if SS_FFT_E1ROW      /* first exchange in the row layout of the second one: the reader's 16 values are contiguous (8 x ds_read_b128) */
 #define X1W(ka, tb_, ta_) ((ka) * kPlane + (tb_) * kRow + (ta_))
-#else
-#define X1W(ka, tb_, ta_) ((ka) * kX1Stride + (tb_) + 16 * (ta_))
-#endif
 #define X2W(kb, ka_, tb_) ((kb) * kPlane + (ka_) * kRow + (tb_))
     const int t = threadIdx.x;
     const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
@@ -610,7 +574,11 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
 #pragma unroll
         for (int ka = 1; ka < 16; ka++) tw1[ka] = twn[t * ka];
     }
+#if SS_FFT_TW2K
+    tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[(t & 15) * (t >> 4)];      // [kb][tb]: W_256^(tb kb) at kb * 16 + tb
+#else
     tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[t];
+#endif
     if (COLS) {
         for (uint32_t g = (uint32_t)t; 4u * g < p.bin_stride; g += 256u)
             reinterpret_cast<uint2 *>(bincol)[g] = reinterpret_cast<const uint2 *>(p.bin_col)[g];
@@ -666,7 +634,11 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
             }
         }
     };
+#if SS_MS1_ZROW
     auto zero_bits = [&]() -> uint32_t { return ((hopmask & 0xFFu) == 0u ? 1u : 0u) | ((hopmask & 0xFF00u) == 0u ? 2u : 0u); };
+#else
+    auto zero_bits = [&]() -> uint32_t { return 0u; };
+#endif
     publish_zero(zero_bits(), 0u, w_begin);
     SS_FPROF_DECL
     for (uint32_t w = w_begin; w < w_end; ++w) {
@@ -675,13 +647,6 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
         const uint32_t par = (w - w_begin) & 1u;
         if (COLS && w != w_begin) flush_columns(w - 1);      // (its next atomics are four barriers away)
         const uint32_t curz = zero_bits();                   // this wave's slice of THIS window (hopmask moves on at the slide)
-#if !SS_FFT_LATE_HOP
-#pragma unroll
-        for (int q = 0; q < HS; q++) {
-            nx[q] = make_float2(0.f, 0.f);
-            if (more) nx[q] = src[(size_t)(w + 1 - w_begin) * p.hop + t + 256 * (16 - HS + q)];
-        }
-#endif
         v2f z[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) z[j] = v2f{sm[j] * hw[j], df[j] * hw[j]};
@@ -700,13 +665,11 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
             }
             xbuf[X1W(ka, tb, hi)] = v;
         }
-#if SS_FFT_LATE_HOP == 1      /* the hop's loads behind the first radix pass: two more passes and the publish still cover them */
 #pragma unroll
         for (int q = 0; q < HS; q++) {
             nx[q] = make_float2(0.f, 0.f);
             if (more) nx[q] = src[(size_t)(w + 1 - w_begin) * p.hop + t + 256 * (16 - HS + q)];
         }
-#endif
         SS_FPROF_MARK(0);
         __syncthreads();
         SS_FPROF_MARK(1);
@@ -719,14 +682,31 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
         fft16(z);
         SS_PRIO_HI();
         xbuf[X2W(0, hi, tb)] = z[R16(0)];
+#if SS_FFT_TW2K
+        {   // second-pass twiddles from the [kb][tb] table (address = tb * 8 + an immediate), four at a time, the next four
+            // requested before the current four are used
+            const v2f *twp = tw2s + tb;
+            v2f twa[4], twb[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) twa[j] = twp[16 * (1 + j)];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int kb0 = 1 + 4 * g, nk = g == 3 ? 3 : 4;
+                if (g < 3) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) if (kb0 + 4 + j < 16) twb[j] = twp[16 * (kb0 + 4 + j)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < nk; j++) xbuf[X2W(kb0 + j, hi, tb)] = pk_cmul(z[R16(kb0 + j)], twa[j]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; j++) twa[j] = twb[j];
+            }
+        }
+#else
 #pragma unroll
         for (int kb = 1; kb < 16; kb++) xbuf[X2W(kb, hi, tb)] = pk_cmul(z[R16(kb)], tw2s[tb * kb]);
-#if SS_FFT_LATE_HOP == 2
-#pragma unroll
-        for (int q = 0; q < HS; q++) {
-            nx[q] = make_float2(0.f, 0.f);
-            if (more) nx[q] = src[(size_t)(w + 1 - w_begin) * p.hop + t + 256 * (16 - HS + q)];
-        }
 #endif
         SS_FPROF_MARK(4);
         __syncthreads();
@@ -745,7 +725,7 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
         SS_FPROF_MARK(8);
         __syncthreads();
         SS_FPROF_MARK(9);
-        SS_PRIO_EPI();
+        SS_PRIO_LO();
         // the sliding registers take the prefetched hop before the epilogue's stores (see fft4096_epilogue)
         if (more) {
 #pragma unroll
@@ -754,14 +734,21 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
 #pragma unroll
             for (int q = 0; q < HS; q++) {
                 sm[16 - HS + q] = nx[q].x + nx[q].y; df[16 - HS + q] = nx[q].x - nx[q].y;
-                nm |= absbits(sm[16 - HS + q]); nd |= absbits(df[16 - HS + q]);
+                nm |= __float_as_uint(sm[16 - HS + q]); nd |= __float_as_uint(df[16 - HS + q]);
             }
+            nm &= 0x7fffffffu; nd &= 0x7fffffffu;            // (a -0.0 is a zero: the sign is dropped once, after the ORs)
+#if SS_MS1_ZROW
             hopmask = ((hopmask >> 1) & 0x7F7Fu) | ((wave_any(nm) ? 1u : 0u) << (NH - 1)) | ((wave_any(nd) ? 1u : 0u) << (8 + NH - 1));
+#endif
             publish_zero(zero_bits(), par ^ 1u, w + 1);
         }
         float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
         if (COLS) fft4096_epilogue<false, true>(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, nullptr, nullptr, true, colbuf, bincol, p.cols, cgain);
+#if SS_MS1_LDSTAB
         else fft4096_epilogue<true>(xbuf, t, p.first_bin, p.n_bins, p.db_offset, offp, o_mid, o_mid + p.bin_stride);
+#else
+        else fft4096_epilogue<false>(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride);
+#endif
         if (__builtin_expect(curz != 0u, 0)) {
             // my slice is empty: is everybody's?  (every wave of an empty row arrives here and reads the same four slots)
             bool z0 = false, z1 = false;
@@ -791,7 +778,9 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_pairw(FftBatchPa
 {
     __shared__ __attribute__((aligned(16))) v2f xbuf[16 * kPlane];        // 36864 B
     __shared__ __attribute__((aligned(16))) v2f tw2s[256];                //  2048 B
-    __shared__ uint32_t zflag[2][2];      // [pair parity][first, second window]: some sample of the window is non-zero
+    // zero-row detection as in k_fft4096_ms1: [pair parity][first, second window][wave] = the pair for which that wave's slice
+    // of the window was all zero (only waves whose own slice is empty ever touch it)
+    __shared__ __attribute__((aligned(16))) uint32_t zslot[2][2][4];
 #define X1W(ka, tb_, ta_) ((ka) * kX1Stride + (tb_) + 16 * (ta_))
 #define X2W(kb, ka_, tb_) ((kb) * kPlane + (ka_) * kRow + (tb_))
     const int t = threadIdx.x;
@@ -836,21 +825,25 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_pairw(FftBatchPa
 #pragma unroll
     for (int g = 0; g < 5; g++)
         hopmask |= (wave_any(absbits(raw[4 * g]) | absbits(raw[4 * g + 1]) | absbits(raw[4 * g + 2]) | absbits(raw[4 * g + 3])) ? 1u : 0u) << g;
-    if (t < 4) (&zflag[0][0])[t] = 0u;
+    if (t < 16) (&zslot[0][0][0])[t] = 0xFFFFFFFFu;
     __syncthreads();
+    const uint32_t wvid = (uint32_t)__builtin_amdgcn_readfirstlane(t >> 6);
+    auto zero_bits = [&]() -> uint32_t { return ((hopmask & 0x0Fu) == 0u ? 1u : 0u) | ((hopmask & 0x1Eu) == 0u ? 2u : 0u); };
+    auto publish_zero = [&](uint32_t zbits, uint32_t parity, uint32_t pnext) {
+        if (__builtin_expect(zbits != 0u, 0)) {
+            if ((t & 63) == 0) {
+                if (zbits & 1u) zslot[parity][0][wvid] = pnext;
+                if (zbits & 2u) zslot[parity][1][wvid] = pnext;
+            }
+        }
+    };
+    publish_zero(zero_bits(), 0u, pp_begin);
     for (uint32_t pp = pp_begin; pp < pp_end; ++pp) {
         const bool two = (2u * pp + 1u < n_win);
         const bool more = (pp + 1 < pp_end);
         const bool more2 = more && (2u * pp + 3u < n_win);
         const uint32_t par = (pp - pp_begin) & 1u;
-        {
-            const bool wa = (hopmask & 0x0Fu) != 0u, wb = (hopmask & 0x1Eu) != 0u;
-            if ((t & 63) == 0) {
-                if (wa) zflag[par][0] = 1u;
-                if (wb) zflag[par][1] = 1u;
-            }
-            if (t == 64) { zflag[par ^ 1u][0] = 0u; zflag[par ^ 1u][1] = 0u; }      // (uniform addresses: nothing per-lane to keep in a register)
-        }
+        const uint32_t curz = zero_bits();                 // this wave's slices of THIS pair (hopmask moves on at the slide)
         float nx[8];
         const float *nsrc = src + ((size_t)(pp - pp_begin) * 2048u + t) * C;
 #pragma unroll
@@ -893,13 +886,15 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_pairw(FftBatchPa
         for (int kc = 0; kc < 16; kc++)
             if ((p.publish_mask >> kc) & 1u) xbuf[kc * 256 + tsw] = z[R16(kc)];
         __syncthreads();
-        SS_PRIO_EPI();
+        SS_PRIO_LO();
         float *o_first = outp + (size_t)(pp - pp_begin) * 2u * row_stride;
         fft4096_epilogue(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_first, o_first + row_stride, two);
-        {
-            const uint32_t z0 = lds_uniform(&zflag[par][0]), z1 = lds_uniform(&zflag[par][1]);
-            if (__builtin_expect((z0 & z1) == 0u, 0))
-                fft4096_floor_rows(t, p.n_bins, p.db_offset, p.offpink, o_first, o_first + row_stride, z0 == 0u, two && z1 == 0u);
+        if (__builtin_expect(curz != 0u, 0)) {
+            bool z0 = false, z1 = false;
+            if (curz & 1u) { const uint4 q = *reinterpret_cast<const uint4 *>(zslot[par][0]); z0 = q.x == pp && q.y == pp && q.z == pp && q.w == pp; }
+            if (curz & 2u) { const uint4 q = *reinterpret_cast<const uint4 *>(zslot[par][1]); z1 = q.x == pp && q.y == pp && q.z == pp && q.w == pp; }
+            z0 = __builtin_amdgcn_readfirstlane(z0) != 0; z1 = __builtin_amdgcn_readfirstlane(z1) != 0;
+            if (z0 || (two && z1)) fft4096_floor_rows(t, p.n_bins, p.db_offset, p.offpink, o_first, o_first + row_stride, z0, two && z1);
         }
         if (more) {
 #pragma unroll
@@ -908,6 +903,7 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_pairw(FftBatchPa
             for (int q = 0; q < 8; q++) raw[12 + q] = nx[q];
             hopmask = (hopmask >> 2) | ((wave_any(absbits(nx[0]) | absbits(nx[1]) | absbits(nx[2]) | absbits(nx[3])) ? 1u : 0u) << 3) |
                       ((wave_any(absbits(nx[4]) | absbits(nx[5]) | absbits(nx[6]) | absbits(nx[7])) ? 1u : 0u) << 4);
+            publish_zero(zero_bits(), par ^ 1u, pp + 1);
         }
         __syncthreads();
     }
@@ -1134,11 +1130,7 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
     __shared__ __attribute__((aligned(16))) v2f xbuf2[2][16 * kPlane];       // 2 x 36864 B
     __shared__ __attribute__((aligned(16))) v2f tw2s[256];                    //  2048 B
     __shared__ __attribute__((aligned(16))) float stage[4][256];              //  4096 B: 79872 B per workgroup, two per CU
-#if SS_FFT_E1ROW      /* first exchange in the row layout of the second one: the reader's 16 values are contiguous (8 x ds_read_b128) */
 #define X1W(ka, tb_, ta_) ((ka) * kPlane + (tb_) * kRow + (ta_))
-#else
-#define X1W(ka, tb_, ta_) ((ka) * kX1Stride + (tb_) + 16 * (ta_))
-#endif
 #define X2W(kb, ka_, tb_) ((kb) * kPlane + (ka_) * kRow + (tb_))
     const int t = threadIdx.x;
     const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
@@ -1160,7 +1152,11 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
     const float *base = p.pcm + ((size_t)stream * p.frames_per_stream + p.first_start + (size_t)w_begin * 1024u) * C;
     const v2f *tw16k = reinterpret_cast<const v2f *>(p.tw_n);       // W_16384^k, k < 8192
     const v2f *tw4k = reinterpret_cast<const v2f *>(p.tw_core);     // W_4096^k
+#if SS_FFT_TW2K
+    tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[(t & 15) * (t >> 4)];      // [kb][tb]: W_256^(tb kb) at kb * 16 + tb
+#else
     tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[t];
+#endif
 
     // samples n .. n + 3 of this workgroup's channel (n relative to the run's first window): the two
     // halves' complex inputs z_0 = (x[n], x[n+1]), z_1 = (x[n+2], x[n+3])
@@ -1204,9 +1200,6 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
     for (uint32_t w = w_begin; w < w_end; ++w) {
         const bool more = (w + 1 < w_end);
         v2f nx0 = {0.0f, 0.0f}, nx1 = {0.0f, 0.0f};
-#if !SS_FFT16K_LATE_HOP
-        if (more) ld4((size_t)(w + 1 - w_begin) * 1024u + n0 + 1024u * 15u, nx0, nx1);
-#endif
         v2f z0[16], z1[16];
         // cos(j pi/8), sin(j pi/8): the Hann weight of slot j is 1/2 - 1/2 (cos a cj - sin a sj)
         constexpr float cj[16] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.0f,
@@ -1217,67 +1210,6 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
                                   0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.0f,
                                   -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.0f,
                                   -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f};
-#if SS_FFT16K_SKEW
-        // The two halves are independent problems and run SKEWED by one phase: while one half's exchange is in flight
-        // through LDS (its reads issued right behind a barrier), the other half's butterflies and twiddles issue on the
-        // VALU, so no read is waited for with nothing to do (in lockstep — both halves reading between the same two
-        // barriers — the kernel's VALU-busy and LDS-busy fractions simply added up: 53 % + 46 %).  Same seven barriers per
-        // window.  Every barrier orders one half's writes before its reads AND retires the other half's reads (a wave
-        // waits for its own LDS reads before it signals), which frees that buffer for the next pass's writes.
-#pragma unroll
-        for (int j = 0; j < 16; j++) z0[j] = raw0[j] * (j == 0 ? we0a : (j == 15 ? we15a : half + hc0 * cj[j] + hs0 * sj[j]));
-        fft16(z0);
-#pragma unroll
-        for (int ka = 1; ka < 16; ka++) {
-            if (ka & 3) z0[R16(ka)] = pk_cmul(z0[R16(ka)], twg[ka & 3]);
-            if (ka & 12) z0[R16(ka)] = pk_cmul(z0[R16(ka)], twg[ka & 12]);
-        }
-        // (loop-end barrier of the previous window sits HERE: everything above touches no LDS, so a wave that has finished
-        // its share of the previous epilogue starts this window while the others are still reading the spectra)
-        if (w != w_begin) __syncthreads();
-#pragma unroll
-        for (int ka = 0; ka < 16; ka++) xbuf2[0][X1W(ka, tb, hi)] = z0[R16(ka)];
-        __syncthreads();                                        // B1: half 0, exchange 1 written
-#pragma unroll
-        for (int ta = 0; ta < 16; ta++) z0[ta] = xbuf2[0][X1W(hi, tb, ta)];
-#pragma unroll
-        for (int j = 0; j < 16; j++) z1[j] = raw1[j] * (j == 0 ? we0b : (j == 15 ? we15b : half + hc1 * cj[j] + hs1 * sj[j]));
-        fft16(z1);
-        xbuf2[1][X1W(0, tb, hi)] = z1[R16(0)];
-#pragma unroll
-        for (int ka = 1; ka < 16; ka++) {
-            v2f v = z1[R16(ka)];
-            if (ka & 3) v = pk_cmul(v, twg[ka & 3]);
-            if (ka & 12) v = pk_cmul(v, twg[ka & 12]);
-            xbuf2[1][X1W(ka, tb, hi)] = v;
-        }
-        if (more) ld4((size_t)(w + 1 - w_begin) * 1024u + n0 + 1024u * 15u, nx0, nx1);
-        __syncthreads();                                        // B2: half 1, exchange 1 written; half 0's reads retired
-#pragma unroll
-        for (int ta = 0; ta < 16; ta++) z1[ta] = xbuf2[1][X1W(hi, tb, ta)];
-        fft16(z0);
-        xbuf2[0][X2W(0, hi, tb)] = z0[R16(0)];
-#pragma unroll
-        for (int kb = 1; kb < 16; kb++) xbuf2[0][X2W(kb, hi, tb)] = pk_cmul(z0[R16(kb)], tw2s[tb * kb]);
-        __syncthreads();                                        // B3: half 0, exchange 2 written; half 1's reads retired
-#pragma unroll
-        for (int qq = 0; qq < 16; qq++) z0[qq] = xbuf2[0][X2W(hi, tb, qq)];
-        fft16(z1);
-        xbuf2[1][X2W(0, hi, tb)] = z1[R16(0)];
-#pragma unroll
-        for (int kb = 1; kb < 16; kb++) xbuf2[1][X2W(kb, hi, tb)] = pk_cmul(z1[R16(kb)], tw2s[tb * kb]);
-        __syncthreads();                                        // B4: half 1, exchange 2 written; half 0's reads retired
-#pragma unroll
-        for (int qq = 0; qq < 16; qq++) z1[qq] = xbuf2[1][X2W(hi, tb, qq)];
-        fft16(z0);
-#pragma unroll
-        for (int kc = 0; kc < 16; kc++) xbuf2[0][kc * 256 + tsw] = z0[R16(kc)];   // Z_q[k] at SPEC_POS(k)
-        __syncthreads();                                        // B5: half 1's reads retired (its buffer takes the publish next)
-        fft16(z1);
-#pragma unroll
-        for (int kc = 0; kc < 16; kc++) xbuf2[1][kc * 256 + tsw] = z1[R16(kc)];
-        __syncthreads();                                        // B6: both spectra published
-#else
         // the two halves are independent problems: every barrier phase carries both (half the barriers
         // per transform, two instruction streams to cover LDS latency)
 #pragma unroll
@@ -1303,13 +1235,45 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
             if (ka & 12) v = pk_cmul(v, twg[ka & 12]);
             xbuf2[1][X1W(ka, tb, hi)] = v;
         }
-#if SS_FFT16K_LATE_HOP
         if (more) ld4((size_t)(w + 1 - w_begin) * 1024u + n0 + 1024u * 15u, nx0, nx1);
-#endif
         __syncthreads();
 #pragma unroll
         for (int ta = 0; ta < 16; ta++) { z0[ta] = xbuf2[0][X1W(hi, tb, ta)]; z1[ta] = xbuf2[1][X1W(hi, tb, ta)]; }
         __syncthreads();
+#if SS_FFT_TW2K
+        // Second-pass twiddles W_256^(tb kb): ONE table read serves both halves, the table is laid out [kb][tb] (a lane's
+        // address is tb * 8 + an immediate) and the reads come in batches of four, the next batch requested before the current
+        // one is used.  (Read one at a time, once per half — what the straightforward loop compiles to at this register
+        // pressure — each of the thirty reads per window was waited for on the spot: thirty exposed LDS round trips.)
+        fft16(z0);
+        fft16(z1);
+        xbuf2[0][X2W(0, hi, tb)] = z0[R16(0)];
+        xbuf2[1][X2W(0, hi, tb)] = z1[R16(0)];
+        {
+            const v2f *twp = tw2s + tb;
+            v2f twa[4], twb[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) twa[j] = twp[16 * (1 + j)];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int kb0 = 1 + 4 * g, nk = g == 3 ? 3 : 4;
+                if (g < 3) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) if (kb0 + 4 + j < 16) twb[j] = twp[16 * (kb0 + 4 + j)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < nk; j++) {
+                    xbuf2[0][X2W(kb0 + j, hi, tb)] = pk_cmul(z0[R16(kb0 + j)], twa[j]);
+                    xbuf2[1][X2W(kb0 + j, hi, tb)] = pk_cmul(z1[R16(kb0 + j)], twa[j]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; j++) twa[j] = twb[j];
+            }
+        }
+        __syncthreads();
+#else
         fft16(z0);
         xbuf2[0][X2W(0, hi, tb)] = z0[R16(0)];
 #pragma unroll
@@ -1319,6 +1283,7 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
 #pragma unroll
         for (int kb = 1; kb < 16; kb++) xbuf2[1][X2W(kb, hi, tb)] = pk_cmul(z1[R16(kb)], tw2s[tb * kb]);
         __syncthreads();
+#endif
 #pragma unroll
         for (int qq = 0; qq < 16; qq++) { z0[qq] = xbuf2[0][X2W(hi, tb, qq)]; z1[qq] = xbuf2[1][X2W(hi, tb, qq)]; }
         __syncthreads();
@@ -1330,7 +1295,6 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
         for (int kc = 0; kc < 16; kc++) xbuf2[1][kc * 256 + tsw] = z1[R16(kc)];
         __syncthreads();
 
-#endif
 
         // ---- epilogue.  Iteration `it` covers 1024 retained bins, wave wv the 256 of them starting at
         // 1024 it + 256 wv.  Reading: lane l takes bins +l, +64+l, +128+l, +192+l, so every LDS read of the two
@@ -1339,9 +1303,6 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
         // that lane l stores bins +4l..+4l+3 with one 16-byte store.  From one iteration to the next the bin
         // index grows by 1024: positions move by +-1024 (SPEC_POS only looks at bits 1 and 6), twiddles turn by W_16^1.
         float *o = p.out + (((size_t)stream * p.n_windows + w) * fft_ch + ch) * p.bin_stride;
-#if defined(SS_ABL16) && SS_ABL16 == 1      /* ablation (timing only): no epilogue at all */
-        if (t == 0) o[0] = xbuf2[0][w & 4095u].x + xbuf2[1][w & 4095u].y;
-#else
         {
             const uint32_t lane = (uint32_t)t & 63u, wv = (uint32_t)t >> 6;
             float *stg = stage[wv];
@@ -1385,27 +1346,19 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
                 const float4 v = reinterpret_cast<const float4 *>(stg)[lane];
                 __builtin_amdgcn_wave_barrier();
                 const uint32_t g = 256u * it + 64u * wv + lane;        // group of four bins this lane stores
-#if defined(SS_ABL16) && SS_ABL16 == 2      /* ablation (timing only): no output stores */
-                asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-                (void)g; (void)o;
-#else
                 if (g < ngroups) {
                     float4 pk = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (p.pink) pk = *reinterpret_cast<const float4 *>(p.pink + 4u * g);
                     reinterpret_cast<float4 *>(o)[g] = make_float4(v.x + pk.x, v.y + pk.y, v.z + pk.z, v.w + pk.w);
                 }
-#endif
             }
         }
-#endif
         if (more) {
 #pragma unroll
             for (int j = 0; j < 15; j++) { raw0[j] = raw0[j + 1]; raw1[j] = raw1[j + 1]; }
             raw0[15] = nx0; raw1[15] = nx1;
         }
-#if !SS_FFT16K_SKEW
         __syncthreads();                    // epilogue reads are done before the next window's pass-1 writes
-#endif
     }
 #undef X1W
 #undef X2W
@@ -1456,13 +1409,9 @@ hipError_t launch_fft4096_ms(const FftBatchParams &p, hipStream_t s)
     const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
     dim3 grid(groups * p.n_streams), block(256);
     // hop 1024 (the reference's cadence): the single-window kernel at 3 workgroups per CU measured 2.5 %
-    // faster than the window-pair kernel at 2 (A/B in one process, 3.48 vs 3.57 ms); -DSS_FFT_PAIR selects the latter
-#if defined(SS_FFT_PAIR)
-    if (p.hop == 1024) hipLaunchKernelGGL(k_fft4096_ms<4>, grid, block, 0, s, p);
-#else
+    // faster than the window-pair kernel k_fft4096_ms<4> at 2 (A/B in one process, 3.48 vs 3.57 ms)
     if (p.hop == 1024 && p.out_cols) hipLaunchKernelGGL((k_fft4096_ms1<4, true, true>), grid, block, 0, s, p);
     else if (p.hop == 1024) hipLaunchKernelGGL((k_fft4096_ms1<4, true, false>), grid, block, 0, s, p);
-#endif
     else if (p.hop == 512) hipLaunchKernelGGL(k_fft4096_ms<2>, grid, block, 0, s, p);
     else if (p.hop == 2048) hipLaunchKernelGGL(k_fft4096_ms<8>, grid, block, 0, s, p);
     else hipLaunchKernelGGL(k_fft4096_ms_anyhop, grid, block, 0, s, p);

@@ -55,7 +55,6 @@ namespace ssk {
 // ============================================================================
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
-typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
 
 
 // Development build (-DSS_TD_PROF): per-phase shader-clock totals of k_time_domain, summed over all waves
@@ -107,20 +106,6 @@ __device__ __forceinline__ void state_undiff(double &v1, double &v2, double &v3,
     v2 = v1 - d12; v3 = v2 - d23; v4 = v3 - d34;
 }
 
-#ifndef SS_TP_F16
-#define SS_TP_F16 1
-#endif
-#ifndef SS_TD_LATE_PREFETCH
-#define SS_TD_LATE_PREFETCH 0     // 1: issue the next tile's loads behind the K-weighting passes (measured: no gain, -0.5 %)
-#endif
-#ifndef SS_TD_ROWSCAN
-#define SS_TD_ROWSCAN 1
-#endif
-#ifndef SS_TP_K32
-#define SS_TP_K32 0      // 1: v_mfma_f32_16x16x32_f16 for A_hi (B_hi + B_lo).  Measured no faster than three K = 16 products, and with
-                         // it the spectrum kernel running BESIDE this one (overlap mode) returned isolated wrong windows (tools/probe_overlap_race.py);
-                         // never with the K = 16 form.  Kept for the record, not compiled.
-#endif
 constexpr int kTdHaloFrames = 24;     // minimum halo: >= HIST-1 of the longest branch (multiple of 4: the tile stays 16-B aligned)
 constexpr int kTdTailFrames = 16;     // zeroed slack past the tile end: K-weighting look-ahead and the last f32 MFMA window
 // floats of slack behind a wave's tile: the zeroed frames above, or — larger — room for the planar f16 true-peak layout
@@ -212,14 +197,6 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
     if (gw >= p.n_streams * p.nseg) return;                                // whole wave leaves (no barriers used)
     const uint32_t stream = gw / p.nseg, sg = gw - stream * p.nseg;
 
-#ifdef SS_TD_SKEW
-    // Waves of a SIMD run tiles of equal length in step, so their matrix-pipe phases (true peak) coincide and nothing
-    // overlaps them.  Delay each wave by its slot in the SIMD times a fraction of a tile.
-    if (p.nseg > 1) {
-        const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3u;      // HW_ID.wave_id
-        for (uint32_t i = 0; i < slot * SS_TD_SKEW; i++) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     float *tilebuf = reinterpret_cast<float *>(smem) + (size_t)wave_in_block * wave_lds_floats;
     const TdConst &K = *p.k;
     const uint32_t C = CT ? (uint32_t)CT : p.channels;
@@ -231,7 +208,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
     // cross rows (ds_bpermute: 22 cycles of the LDS crossbar each, and a dependent latency per step).  The walk through the
     // interleaved tile is bank-conflict free for odd L ((r + 4 q) L C + c covers 64 distinct banks) and 2-way conflicted for
     // L = 30, which td_chunk_frames still prefers where it cuts the sub-block into whole tiles of whole chunks.
-    constexpr bool kRowScan = (CT != 0) && (16 % (CT ? CT : 1) == 0) && (SS_TD_ROWSCAN != 0);
+    constexpr bool kRowScan = (CT != 0) && (16 % (CT ? CT : 1) == 0);
     const uint32_t lane_q = (lane & 15u) / C;           // position of this lane's chunk inside its row
     const uint32_t chunk = kRowScan ? (lane >> 4) + 4u * lane_q : lane / C;
     const uint32_t ch = kRowScan ? (lane & 15u) - lane_q * C : lane - chunk * C;
@@ -323,28 +300,24 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
     // [k FB - 12, (k + 1) FB - 12).  A block occupies exactly the bytes of FB source frames, so the conversion walks
     // the blocks from the top down and never overwrites a sample it still has to read.
     // Column (channel, block of 4 outputs b) then reads its 16-sample window [4 b - 12, 4 b + 4) as aligned 8-byte
-    // pieces, and D = A_hi (B_hi + B_lo) + A_lo B_hi runs as
-    //   v_mfma_f32_16x16x32_f16  A = [a_hi | a_hi], B = [x_hi ; x_lo]     (K = 32 at the issue cost of K = 16)
-    //   v_mfma_f32_16x16x16_f16  A = a_lo,          B = x_hi
-    // with rows (phase f, output r), A[(f,r)][k] = c_f[12 + r - k]; the dropped lo*lo term and the split
-    // remainders are < 2^-21 of the tile's peak.  One group of 16 columns advances every window by exactly one block,
-    // so the three read addresses of a lane just step by 256 bytes per group.  Unlike the f32 MFMA this runs beside
+    // pieces of the hi and the lo plane, and D = A_hi B_hi + A_hi B_lo + A_lo B_hi runs as three
+    // v_mfma_f32_16x16x16_f16 with rows (phase f, output r), A[(f,r)][k] = c_f[12 + r - k]; the dropped lo*lo term and
+    // the split remainders are < 2^-21 of the tile's peak.  One group of 16 columns advances every window by exactly one
+    // block, so the read addresses of a lane just step by 256 bytes per group.  Unlike the f32 MFMA this runs beside
     // other waves' f64 VALU work (tools/ubench4.hip), and the per-window split that used to cost 18 VALU
     // lane-instructions per sample is about 4.
-    constexpr bool kTpPlanar = (FACTOR == 4) && (SS_TP_F16 != 0);
-    // MFMA 1 (v_mfma_f32_16x16x32_f16, K = 32 at the issue cost of K = 16): A = [a_hi | a_hi], B = [x_hi ; x_lo]
-    // MFMA 2 (v_mfma_f32_16x16x16_f16):                                     A = a_lo,          B = x_hi
-    halfx8 a32 = {0, 0, 0, 0, 0, 0, 0, 0};              // lane (mrow, kq): a_hi[8 (kq & 1) + j], j = 0..7
+    // (gfx950's K = 32 form, v_mfma_f32_16x16x32_f16 — two products instead of three — is NOT used: a wave issuing it
+    // corrupts v_pk_add_f32 results of OTHER waves on the same SIMD, i.e. of the spectrum kernel when the two kernels
+    // share the chip; isolated by tools/ubench_k32_interference.hip, profiles/r03_ubench_k32_interference.txt)
+    constexpr bool kTpPlanar = (FACTOR == 4);
     halfx4 a16_lo = {0, 0, 0, 0};                       // lane (mrow, kq): a_lo[4 kq + j], j = 0..3
-    halfx4 a16_hi = {0, 0, 0, 0};                       // (SS_TP_K32 == 0: three K = 16 products instead)
+    halfx4 a16_hi = {0, 0, 0, 0};                       //                  a_hi[4 kq + j]
     if (kTpPlanar) {
         const int fph = mrow >> 2, r = mrow & 3;       // rows 0..11 = (phase, output); rows 12..15 are zero
         auto tap = [&](int k) -> float {               // A[(f, r)][k] = c_f[12 + r - k]
             const int t = 12 + r - k;
             return (mrow < 12 && t >= 0 && t < 12) ? K.tp[fph][t] : 0.0f;
         };
-#pragma unroll
-        for (int j = 0; j < 8; j++) a32[j] = (_Float16)tap(8 * (kq & 1) + j);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const float c = tap(4 * kq + j);
@@ -441,9 +414,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
         if (sub_done || ntoff >= tile_len) ntoff = 0;
         uint32_t nseg_frames;
         SS_TILE_FRAMES(npos, noff, ntoff, nseg_frames);
-#if !SS_TD_LATE_PREFETCH
         SS_PREFETCH(npos, nseg_frames);
-#endif
         __builtin_amdgcn_wave_barrier();               // LDS is in-order per wave: only ordering is needed
         SS_PROF_MARK(0);
 
@@ -603,10 +574,6 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
         }
         SS_PROF_MARK(2);
         // ---- in-wave scan over chunks: z_i += (A^L)^(2^k) z_{i - 2^k}  (the steps commute: powers of one matrix)
-#ifndef SS_ABL_SCAN_FROM
-#define SS_ABL_SCAN_FROM 0
-#define SS_ABL_SCAN_TO 32
-#endif
         if (kRowScan) {
             // distances 1 and 2: the source chunk sits in another row
 #pragma unroll
@@ -634,7 +601,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
 #undef SS_ROW_STEP
 #undef SS_DPP_SHR64
         } else {
-            for (int kstep = SS_ABL_SCAN_FROM; kstep < SS_ABL_SCAN_TO && (1u << kstep) < nchunks; kstep++) {
+            for (int kstep = 0; (1u << kstep) < nchunks; kstep++) {
                 const uint32_t d = (1u << kstep) * C;
                 const double xin[4] = {__shfl_up(z[0], d, 64), __shfl_up(z[1], d, 64), __shfl_up(z[2], d, 64), __shfl_up(z[3], d, 64)};
                 if (active && lane >= d) mat4_apply_add(mpow + 16 * kstep, xin, z);
@@ -696,12 +663,6 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
             }
             if (!warm) { e_run += e; sp_run = fmaxf(sp_run, sp); }
         }
-#if SS_TD_LATE_PREFETCH
-        // The next tile's loads are issued here, behind the K-weighting passes: the 32 registers they land in are then
-        // not live through the passes (the kernel's register peak), and the true-peak phase that follows (microseconds)
-        // still covers their latency.
-        SS_PREFETCH(npos, nseg_frames);
-#endif
         SS_PROF_MARK(4);
         // ---- true peak on the matrix pipe (not during the run-in)
         bool halo_done = false;
@@ -763,9 +724,6 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
                 }
                 const uint32_t f0 = nplanar * tp_bpg * 4;                  // frames covered by the planar path
                 if (f0 < seg) tp_f32_range(f0, seg - f0);
-#if defined(SS_ABL_TP) && SS_ABL_TP == 2
-                nplanar = 0;
-#endif
                 if (nplanar) {
                     const float scale = __uint_as_float(scale_bits);
                     const uint32_t ps = f0 + 12;                           // converted frames: [-12, f0), even
@@ -846,9 +804,8 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
                         if (nround > 1 || top_ok) { wbase[0] = hh; wbase[32] = ll; }
                         __builtin_amdgcn_wave_barrier();
                     }
-                    // (4) column (channel tp_c, block of outputs b = 16/C g + mrow / C) reads its window [4 b, 4 b + 16) of
-                    // converted frames as three aligned 4-half pieces: for the K = 32 product halves 8 (kq & 1) .. + 8 of the hi
-                    // (kq < 2) or lo (kq >= 2) plane, for the K = 16 product halves 4 kq .. + 4 of the hi plane.
+                    // (4) column (channel tp_c, block of outputs b = 16/C g + mrow / C) reads halves 4 kq .. + 4 of its window
+                    // [4 b, 4 b + 16) of converted frames from the hi plane and from the lo plane (aligned 8-byte pieces)
                     const char *tb = reinterpret_cast<const char *>(tile);
                     auto plane_addr = [&](uint32_t j, uint32_t lo) -> const char * {
                         return tb + ((j >> lb) << 8) + (lo << 7) + ((tp_c * FB + (j & (FB - 1u))) << 1);
@@ -857,50 +814,6 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
                     auto ld4 = [](const char *q, int off) -> halfx4 { return __builtin_bit_cast(halfx4, *reinterpret_cast<const uint2 *>(q + off)); };
                     SS_PROF_MARK(5);
                     float m16 = 0.0f;
-#if SS_TP_K32
-                    const uint32_t j32 = jb + 8u * ((uint32_t)kq & 1u);
-                    const char *p32a = plane_addr(j32, (uint32_t)kq >> 1), *p32b = plane_addr(j32 + 4u, (uint32_t)kq >> 1);
-                    const char *p16 = plane_addr(jb + 4u * (uint32_t)kq, 0);
-                    auto ld8 = [](const char *qa, const char *qb, int off) -> halfx8 {
-                        const uint2 a = *reinterpret_cast<const uint2 *>(qa + off), b = *reinterpret_cast<const uint2 *>(qb + off);
-                        const uint4 v = make_uint4(a.x, a.y, b.x, b.y);
-                        return __builtin_bit_cast(halfx8, v);
-                    };
-                    const uint32_t npair = nplanar >> 1;
-#endif
-#if defined(SS_ABL_TP) && SS_ABL_TP == 1
-                    if (false)
-#endif
-#if SS_TP_K32
-                    if (npair) {
-                        halfx8 bA = ld8(p32a, p32b, 0), bB = ld8(p32a, p32b, 256);
-                        halfx4 cA = ld4(p16, 0), cB = ld4(p16, 256);
-                        for (uint32_t it = 0; it < npair; it++) {
-                            // next pair's operands first (the last iteration re-reads its own: nothing is read past the planes)
-                            const uint32_t adv = (it + 1 < npair) ? 512u : 0u;
-                            p32a += adv; p32b += adv; p16 += adv;
-                            const halfx8 nA = ld8(p32a, p32b, 0), nB = ld8(p32a, p32b, 256);
-                            const halfx4 ncA = ld4(p16, 0), ncB = ld4(p16, 256);
-                            floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32, bA, acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32, bB, acc1, 0, 0, 0);
-                            acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_lo, cA, acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_lo, cB, acc1, 0, 0, 0);
-                            m16 = fmaxf(fmaxf(m16, fmaxf(fabsf(acc0[0]), fabsf(acc0[1]))), fmaxf(fabsf(acc0[2]), fabsf(acc0[3])));
-                            m16 = fmaxf(fmaxf(m16, fmaxf(fabsf(acc1[0]), fabsf(acc1[1]))), fmaxf(fabsf(acc1[2]), fabsf(acc1[3])));
-                            bA = nA; bB = nB; cA = ncA; cB = ncB;
-                        }
-                        p32a += 512; p32b += 512; p16 += 512;
-                    }
-                    if (nplanar & 1u) {                                    // the odd last group
-                        const halfx8 bA = ld8(p32a, p32b, 0);
-                        const halfx4 cA = ld4(p16, 0);
-                        floatx4 acc0 = {0.f, 0.f, 0.f, 0.f};
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32, bA, acc0, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_lo, cA, acc0, 0, 0, 0);
-                        m16 = fmaxf(fmaxf(m16, fmaxf(fabsf(acc0[0]), fabsf(acc0[1]))), fmaxf(fabsf(acc0[2]), fabsf(acc0[3])));
-                    }
-#else
                     {
                         // three K = 16 products per group (hi and lo planes at halves 4 kq .. + 4), four groups per iteration:
                         // four independent accumulator chains, and the next iteration's operands are read before this one's MFMAs
@@ -909,9 +822,6 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
                             return fmaxf(fmaxf(fmaxf(m, fabsf(a[0])), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3])));
                         };
                         const uint32_t nquad = nplanar >> 2;
-#if defined(SS_ABL_TP) && SS_ABL_TP == 1
-                        if (false)
-#endif
                         if (nquad) {
                             halfx4 h[4], l[4];
 #pragma unroll
@@ -959,7 +869,6 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
                             m16 = absmax4(m16, acc0);
                         }
                     }
-#endif
                     tp_run = fmaxf(tp_run, m16 * __uint_as_float(inv_bits));
                 }
             } else {
@@ -1151,16 +1060,13 @@ uint32_t td_chunk_frames(uint32_t C, uint32_t s100)
     return best;
 }
 
-#ifndef SS_TD_FULL_TILES
-#define SS_TD_FULL_TILES 0      // 1: tiles of the full scan width and a short last one per sub-block instead of equal pieces (experiment)
-#endif
 // waves of k_time_domain one CU holds at once (LDS per wave grows with the channel count and the decimation halo)
 uint32_t td_resident_waves_per_cu(uint32_t C, uint32_t s100, uint32_t halo_frames)
 {
     const uint32_t L = td_chunk_frames(C, s100);
     const uint32_t cap = (64u / C) * L;
     const uint32_t pieces = (s100 + cap - 1) / cap;
-    uint32_t tile_len = SS_TD_FULL_TILES ? cap : (s100 + pieces - 1) / pieces;
+    uint32_t tile_len = (s100 + pieces - 1) / pieces;
     if (tile_len > cap) tile_len = cap;
     const uint32_t halo = halo_frames ? halo_frames : (uint32_t)kTdHaloFrames;
     uint32_t wave_floats = (halo + tile_len) * C + td_slack_floats(C) + kMaxChannels;
@@ -1182,7 +1088,7 @@ static hipError_t td_launch(const TdParams &p, hipStream_t s)
     const uint32_t nch = 64u / C;
     const uint32_t cap = nch * L;                                   // frames one wave can scan at once
     const uint32_t pieces = (S + cap - 1) / cap;                    // equal tiles per sub-block
-    uint32_t tile_len = SS_TD_FULL_TILES ? cap : (S + pieces - 1) / pieces;
+    uint32_t tile_len = (S + pieces - 1) / pieces;
     if (tile_len > cap) tile_len = cap;
     // per-wave LDS: halo + tile + slack + 64 peak slots
     const uint32_t halo = WAVE ? p.halo_frames : (uint32_t)kTdHaloFrames;
@@ -1214,7 +1120,7 @@ static int td_wave_int4(const TdParams &p)
     const uint32_t L = td_chunk_frames(C, S);
     const uint32_t cap = (64u / C) * L;
     const uint32_t pieces = (S + cap - 1) / cap;
-    uint32_t tile_len = SS_TD_FULL_TILES ? cap : (S + pieces - 1) / pieces;
+    uint32_t tile_len = (S + pieces - 1) / pieces;
     if (tile_len > cap) tile_len = cap;
     if (!(((uint64_t)S * C) % 4u == 0 && ((uint64_t)tile_len * C) % 4u == 0 && (p.halo_frames * C) % 4u == 0)) return 0;
     return spp <= 128 ? 2 : 3;

@@ -159,3 +159,36 @@ def test_dual_mono_empty_row_reads_the_floor(oracle, n, which):
         assert np.allclose(got[w, empty], ref[w, empty], rtol=0.0, atol=2e-4), (n, which, w, float(got[w, empty].max()))
         assert db_close(got[w, 1 - empty], ref[w, 1 - empty]), (n, which, w)
     b.close()
+
+
+@pytest.mark.parametrize("channels", [1, 6])
+def test_digital_silence_in_front_of_a_programme_pair_kernel(oracle, channels):
+    """k_fft4096_pairw rides TWO consecutive windows of one channel on one complex transform.  Digital silence followed by a
+    programme: the last all-zero window shares its transform with the first window that touches the programme, and must
+    still read the reference's floor (-150 dB + pink) in every bin, not the partner's rounding noise."""
+    rate, n = 48000, 4096
+    frames = 21504 + 1024 * 30 + 100
+    rng = np.random.default_rng(4)
+    x = np.zeros((frames, channels), np.float32)
+    for c in range(channels):
+        start = 21504 - 1024 * (c % 2)                     # odd channels: the boundary falls between the windows of a pair
+        t = np.arange(frames - start) / rate
+        x[start:, c] = (0.3 * np.sin(2 * np.pi * (300.0 + 170.0 * c) * t) + 0.03 * rng.uniform(-1, 1, frames - start)).astype(np.float32)
+    b = ssa.Batch(rate, channels, 1, frames, n, 1024, flags=L.SS_BATCH_FFT)
+    b.upload(0, x.reshape(-1)); b.run(); b.sync()
+    got = b.fft(0)
+    _, _, pink = b.bin_tables()
+    n_floor = 0
+    for w in range(got.shape[0]):
+        p = (w + n // 1024 + 1) * 1024
+        for c in range(channels):
+            seg = np.ascontiguousarray(x[p - n:p, c])
+            ref = oracle.get_fft(rate, seg)[:, 1]
+            if not seg.any():
+                assert np.allclose(ref, -150.0 + pink, atol=1e-4)
+                assert np.allclose(got[w, c], ref, rtol=0.0, atol=2e-4), (channels, w, c, float(got[w, c].max()))
+                n_floor += 1
+            else:
+                assert db_close(got[w, c], ref), (channels, w, c, db_report(got[w, c], ref))
+    assert n_floor >= 16 * channels
+    b.close()

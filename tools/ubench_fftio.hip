@@ -17,10 +17,26 @@ __global__ __launch_bounds__(256) void k_flat(float4 *__restrict__ out, size_t n
     }
 }
 
-template <int MODE, int STRIDE = 1708>   // 1 loads, 2 stores, 3 both
+// flat copy-shaped kernel: the same byte counts as the spectrum kernel (3.89 GB read, 6.49 GB written), fully contiguous, full
+// occupancy, no LDS: what the memory system gives a MIXED read/write stream of this ratio whatever the access pattern
+__global__ __launch_bounds__(256) void k_flat_mixed(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n_in4, size_t n_out4)
+{
+    float acc = 0.f;
+    const size_t step = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, j = i;
+    // five stores per three loads (6.49 : 3.89)
+    for (; j < n_out4; ) {
+        for (int q = 0; q < 3 && i < n_in4; q++, i += step) { const float4 v = in[i]; acc += v.x + v.y + v.z + v.w; }
+        for (int q = 0; q < 5 && j < n_out4; q++, j += step) out[j] = make_float4(acc, 1.f, 2.f, 3.f);
+    }
+}
+
+// LDSPAD = false: the same per-workgroup row pattern at FULL occupancy (no LDS footprint): separates the pattern from the
+// three-workgroups-per-CU occupancy the real kernel runs at
+template <int MODE, int STRIDE = 1708, bool LDSPAD = true>   // 1 loads, 2 stores, 3 both
 __global__ __launch_bounds__(256, 3) void k_io(const float2 *__restrict__ in, float *__restrict__ out, int nwin, size_t frames_per_stream, int groups)
 {
-    __shared__ float lds[9728];            // the real kernel's 38.9 KB: same occupancy (3 workgroups per CU)
+    __shared__ float lds[LDSPAD ? 9728 : 256];            // the real kernel's 38.9 KB: same occupancy (3 workgroups per CU)
     const int t = threadIdx.x;
     const uint32_t stream = blockIdx.x / groups, grp = blockIdx.x % groups;
     const float2 *src = in + (size_t)stream * frames_per_stream + 1024 + (size_t)grp * nwin * 1024;
@@ -82,6 +98,33 @@ int main()
             if (ms < best) best = ms;
         }
         printf("%-12s %.3f ms  %.2f GB -> %.2f TB/s (rows padded to 1728 floats, same useful bytes)\n", "stores/align", best, out_gb, out_gb / best);
+    }
+    // the row pattern at full occupancy (no LDS footprint)
+    for (int mode = 2; mode <= 3; mode++) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 5; rep++) {
+            hipEventRecord(e0);
+            if (mode == 2) hipLaunchKernelGGL((k_io<2, 1708, false>), dim3(streams * groups), dim3(256), 0, 0, in, out, nwin, frames, groups);
+            else hipLaunchKernelGGL((k_io<3, 1708, false>), dim3(streams * groups), dim3(256), 0, 0, in, out, nwin, frames, groups);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best) best = ms;
+        }
+        const double gb = (mode & 1 ? in_gb : 0) + out_gb;
+        printf("%-12s %.3f ms  %.2f GB -> %.2f TB/s (row pattern, no LDS footprint: full occupancy)\n", mode == 2 ? "stores/occ" : "both/occ", best, gb, gb / best);
+    }
+    // a flat, contiguous MIXED stream of the same read and write byte counts at full occupancy
+    {
+        const size_t n_in4 = (size_t)(in_gb * 1e9 / 16), n_out4 = (size_t)(out_gb * 1e9 / 16);
+        float best = 1e9f;
+        for (int rep = 0; rep < 5; rep++) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(k_flat_mixed, dim3(256 * 16), dim3(256), 0, 0, reinterpret_cast<const float4 *>(in), reinterpret_cast<float4 *>(out), n_in4, n_out4);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best) best = ms;
+        }
+        printf("%-12s %.3f ms  %.2f GB -> %.2f TB/s (flat contiguous loads + stores, same byte counts, full occupancy)\n", "flat mixed", best, in_gb + out_gb, (in_gb + out_gb) / best);
     }
     // flat contiguous stores of the same byte count
     for (int nt = 0; nt < 2; nt++) {
