@@ -208,19 +208,29 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
             // (reloaded at the top of every epilogue).  There the second group's index is opaque per window instead: its
             // eight addresses are recomputed (a few integer instructions each) and nothing is spilled.
             if (COLS && i == 1) asm volatile("" : "+v"(k0));
-            float qm[4], qs[4];
+            // every LDS read of the group is requested before the first value is used (the transform's 32 registers are dead
+            // here): left to itself the compiler reads a pair of values, waits, computes, reads the next — one exposed LDS round
+            // trip per bin
+            v2f zk[4], zm[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const uint32_t k = k0 + e;                       // k <= 2051 < 4096: the mirror index stays positive
-                const v2f zk = xb[SPEC_POS(k)];
-                const v2f zm = xb[SPEC_POS(4096 - k)];           // Z[N - k]
+                zk[e] = xb[SPEC_POS(k)];
+                zm[e] = xb[SPEC_POS(4096 - k)];                  // Z[N - k]
+            }
+            if (LDS_TABLE) op[i] = reinterpret_cast<const float4 *>(offpink)[g];
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            float qm[4], qs[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
                 v2f m2, s2;                                      // 2*M = (zk.x+zm.x, zk.y-zm.y); 2*S ~ (zk.y+zm.y, zk.x-zm.x)
-                asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,0] neg_hi:[0,1]" : "=v"(m2) : "v"(zk), "v"(zm));
-                asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(s2) : "v"(zk), "v"(zm));
+                asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,0] neg_hi:[0,1]" : "=v"(m2) : "v"(zk[e]), "v"(zm[e]));
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(s2) : "v"(zk[e]), "v"(zm[e]));
                 qm[e] = fmaf(m2.x, m2.x, m2.y * m2.y);
                 qs[e] = fmaf(s2.x, s2.x, s2.y * s2.y);
             }
-            if (LDS_TABLE) op[i] = reinterpret_cast<const float4 *>(offpink)[g];
             const float opv[4] = {op[i].x, op[i].y, op[i].z, op[i].w};
             const float qmin = fminf(fminf(fminf(qm[0], qm[1]), fminf(qm[2], qm[3])), fminf(fminf(qs[0], qs[1]), fminf(qs[2], qs[3])));
             if (__builtin_expect(__ballot(qmin == 0.0f) == 0ull, 1)) {
@@ -1195,6 +1205,14 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
     const uint32_t ngroups = (p.n_bins + 3) >> 2;
     constexpr float kDb = 3.01029995663981195f;
     const float off2 = p.db_offset - 6.02059991327962390f;      // the epilogue carries 2 X
+    // Everything loaded above is "used" once here, in front of the window loop.  A register whose load is still pending at
+    // the loop's entry gets its s_waitcnt at its first use INSIDE the loop, and vmcnt counts stores too: in every later
+    // iteration that wait — vmcnt(0) in the middle of the first radix pass — stood there for the PREVIOUS window's output
+    // stores to reach memory.
+    asm volatile("" : "+v"(twg[1]), "+v"(twg[2]), "+v"(twg[3]), "+v"(twg[4]), "+v"(twg[8]), "+v"(twg[12]));
+    asm volatile("" ::"v"(we0a), "v"(we0b), "v"(we15a), "v"(we15b));
+#pragma unroll
+    for (int j = 0; j < 16; j++) asm volatile("" : "+v"(raw0[j]), "+v"(raw1[j]));
     __syncthreads();
 
     for (uint32_t w = w_begin; w < w_end; ++w) {
@@ -1293,8 +1311,20 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
         fft16(z1);
 #pragma unroll
         for (int kc = 0; kc < 16; kc++) xbuf2[1][kc * 256 + tsw] = z1[R16(kc)];
+        // the epilogue's four twiddles are requested here, in front of the barrier that closes the publish (the transforms'
+        // registers have just died): the loads fly while the workgroup gathers
+        const uint32_t lane = (uint32_t)t & 63u, wv = (uint32_t)t >> 6;
+        v2f wt[4];
+        {
+            uint32_t fbq = p.first_bin;
+            asm volatile("" : "+s"(fbq));
+#pragma unroll
+            for (int e = 0; e < 4; e++) wt[e] = tw16k[(fbq + 256u * wv + 64u * e + lane) & 8191u];
+        }
         __syncthreads();
-
+        // the prefetched hop is claimed HERE, in front of the epilogue's stores: claimed at the slide behind them, its wait
+        // (loads and stores share vmcnt, in order) would also stand for every store of this window
+        asm volatile("" : "+v"(nx0), "+v"(nx1));
 
         // ---- epilogue.  Iteration `it` covers 1024 retained bins, wave wv the 256 of them starting at
         // 1024 it + 256 wv.  Reading: lane l takes bins +l, +64+l, +128+l, +192+l, so every LDS read of the two
@@ -1304,10 +1334,8 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
         // index grows by 1024: positions move by +-1024 (SPEC_POS only looks at bits 1 and 6), twiddles turn by W_16^1.
         float *o = p.out + (((size_t)stream * p.n_windows + w) * fft_ch + ch) * p.bin_stride;
         {
-            const uint32_t lane = (uint32_t)t & 63u, wv = (uint32_t)t >> 6;
             float *stg = stage[wv];
             uint32_t pb[4], pm[4];
-            v2f wt[4];
             uint32_t fb = p.first_bin;
             asm volatile("" : "+s"(fb));        // per-window recomputation: hoisting these 16 registers out of the loop spills
 #pragma unroll
@@ -1315,16 +1343,31 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
                 const uint32_t b = fb + 256u * wv + 64u * e + lane;
                 const uint32_t bq = b & 4095u, mq = (4096u - bq) & 4095u;
                 pb[e] = SPEC_POS(bq); pm[e] = SPEC_POS(mq);
-                wt[e] = tw16k[b & 8191u];
             }
             const v2f rho = {0.92387953251128674f, -0.38268343236508977f};
             const uint32_t n_iter = (4u * ngroups + 1023u) >> 10;
+            // the four twiddles are "used" here, in front of the loop: otherwise the wait for their loads lands INSIDE the loop
+            // (its first multiply) as s_waitcnt vmcnt(0), where from the second iteration on it waits for the pink row instead
+            asm volatile("" : "+v"(wt[0]), "+v"(wt[1]), "+v"(wt[2]), "+v"(wt[3]));
             for (uint32_t it = 0; it < n_iter; it++) {
+                // The iteration's loads first: the pink row of the group this lane will store (a global load: waited for right
+                // where it was issued — behind the arithmetic, in front of the store — it cost a full L2 round trip per
+                // iteration), then all sixteen spectrum values of the lane's four bins (read a bin at a time they cost four
+                // exposed LDS round trips per iteration; the transforms' 64 registers are dead here).
+                const uint32_t g = 256u * it + 64u * wv + lane;        // group of four bins this lane stores
+                float4 pk = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.pink) pk = *reinterpret_cast<const float4 *>(p.pink + 4u * (g < ngroups ? g : ngroups - 1u));   // (clamped, not predicated: no exec-mask branch around the load)
+                v2f e0v[4], emv[4], o0v[4], omv[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    e0v[e] = xbuf2[0][pb[e]]; emv[e] = xbuf2[0][pm[e]];
+                    o0v[e] = xbuf2[1][pb[e]]; omv[e] = xbuf2[1][pm[e]];
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 float r[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const v2f e0 = xbuf2[0][pb[e]], em = xbuf2[0][pm[e]];
-                    const v2f o0 = xbuf2[1][pb[e]], om = xbuf2[1][pm[e]];
+                    const v2f e0 = e0v[e], em = emv[e], o0 = o0v[e], om = omv[e];
                     v2f a0, a1, a2, a3;        // 2 A_r[b]
                     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,0] neg_hi:[0,1]" : "=v"(a0) : "v"(e0), "v"(em));
                     asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[1,0]" : "=v"(a1) : "v"(e0), "v"(em));
@@ -1345,12 +1388,7 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
                 __builtin_amdgcn_wave_barrier();                      // LDS is in order per wave: ordering is all that is needed
                 const float4 v = reinterpret_cast<const float4 *>(stg)[lane];
                 __builtin_amdgcn_wave_barrier();
-                const uint32_t g = 256u * it + 64u * wv + lane;        // group of four bins this lane stores
-                if (g < ngroups) {
-                    float4 pk = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (p.pink) pk = *reinterpret_cast<const float4 *>(p.pink + 4u * g);
-                    reinterpret_cast<float4 *>(o)[g] = make_float4(v.x + pk.x, v.y + pk.y, v.z + pk.z, v.w + pk.w);
-                }
+                if (g < ngroups) reinterpret_cast<float4 *>(o)[g] = make_float4(v.x + pk.x, v.y + pk.y, v.z + pk.z, v.w + pk.w);
             }
         }
         if (more) {

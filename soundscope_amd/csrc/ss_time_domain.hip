@@ -538,12 +538,9 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
         const uint32_t len = active ? ((seg - chunk * L) < L ? (seg - chunk * L) : L) : 0u;
         const float *xs = tile + (size_t)chunk * L * C + ch;
         const uint32_t nb_full = L / kTdBatch;          // whole batches in a full chunk
-        // sample i of this lane's (chunk, channel).  (Stereo reading whole frames as ds_read_b64 + select — mod-64 banks, two
-        // deep instead of four — was measured: 1.99 -> 2.13 ms, profiles/r03_ab_ms1_td_variants.txt; the select and the
-        // unmergeable reads cost more than the conflicts.)
-        auto ldx = [&](uint32_t i) -> float {
-            return xs[i * C];
-        };
+        // (Stereo reading whole frames as ds_read_b64 + select in the two passes below — mod-64 banks, two deep instead of the
+        // four of ds_read_b32's mod-32 banks at this chunk stride — was measured: 1.99 -> 2.13 ms,
+        // profiles/r03_ab_ms1_td_variants.txt; the select and the unmergeable reads cost more than the conflicts.)
 
         // ---- pass 1: zero-state response of the state recurrence
         double z[4] = {0.0, 0.0, 0.0, 0.0};
@@ -551,19 +548,19 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
             double v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0;
             uint32_t i = 0;
             if (len == L) {                             // full chunk: batched, predicate-free, look-ahead form
-                uint32_t xi = 3;                        // the batch loop consumes x[i + 3]
-                SS_KW_LA_INIT((double)ldx(0), (double)ldx(1), (double)ldx(2))
-                for (uint32_t bq = 0; bq < nb_full; bq++, xi += kTdBatch) {
+                const float *xp = xs + 3 * C;           // the batch loop consumes x[i + 3]
+                SS_KW_LA_INIT((double)xs[0], (double)xs[C], (double)xs[2 * C])
+                for (uint32_t bq = 0; bq < nb_full; bq++, xp += kTdBatch * C) {
                     float xb[kTdBatch];
 #pragma unroll
-                    for (int u = 0; u < kTdBatch; u++) xb[u] = ldx(xi + u);   // reaches <= 3 frames past the chunk (slack)
+                    for (int u = 0; u < kTdBatch; u++) xb[u] = xp[u * (int)C];   // reaches <= 3 frames past the chunk (slack)
 #pragma unroll
                     for (int u = 0; u < kTdBatch; u++) { SS_KW_LA_STEP((double)xb[u]) SS_KW_SHIFT() }
                 }
                 i = nb_full * kTdBatch;
-                for (; i < len; i++) { SS_KW_LA_STEP((double)ldx(i + 3)) SS_KW_SHIFT() }
+                for (; i < len; i++) { SS_KW_LA_STEP((double)xs[(i + 3) * C]) SS_KW_SHIFT() }
             }
-            for (; i < len; i++) { SS_KW_STATE((double)ldx(i)) SS_KW_SHIFT() }
+            for (; i < len; i++) { SS_KW_STATE((double)xs[i * C]) SS_KW_SHIFT() }
             z[0] = v1; z[1] = v2; z[2] = v3; z[3] = v4;
             state_diff(z);                              // the scan runs in difference coordinates
             if (active && chunk == 0) {
@@ -628,15 +625,15 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
             if (len == L) {
                 // sample peak over x[0 .. L+2]: the three look-ahead samples are the next chunk's (or the
                 // zeroed slack behind the tile), so including them cannot change the channel's maximum
-                uint32_t xi = 3;
-                const float xa = ldx(0), xb1 = ldx(1), xc = ldx(2);
+                const float *xp = xs + 3 * C;
+                const float xa = xs[0], xb1 = xs[C], xc = xs[2 * C];
                 sp = fmaxf(fmaxf(fabsf(xa), fabsf(xb1)), fabsf(xc));
                 SS_KW_LA_INIT((double)xa, (double)xb1, (double)xc)
                 SS_KW_LA_OUT_INIT()
-                for (uint32_t bq = 0; bq < nb_full; bq++, xi += kTdBatch) {
+                for (uint32_t bq = 0; bq < nb_full; bq++, xp += kTdBatch * C) {
                     float xb[kTdBatch];
 #pragma unroll
-                    for (int u = 0; u < kTdBatch; u++) xb[u] = ldx(xi + u);
+                    for (int u = 0; u < kTdBatch; u++) xb[u] = xp[u * (int)C];
 #pragma unroll
                     for (int u = 0; u < kTdBatch; u++) {
                         sp = fmaxf(sp, fabsf(xb[u]));
@@ -647,7 +644,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
                 }
                 i = nb_full * kTdBatch;
                 for (; i < len; i++) {
-                    const float xn = ldx(i + 3);
+                    const float xn = xs[(i + 3) * C];
                     sp = fmaxf(sp, fabsf(xn));
                     SS_KW_LA_STEP((double)xn) SS_KW_LA_OUT() SS_KW_SHIFT()
                     e = fma(y_, y_, e);
@@ -655,7 +652,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
                 }
             }
             for (; i < len; i++) {
-                const float xf = ldx(i);
+                const float xf = xs[i * C];
                 sp = fmaxf(sp, fabsf(xf));
                 SS_KW_STATE((double)xf) SS_KW_OUT() SS_KW_SHIFT()
                 e = fma(y_, y_, e);
