@@ -179,6 +179,12 @@ def time_config(ssa, L, rate, channels, streams, frames, fft_n, hop, tp_factor, 
         res["spectrum_kernel"] = {"algorithmic_bytes": alg, "hbm_frac": alg / (fft_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "algorithmic_flops": flops, "fp32_frac": flops / (fft_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS}
         if fft_n == 16384 and hop == 1024:
+            # what k_fft16k_run executes per real window: two complex 4096-point transforms (the real 16384-point transform as a
+            # decimation in time by four, two halves packed), the Hann weights, and per retained bin the four-term recombination
+            # and the dB conversion (~30 flops) — about half of the nominal 5 N log2 N
+            executed = (2 * 5.0 * 4096 * 12 + 3.0 * fft_n + 30.0 * lay.n_bins) * streams * lay.n_windows * lay.fft_channels
+            res["spectrum_kernel"]["executed_flops"] = executed
+            res["spectrum_kernel"]["fp32_frac_executed"] = executed / (fft_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS
             # k_fft16k_run moves, per window and channel, 2 halves x (3 exchanges written + read) of 4096 complex f32
             # plus the 4 KB dB staging row: the design's LDS traffic against 128 B/clk/CU
             lds = streams * lay.n_windows * lay.fft_channels * (2 * 3 * 2 * 4096 * 8 + 2 * 4 * lay.n_bins)

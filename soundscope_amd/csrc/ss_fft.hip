@@ -6,9 +6,6 @@
 #include "ss_kernels.h"
 #include <cstdlib>
 
-#ifndef SS_FFT_TW2K
-#define SS_FFT_TW2K 1          // second-pass twiddle table as [kb][tb], batched reads shared by both halves (k_fft16k_run) / requested early (k_fft4096_ms1)
-#endif
 #ifndef SS_FFT_WAVES
 #define SS_FFT_WAVES 2   // min waves per SIMD the N=4096 pair kernel is register-allocated for
 #endif
@@ -539,12 +536,6 @@ __device__ unsigned long long g_fft_prof[16];
 #define SS_FPROF_MARK(i)
 #define SS_FPROF_END
 #endif
-#ifndef SS_MS1_ZROW
-#define SS_MS1_ZROW 1      /* temporary A/B switches */
-#endif
-#ifndef SS_MS1_LDSTAB
-#define SS_MS1_LDSTAB 1
-#endif
 template <int HS, bool TW6, bool COLS>
 __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchParams p)
 {
@@ -584,11 +575,7 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
 #pragma unroll
         for (int ka = 1; ka < 16; ka++) tw1[ka] = twn[t * ka];
     }
-#if SS_FFT_TW2K
     tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[(t & 15) * (t >> 4)];      // [kb][tb]: W_256^(tb kb) at kb * 16 + tb
-#else
-    tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[t];
-#endif
     if (COLS) {
         for (uint32_t g = (uint32_t)t; 4u * g < p.bin_stride; g += 256u)
             reinterpret_cast<uint2 *>(bincol)[g] = reinterpret_cast<const uint2 *>(p.bin_col)[g];
@@ -644,11 +631,7 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
             }
         }
     };
-#if SS_MS1_ZROW
     auto zero_bits = [&]() -> uint32_t { return ((hopmask & 0xFFu) == 0u ? 1u : 0u) | ((hopmask & 0xFF00u) == 0u ? 2u : 0u); };
-#else
-    auto zero_bits = [&]() -> uint32_t { return 0u; };
-#endif
     publish_zero(zero_bits(), 0u, w_begin);
     SS_FPROF_DECL
     for (uint32_t w = w_begin; w < w_end; ++w) {
@@ -692,7 +675,6 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
         fft16(z);
         SS_PRIO_HI();
         xbuf[X2W(0, hi, tb)] = z[R16(0)];
-#if SS_FFT_TW2K
         {   // second-pass twiddles from the [kb][tb] table (address = tb * 8 + an immediate), four at a time, the next four
             // requested before the current four are used
             const v2f *twp = tw2s + tb;
@@ -714,10 +696,6 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
                 for (int j = 0; j < 4; j++) twa[j] = twb[j];
             }
         }
-#else
-#pragma unroll
-        for (int kb = 1; kb < 16; kb++) xbuf[X2W(kb, hi, tb)] = pk_cmul(z[R16(kb)], tw2s[tb * kb]);
-#endif
         SS_FPROF_MARK(4);
         __syncthreads();
         SS_FPROF_MARK(5);
@@ -747,18 +725,12 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
                 nm |= __float_as_uint(sm[16 - HS + q]); nd |= __float_as_uint(df[16 - HS + q]);
             }
             nm &= 0x7fffffffu; nd &= 0x7fffffffu;            // (a -0.0 is a zero: the sign is dropped once, after the ORs)
-#if SS_MS1_ZROW
             hopmask = ((hopmask >> 1) & 0x7F7Fu) | ((wave_any(nm) ? 1u : 0u) << (NH - 1)) | ((wave_any(nd) ? 1u : 0u) << (8 + NH - 1));
-#endif
             publish_zero(zero_bits(), par ^ 1u, w + 1);
         }
         float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
         if (COLS) fft4096_epilogue<false, true>(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, nullptr, nullptr, true, colbuf, bincol, p.cols, cgain);
-#if SS_MS1_LDSTAB
         else fft4096_epilogue<true>(xbuf, t, p.first_bin, p.n_bins, p.db_offset, offp, o_mid, o_mid + p.bin_stride);
-#else
-        else fft4096_epilogue<false>(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride);
-#endif
         if (__builtin_expect(curz != 0u, 0)) {
             // my slice is empty: is everybody's?  (every wave of an empty row arrives here and reads the same four slots)
             bool z0 = false, z1 = false;
@@ -819,7 +791,7 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_pairw(FftBatchPa
     v2f tw1[16];
     tw1[1] = twn[t]; tw1[2] = twn[2 * t]; tw1[3] = twn[3 * t];
     tw1[4] = twn[4 * t]; tw1[8] = twn[8 * t]; tw1[12] = twn[12 * t];
-    tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[t];
+    tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[(t & 15) * (t >> 4)];      // [kb][tb]: W_256^(tb kb) at kb * 16 + tb (see k_fft4096_ms1)
     const int tb = t & 15, hi = t >> 4;
     const int tsw = SPEC_POS(t);
     const size_t row_stride = (size_t)fft_ch * p.bin_stride;              // window w -> window w + 1 of the same channel
@@ -883,8 +855,26 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_pairw(FftBatchPa
         fft16(z);
         SS_PRIO_HI();
         xbuf[X2W(0, hi, tb)] = z[R16(0)];
+        {
+            const v2f *twp = tw2s + tb;
+            v2f twa[4], twb[4];
 #pragma unroll
-        for (int kb = 1; kb < 16; kb++) xbuf[X2W(kb, hi, tb)] = pk_cmul(z[R16(kb)], tw2s[tb * kb]);
+            for (int j = 0; j < 4; j++) twa[j] = twp[16 * (1 + j)];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int kb0 = 1 + 4 * g, nk = g == 3 ? 3 : 4;
+                if (g < 3) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) if (kb0 + 4 + j < 16) twb[j] = twp[16 * (kb0 + 4 + j)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < nk; j++) xbuf[X2W(kb0 + j, hi, tb)] = pk_cmul(z[R16(kb0 + j)], twa[j]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; j++) twa[j] = twb[j];
+            }
+        }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 16; q++) z[q] = xbuf[X2W(hi, tb, q)];
@@ -1162,11 +1152,7 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
     const float *base = p.pcm + ((size_t)stream * p.frames_per_stream + p.first_start + (size_t)w_begin * 1024u) * C;
     const v2f *tw16k = reinterpret_cast<const v2f *>(p.tw_n);       // W_16384^k, k < 8192
     const v2f *tw4k = reinterpret_cast<const v2f *>(p.tw_core);     // W_4096^k
-#if SS_FFT_TW2K
     tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[(t & 15) * (t >> 4)];      // [kb][tb]: W_256^(tb kb) at kb * 16 + tb
-#else
-    tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[t];
-#endif
 
     // samples n .. n + 3 of this workgroup's channel (n relative to the run's first window): the two
     // halves' complex inputs z_0 = (x[n], x[n+1]), z_1 = (x[n+2], x[n+3])
@@ -1258,7 +1244,6 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
 #pragma unroll
         for (int ta = 0; ta < 16; ta++) { z0[ta] = xbuf2[0][X1W(hi, tb, ta)]; z1[ta] = xbuf2[1][X1W(hi, tb, ta)]; }
         __syncthreads();
-#if SS_FFT_TW2K
         // Second-pass twiddles W_256^(tb kb): ONE table read serves both halves, the table is laid out [kb][tb] (a lane's
         // address is tb * 8 + an immediate) and the reads come in batches of four, the next batch requested before the current
         // one is used.  (Read one at a time, once per half — what the straightforward loop compiles to at this register
@@ -1291,17 +1276,6 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
             }
         }
         __syncthreads();
-#else
-        fft16(z0);
-        xbuf2[0][X2W(0, hi, tb)] = z0[R16(0)];
-#pragma unroll
-        for (int kb = 1; kb < 16; kb++) xbuf2[0][X2W(kb, hi, tb)] = pk_cmul(z0[R16(kb)], tw2s[tb * kb]);
-        fft16(z1);
-        xbuf2[1][X2W(0, hi, tb)] = z1[R16(0)];
-#pragma unroll
-        for (int kb = 1; kb < 16; kb++) xbuf2[1][X2W(kb, hi, tb)] = pk_cmul(z1[R16(kb)], tw2s[tb * kb]);
-        __syncthreads();
-#endif
 #pragma unroll
         for (int qq = 0; qq < 16; qq++) { z0[qq] = xbuf2[0][X2W(hi, tb, qq)]; z1[qq] = xbuf2[1][X2W(hi, tb, qq)]; }
         __syncthreads();
