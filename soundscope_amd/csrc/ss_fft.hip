@@ -6,6 +6,9 @@
 #include "ss_kernels.h"
 #include <cstdlib>
 
+#ifndef SS_FFT_PAIRW_WAVES
+#define SS_FFT_PAIRW_WAVES 3   // min waves per SIMD k_fft4096_pairw is register-allocated for (4: 128 VGPRs with 13 spilled, measured 10 % slower)
+#endif
 #ifndef SS_FFT_WAVES
 #define SS_FFT_WAVES 2   // min waves per SIMD the N=4096 pair kernel is register-allocated for
 #endif
@@ -756,7 +759,7 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
 // ride one complex transform the way mid and side do — z[n] = (x[n] + i x[n + 1024]) hann[n] — so the "mid" row of
 // the epilogue is window w and the "side" row window w + 1, and the whole of k_fft4096_ms1 carries over.  A workgroup
 // walks window PAIRS; the sliding registers hold 20 slots and advance by 8 (2048 frames) per iteration.
-__global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_pairw(FftBatchParams p, uint32_t fft_ch)
+__global__ __launch_bounds__(256, SS_FFT_PAIRW_WAVES) void k_fft4096_pairw(FftBatchParams p, uint32_t fft_ch)
 {
     __shared__ __attribute__((aligned(16))) v2f xbuf[16 * kPlane];        // 36864 B
     __shared__ __attribute__((aligned(16))) v2f tw2s[256];                //  2048 B

@@ -1,5 +1,5 @@
 import sys
-sys.path.insert(0,'/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import soundscope_amd as ssa
 from soundscope_amd import _lib as L
 for ch, ns in ((1, 2048), (2, 1024), (6, 340)):
