@@ -540,7 +540,9 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
         const uint32_t nb_full = L / kTdBatch;          // whole batches in a full chunk
         // (Stereo reading whole frames as ds_read_b64 + select in the two passes below — mod-64 banks, two deep instead of the
         // four of ds_read_b32's mod-32 banks at this chunk stride — was measured: 1.99 -> 2.13 ms,
-        // profiles/r03_ab_ms1_td_variants.txt; the select and the unmergeable reads cost more than the conflicts.)
+        // profiles/r03_ab_ms1_td_variants.txt; the select and the unmergeable reads cost more than the conflicts.  And the
+        // conflicts cost little: with both passes walking the tile lane-linear (conflict-free, wrong results, timing only)
+        // the kernel went from 1.946 to 1.918 ms, profiles/r03_ab_td_conflict_free_passes.txt.)
 
         // ---- pass 1: zero-state response of the state recurrence
         double z[4] = {0.0, 0.0, 0.0, 0.0};
