@@ -560,7 +560,16 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
                     for (int u = 0; u < kTdBatch; u++) { SS_KW_LA_STEP((double)xb[u]) SS_KW_SHIFT() }
                 }
                 i = nb_full * kTdBatch;
-                for (; i < len; i++) { SS_KW_LA_STEP((double)xs[(i + 3) * C]) SS_KW_SHIFT() }
+                if (i < L) {                            // chunk lengths that are no multiple of the batch (L = 49 at 44.1 kHz):
+                    const uint32_t rem = L - i;         // one more batch of reads (into the next chunk or the zeroed slack), of
+                    float xb[kTdBatch];                 // which the first `rem` (wave-uniform) are consumed
+#pragma unroll
+                    for (int u = 0; u < kTdBatch; u++) xb[u] = xp[u * (int)C];
+#pragma unroll
+                    for (int u = 0; u < kTdBatch - 1; u++)
+                        if ((uint32_t)u < rem) { SS_KW_LA_STEP((double)xb[u]) SS_KW_SHIFT() }
+                    i = L;
+                }
             }
             for (; i < len; i++) { SS_KW_STATE((double)xs[i * C]) SS_KW_SHIFT() }
             z[0] = v1; z[1] = v2; z[2] = v3; z[3] = v4;
@@ -645,12 +654,21 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_dom
                     }
                 }
                 i = nb_full * kTdBatch;
-                for (; i < len; i++) {
-                    const float xn = xs[(i + 3) * C];
-                    sp = fmaxf(sp, fabsf(xn));
-                    SS_KW_LA_STEP((double)xn) SS_KW_LA_OUT() SS_KW_SHIFT()
-                    e = fma(y_, y_, e);
-                    if (RING) p.ring[((ring_base + i) % p.ring_frames) * C + ch] = y_;
+                if (i < L) {
+                    const uint32_t rem = L - i;
+                    float xb[kTdBatch];
+#pragma unroll
+                    for (int u = 0; u < kTdBatch; u++) xb[u] = xp[u * (int)C];
+#pragma unroll
+                    for (int u = 0; u < kTdBatch - 1; u++)
+                        if ((uint32_t)u < rem) {
+                            // (x[i + 3] of the last three steps belongs to the next chunk: harmless in a maximum, see above)
+                            sp = fmaxf(sp, fabsf(xb[u]));
+                            SS_KW_LA_STEP((double)xb[u]) SS_KW_LA_OUT() SS_KW_SHIFT()
+                            e = fma(y_, y_, e);
+                            if (RING) p.ring[((ring_base + i + u) % p.ring_frames) * C + ch] = y_;
+                        }
+                    i = L;
                 }
             }
             for (; i < len; i++) {

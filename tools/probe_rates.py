@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import soundscope_amd as ssa
 from soundscope_amd import _lib as L
 streams = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-for rate in (44100, 48000, 88200, 96000, 22050):
+for rate in (44100, 48000, 88200, 96000):
     frames = rate * 10
     b = ssa.Batch(rate, 2, streams, frames, 4096, 1024, flags=L.SS_BATCH_ALL)
     b.synthesize(0x5EED0000, 0)
