@@ -115,9 +115,43 @@ __device__ __forceinline__ uint32_t ring_back(uint32_t jm, uint32_t q, uint32_t 
     return s % cap;
 }
 
+// Weighted energy of the N sub-blocks ending with sub-block j (slot jm = j % cap):  sum_c w_c (P[j-N+1][c] + ... + P[j][c]),
+// each channel added oldest first.  All loads of a batch are issued before the first addition — written as a loop of
+// `cs += P[...]` the thirty terms of a short-term block were thirty dependent round trips to memory (12 us of a tick, and
+// the whole of this kernel's time on a long stream).
+template <int N, bool DIRECT>
+__device__ __forceinline__ double window_energy(const double *__restrict__ P, uint32_t jm, uint32_t cap, uint32_t C,
+                                                const double *__restrict__ weights)
+{
+    constexpr int kBatch = N < 10 ? N : 10;
+    static_assert(N % kBatch == 0, "whole batches");
+    uint32_t s0 = DIRECT ? jm - (uint32_t)(N - 1) : ring_back(jm, (uint32_t)(N - 1), cap);      // slot of the oldest term
+    double sum = 0.0;
+    for (uint32_t c = 0; c < C; c++) {
+        const double w = weights[c];
+        if (w == 0.0) continue;
+        double cs = 0.0;
+        uint32_t sl = s0;
+#pragma unroll
+        for (int b = 0; b < N; b += kBatch) {
+            double v[kBatch];
+#pragma unroll
+            for (int q = 0; q < kBatch; q++) {
+                v[q] = P[(size_t)sl * C + c];
+                sl = DIRECT ? sl + 1u : (sl + 1u == cap ? 0u : sl + 1u);
+            }
+#pragma unroll
+            for (int q = 0; q < kBatch; q++) cs += v[q];
+        }
+        sum += w * cs;
+    }
+    return sum;
+}
+
 // One workgroup per stream; the gating blocks of a stream are independent (histogram increments are LDS atomics), so a
-// long stream (config 2's 600 s: 6000 sub-blocks) is spread over 256 threads; wave 0 then evaluates gate and LRA.
-__global__ __launch_bounds__(256) void k_finalize(FinalizeParams p)
+// long stream (config 2's 600 s: 6000 sub-blocks) is spread over up to 1024 threads — a thread's iteration is a chain of
+// dependent loads, so the kernel's time is its iteration count; wave 0 then evaluates gate and LRA.
+__global__ __launch_bounds__(1024) void k_finalize(FinalizeParams p)
 {
     __shared__ unsigned long long hb[kHistBins];
     __shared__ unsigned long long hs[kHistBins];
@@ -138,31 +172,21 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams p)
     // gating block ending with sub-block j: j-3..j ; short-term block: j-29..j when (j-29) % 10 == 0
     const uint64_t sub_end = p.sub_end_of ? p.sub_end_of[stream] : p.sub_end;          // ragged batches
     uint32_t nb = 0, ns = 0;
-    for (uint64_t j = p.sub_begin + lane; j < sub_end; j += nthr) {
+    // gating blocks: one per sub-block j >= 3
+    for (uint64_t j = (p.sub_begin > 3 ? p.sub_begin : 3) + lane; j < sub_end; j += nthr) {
         const uint32_t jm = direct ? (uint32_t)j : (uint32_t)(j % cap);
-        if (j >= 3) {
-            double sum = 0.0;
-            for (uint32_t c = 0; c < C; c++) {
-                const double w = p.weights[c];
-                if (w == 0.0) continue;
-                double cs = 0.0;
-                for (int q = 3; q >= 0; q--) cs += P[(size_t)(direct ? jm - (uint32_t)q : ring_back(jm, (uint32_t)q, cap)) * C + c];
-                sum += w * cs;
-            }
-            sum /= 4.0 * S;
-            nb++;
-            if (sum >= p.hist_bounds[0]) atomicAdd(&hb[hist_index(p.hist_bounds, sum)], 1ull);
-        }
-        if (j >= 29 && (j - 29) % 10 == 0) {
-            double sum = 0.0;
-            for (uint32_t c = 0; c < C; c++) {
-                const double w = p.weights[c];
-                if (w == 0.0) continue;
-                double cs = 0.0;
-                for (int q = 29; q >= 0; q--) cs += P[(size_t)(direct ? jm - (uint32_t)q : ring_back(jm, (uint32_t)q, cap)) * C + c];
-                sum += w * cs;
-            }
-            sum /= 30.0 * S;
+        const double sum = (direct ? window_energy<4, true>(P, jm, cap, C, p.weights) : window_energy<4, false>(P, jm, cap, C, p.weights)) / (4.0 * S);
+        nb++;
+        if (sum >= p.hist_bounds[0]) atomicAdd(&hb[hist_index(p.hist_bounds, sum)], 1ull);
+    }
+    // short-term blocks: j = 29 + 10 m.  Dealt densely (thread = m), not as every tenth lane of the loop above
+    {
+        const uint64_t m_begin = p.sub_begin > 29 ? (p.sub_begin - 29 + 9) / 10 : 0;      // first m with 29 + 10 m >= sub_begin
+        for (uint64_t m = m_begin + lane;; m += nthr) {
+            const uint64_t j = 29 + 10 * m;
+            if (j >= sub_end) break;
+            const uint32_t jm = direct ? (uint32_t)j : (uint32_t)(j % cap);
+            const double sum = (direct ? window_energy<30, true>(P, jm, cap, C, p.weights) : window_energy<30, false>(P, jm, cap, C, p.weights)) / (30.0 * S);
             ns++;
             if (sum >= p.hist_bounds[0]) atomicAdd(&hs[hist_index(p.hist_bounds, sum)], 1ull);
         }
@@ -197,30 +221,18 @@ __global__ __launch_bounds__(64) void k_finalize_stream(FinalizeParams p)
     const double S = (double)p.k->s100;
     const double *P = p.subblocks;
     uint32_t nb = 0, ns = 0;
-    for (uint64_t j = p.sub_begin + lane; j < p.sub_end; j += 64) {
-        if (j >= 3) {
-            double sum = 0.0;
-            for (uint32_t c = 0; c < C; c++) {
-                const double w = p.weights[c];
-                if (w == 0.0) continue;
-                double cs = 0.0;
-                for (int q = 3; q >= 0; q--) cs += P[(size_t)((j - q) % p.sub_cap) * C + c];
-                sum += w * cs;
-            }
-            sum /= 4.0 * S;
-            nb++;
-            if (sum >= p.hist_bounds[0]) atomicAdd(&gh[hist_index(p.hist_bounds, sum)], 1ull);
-        }
-        if (j >= 29 && (j - 29) % 10 == 0) {
-            double sum = 0.0;
-            for (uint32_t c = 0; c < C; c++) {
-                const double w = p.weights[c];
-                if (w == 0.0) continue;
-                double cs = 0.0;
-                for (int q = 29; q >= 0; q--) cs += P[(size_t)((j - q) % p.sub_cap) * C + c];
-                sum += w * cs;
-            }
-            sum /= 30.0 * S;
+    const uint32_t cap = p.sub_cap;
+    for (uint64_t j = (p.sub_begin > 3 ? p.sub_begin : 3) + lane; j < p.sub_end; j += 64) {
+        const double sum = window_energy<4, false>(P, (uint32_t)(j % cap), cap, C, p.weights) / (4.0 * S);
+        nb++;
+        if (sum >= p.hist_bounds[0]) atomicAdd(&gh[hist_index(p.hist_bounds, sum)], 1ull);
+    }
+    {
+        const uint64_t m_begin = p.sub_begin > 29 ? (p.sub_begin - 29 + 9) / 10 : 0;
+        for (uint64_t m = m_begin + lane;; m += 64) {
+            const uint64_t j = 29 + 10 * m;
+            if (j >= p.sub_end) break;
+            const double sum = window_energy<30, false>(P, (uint32_t)(j % cap), cap, C, p.weights) / (30.0 * S);
             ns++;
             if (sum >= p.hist_bounds[0]) atomicAdd(&gh[kHistBins + hist_index(p.hist_bounds, sum)], 1ull);
         }
@@ -237,9 +249,9 @@ hipError_t launch_finalize(const FinalizeParams &p, hipStream_t s)
     const bool streaming = p.n_streams == 1 && !p.corpus_hist && !p.out_integrated && !p.out_lra && p.sub_stride == 0;
     if (streaming) hipLaunchKernelGGL(k_finalize_stream, dim3(1), dim3(64), 0, s, p);
     else {
-        // a wave per stream when there are many streams or little to do per stream; four waves for a long stream
+        // a wave per stream when there are many streams or little to do per stream; four to sixteen waves for a long stream
         const uint64_t nsub = p.sub_end - p.sub_begin;
-        const uint32_t threads = (nsub > 512 && p.n_streams < 4096) ? 256u : 64u;
+        const uint32_t threads = p.n_streams >= 4096 ? 64u : nsub > 2048 ? 1024u : nsub > 512 ? 256u : 64u;
         hipLaunchKernelGGL(k_finalize, dim3(p.n_streams), dim3(threads), 0, s, p);
     }
     return hipGetLastError();
