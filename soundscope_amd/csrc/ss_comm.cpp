@@ -49,6 +49,12 @@
 
 namespace {
 
+// RCCL shares device buffers between the ranks' processes through HSA IPC.  Hosts whose driver supports only dmabuf IPC
+// need HSA_ENABLE_IPC_MODE_LEGACY=0 (without it ncclCommInitRank fails with "hipIpcGetMemHandle: invalid argument"); the
+// HSA runtime reads the variable once, when the first HIP call starts it, so the default is set when this library is
+// loaded — a value the user exported is left alone.
+__attribute__((constructor)) void default_hsa_ipc_mode() { ::setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0); }
+
 constexpr const char *kMagic = "ssc2";
 // SS_COMM_TIMEOUT_S (seconds, default 180): how long a rank waits for the others at the rendezvous and inside ncclCommInitRank
 int join_timeout_s()
