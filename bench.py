@@ -26,6 +26,10 @@ import numpy as np
 
 # the host driver only supports dmabuf IPC: RCCL across processes needs this (inherited on the GPU boxes; set if missing)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# one node: RCCL's bootstrap needs nothing but loopback (the container's other interfaces / hostname may not be usable);
+# the data path between the GPUs is xGMI peer-to-peer either way.  An exported value wins.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
