@@ -34,6 +34,11 @@ __device__ __forceinline__ float2 cmul_mi(float2 a) { return make_float2(a.y, -a
 // -i / +i, complex multiply) are expressed with op_sel / neg modifiers, which the compiler's SLP
 // packer does not find (it pays ~30 % v_mov to pair registers instead — hence -fno-slp-vectorize).
 typedef float v2f __attribute__((ext_vector_type(2)));
+// one ds_read_b64 (see kRowB): a volatile load in the LDS address space is neither merged with its neighbours nor widened
+__device__ __forceinline__ v2f lds_ld64(const v2f *p)
+{
+    return *(const volatile __attribute__((address_space(3))) v2f *)p;
+}
 // a - i b = (a.x + b.y, a.y - b.x)
 __device__ __forceinline__ v2f pk_sub_ib(v2f a, v2f b)
 {
@@ -148,12 +153,28 @@ constexpr int kX2Stride = 17;    // anyhop kernel: row of 16 padded to 17, confl
 // land on 16 distinct 4-bank slots (36*i mod 64 is a permutation of the multiples of 4).
 constexpr int kRow = 18;
 constexpr int kPlane = 16 * kRow;   // 288 complex per outer index; 16 planes = 4608 complex = 36864 B
+// batch kernels (k_fft4096_ms1, k_fft4096_pairw, k_fft16k_run): rows of 16 complex padded to 17, planes of 16 rows (272, = 16
+// mod 32).  By the LDS rules of MI355X_MICROARCH.md (ds_write_b64: contiguous 16-lane groups, banks (a/4) mod 32;
+// ds_read_b64: 32-lane groups, (a/4) mod 64) both exchanges are then free of bank conflicts in BOTH directions:
+//   write (ka; tb, hi) at ka*272 + tb*17 + hi : a group is tb = 0..15, dword 34 tb + c = 2 tb + c mod 32 — 32 distinct banks
+//     (with rows of 18 it was 4 tb mod 32: two deep, the largest single share of the kernels' conflict cycles);
+//   write (kb; hi, tb) at kb*272 + hi*17 + tb : 32 consecutive dwords;
+//   read  (hi; tb, 0..15) at hi*272 + tb*17 + j as sixteen ds_read_b64: a group is two planes x 16 rows, and
+//     {17 tb} U {17 tb + 16} mod 32 covers every residue once.
+// An odd row stride rules out ds_read_b128 (rows are 8-byte aligned), which costs nothing in the LDS array (b64 and b128
+// both move 256 B per cycle) — but left to itself the compiler pairs such reads into ds_read2_b64, which moves 128 B per
+// cycle: the reads go through lds_ld64 (volatile, LDS address space: one ds_read_b64 each, never merged).
+constexpr int kRowB = 17;
+constexpr int kPlaneB = 16 * kRowB;
 
-// Published spectrum layout: bin k lives at k with bit 1 flipped when bit 6 is set.  A lane that owns four
-// consecutive bins reads them as two aligned 16-byte pairs; the flip spreads the 16-lane groups of
-// ds_read_b128 (and the 32-lane groups of the mirror's ds_read_b64) over distinct banks, while the
-// publishing writes (16 consecutive k per 16-lane group) stay conflict-free.
-#define SPEC_POS(k) ((k) ^ ((((k) >> 6) & 1) << 1))
+// Published spectrum layout of the N = 4096 kernels: bin k lives at k with bits 1:0 XORed with bits 6:5.  A lane owns four
+// consecutive retained bins k0 + e (k0 = first_bin + 4 g) and reads bin e of all lanes with one ds_read_b64 (32-lane groups,
+// banks (a/4) mod 64): the lanes' addresses are 32 bytes apart, so unswizzled only 8 of the 32 bank pairs would be used,
+// four deep; the XOR sends lanes g, g + 8, g + 16, g + 24 to the four different pairs of their 32-byte slot — conflict-free
+// for the bins and for their mirrors 4096 - k (modelled with the rules of MI355X_MICROARCH.md, then measured; flipping bit 1
+// by bit 6 alone, as before, left them two deep).  The publishing writes (16 consecutive k per 16-lane group, permuted
+// inside aligned quads) stay conflict-free.
+#define SPEC_POS(k) ((k) ^ (((k) >> 5) & 3))
 
 // dB epilogue of one window.  xb holds the full spectrum Z[0..4095] in that order; a thread
 // owns groups of FOUR consecutive retained bins (g = t, t + 256), so both output rows are written
@@ -542,7 +563,7 @@ __device__ unsigned long long g_fft_prof[16];
 template <int HS, bool TW6, bool COLS>
 __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchParams p)
 {
-    __shared__ __attribute__((aligned(16))) v2f xbuf[16 * kPlane];        // 36864 B
+    __shared__ __attribute__((aligned(16))) v2f xbuf[16 * kPlaneB];       // 34816 B (the published spectrum uses 32768)
     __shared__ __attribute__((aligned(16))) v2f tw2s[256];                //  2048 B
     // zero-row detection (see fft4096_floor_rows): [window parity][mid, side][wave] = the window for which that wave's slice of
     // the signal was all zero.  Only waves whose own slice IS zero ever write or read here — the ordinary window costs a few
@@ -553,8 +574,8 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
     __shared__ __attribute__((aligned(16))) float offp[2048];
     uint16_t *bincol = reinterpret_cast<uint16_t *>(offp);                //  4096 B
     uint32_t *colbuf = reinterpret_cast<uint32_t *>(offp) + 1024;         //  4096 B: [mid, side][cols <= 512]
-#define X1W(ka, tb_, ta_) ((ka) * kPlane + (tb_) * kRow + (ta_))
-#define X2W(kb, ka_, tb_) ((kb) * kPlane + (ka_) * kRow + (tb_))
+#define X1W(ka, tb_, ta_) ((ka) * kPlaneB + (tb_) * kRowB + (ta_))
+#define X2W(kb, ka_, tb_) ((kb) * kPlaneB + (ka_) * kRowB + (tb_))
     const int t = threadIdx.x;
     const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
     const uint32_t stream = blockIdx.x / groups;
@@ -670,7 +691,7 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
         __syncthreads();
         SS_FPROF_MARK(1);
 #pragma unroll
-        for (int ta = 0; ta < 16; ta++) z[ta] = xbuf[X1W(hi, tb, ta)];
+        for (int ta = 0; ta < 16; ta++) z[ta] = lds_ld64(&xbuf[X1W(hi, tb, ta)]);
         SS_FPROF_MARK(2);
         __syncthreads();
         SS_FPROF_MARK(3);
@@ -683,13 +704,13 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
             const v2f *twp = tw2s + tb;
             v2f twa[4], twb[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) twa[j] = twp[16 * (1 + j)];
+            for (int j = 0; j < 4; j++) twa[j] = lds_ld64(&twp[16 * (1 + j)]);
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int kb0 = 1 + 4 * g, nk = g == 3 ? 3 : 4;
                 if (g < 3) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) if (kb0 + 4 + j < 16) twb[j] = twp[16 * (kb0 + 4 + j)];
+                    for (int j = 0; j < 4; j++) if (kb0 + 4 + j < 16) twb[j] = lds_ld64(&twp[16 * (kb0 + 4 + j)]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -703,7 +724,7 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
         __syncthreads();
         SS_FPROF_MARK(5);
 #pragma unroll
-        for (int q = 0; q < 16; q++) z[q] = xbuf[X2W(hi, tb, q)];
+        for (int q = 0; q < 16; q++) z[q] = lds_ld64(&xbuf[X2W(hi, tb, q)]);
         SS_FPROF_MARK(6);
         __syncthreads();
         SS_FPROF_MARK(7);
@@ -761,13 +782,13 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
 // walks window PAIRS; the sliding registers hold 20 slots and advance by 8 (2048 frames) per iteration.
 __global__ __launch_bounds__(256, SS_FFT_PAIRW_WAVES) void k_fft4096_pairw(FftBatchParams p, uint32_t fft_ch)
 {
-    __shared__ __attribute__((aligned(16))) v2f xbuf[16 * kPlane];        // 36864 B
+    __shared__ __attribute__((aligned(16))) v2f xbuf[16 * kPlaneB];       // 34816 B
     __shared__ __attribute__((aligned(16))) v2f tw2s[256];                //  2048 B
     // zero-row detection as in k_fft4096_ms1: [pair parity][first, second window][wave] = the pair for which that wave's slice
     // of the window was all zero (only waves whose own slice is empty ever touch it)
     __shared__ __attribute__((aligned(16))) uint32_t zslot[2][2][4];
-#define X1W(ka, tb_, ta_) ((ka) * kX1Stride + (tb_) + 16 * (ta_))
-#define X2W(kb, ka_, tb_) ((kb) * kPlane + (ka_) * kRow + (tb_))
+#define X1W(ka, tb_, ta_) ((ka) * kPlaneB + (tb_) * kRowB + (ta_))
+#define X2W(kb, ka_, tb_) ((kb) * kPlaneB + (ka_) * kRowB + (tb_))
     const int t = threadIdx.x;
     const uint32_t pairs_per_block = p.windows_per_block >> 1;            // the host keeps windows_per_block even
     const uint32_t n_pairs_max = (p.n_windows + 1) >> 1;
@@ -852,7 +873,7 @@ __global__ __launch_bounds__(256, SS_FFT_PAIRW_WAVES) void k_fft4096_pairw(FftBa
         }
         __syncthreads();
 #pragma unroll
-        for (int ta = 0; ta < 16; ta++) z[ta] = xbuf[X1W(hi, tb, ta)];
+        for (int ta = 0; ta < 16; ta++) z[ta] = lds_ld64(&xbuf[X1W(hi, tb, ta)]);
         __syncthreads();
         SS_PRIO_LO();
         fft16(z);
@@ -862,13 +883,13 @@ __global__ __launch_bounds__(256, SS_FFT_PAIRW_WAVES) void k_fft4096_pairw(FftBa
             const v2f *twp = tw2s + tb;
             v2f twa[4], twb[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) twa[j] = twp[16 * (1 + j)];
+            for (int j = 0; j < 4; j++) twa[j] = lds_ld64(&twp[16 * (1 + j)]);
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int kb0 = 1 + 4 * g, nk = g == 3 ? 3 : 4;
                 if (g < 3) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) if (kb0 + 4 + j < 16) twb[j] = twp[16 * (kb0 + 4 + j)];
+                    for (int j = 0; j < 4; j++) if (kb0 + 4 + j < 16) twb[j] = lds_ld64(&twp[16 * (kb0 + 4 + j)]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -880,7 +901,7 @@ __global__ __launch_bounds__(256, SS_FFT_PAIRW_WAVES) void k_fft4096_pairw(FftBa
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 16; q++) z[q] = xbuf[X2W(hi, tb, q)];
+        for (int q = 0; q < 16; q++) z[q] = lds_ld64(&xbuf[X2W(hi, tb, q)]);
         __syncthreads();
         SS_PRIO_LO();
         fft16(z);
@@ -1130,11 +1151,11 @@ __global__ __launch_bounds__(512, 2) void k_fft16k(FftBatchParams p, int midside
 template <bool MIDSIDE>
 __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_t fft_ch)
 {
-    __shared__ __attribute__((aligned(16))) v2f xbuf2[2][16 * kPlane];       // 2 x 36864 B
+    __shared__ __attribute__((aligned(16))) v2f xbuf2[2][16 * kPlaneB];      // 2 x 34816 B
     __shared__ __attribute__((aligned(16))) v2f tw2s[256];                    //  2048 B
-    __shared__ __attribute__((aligned(16))) float stage[4][256];              //  4096 B: 79872 B per workgroup, two per CU
-#define X1W(ka, tb_, ta_) ((ka) * kPlane + (tb_) * kRow + (ta_))
-#define X2W(kb, ka_, tb_) ((kb) * kPlane + (ka_) * kRow + (tb_))
+    __shared__ __attribute__((aligned(16))) float stage[4][256];              //  4096 B: 75776 B per workgroup, two per CU
+#define X1W(ka, tb_, ta_) ((ka) * kPlaneB + (tb_) * kRowB + (ta_))
+#define X2W(kb, ka_, tb_) ((kb) * kPlaneB + (ka_) * kRowB + (tb_))
     const int t = threadIdx.x;
     const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
     // Workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.  The channels of one run read the
@@ -1190,7 +1211,9 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
     twg[1] = tw4k[t]; twg[2] = tw4k[2 * t]; twg[3] = tw4k[3 * t];
     twg[4] = tw4k[4 * t]; twg[8] = tw4k[8 * t]; twg[12] = tw4k[12 * t];
     const int tb = t & 15, hi = t >> 4;
-    const int tsw = SPEC_POS(t);
+    // (the epilogue below reads bins stride-1 across the wave — 32 consecutive complex values per lane group, conflict-free
+    // wherever they start — so the published spectra stay in plain natural order here)
+    const int tsw = t;
     const uint32_t ngroups = (p.n_bins + 3) >> 2;
     constexpr float kDb = 3.01029995663981195f;
     const float off2 = p.db_offset - 6.02059991327962390f;      // the epilogue carries 2 X
@@ -1245,7 +1268,7 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
         if (more) ld4((size_t)(w + 1 - w_begin) * 1024u + n0 + 1024u * 15u, nx0, nx1);
         __syncthreads();
 #pragma unroll
-        for (int ta = 0; ta < 16; ta++) { z0[ta] = xbuf2[0][X1W(hi, tb, ta)]; z1[ta] = xbuf2[1][X1W(hi, tb, ta)]; }
+        for (int ta = 0; ta < 16; ta++) { z0[ta] = lds_ld64(&xbuf2[0][X1W(hi, tb, ta)]); z1[ta] = lds_ld64(&xbuf2[1][X1W(hi, tb, ta)]); }
         __syncthreads();
         // Second-pass twiddles W_256^(tb kb): ONE table read serves both halves, the table is laid out [kb][tb] (a lane's
         // address is tb * 8 + an immediate) and the reads come in batches of four, the next batch requested before the current
@@ -1259,13 +1282,13 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
             const v2f *twp = tw2s + tb;
             v2f twa[4], twb[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) twa[j] = twp[16 * (1 + j)];
+            for (int j = 0; j < 4; j++) twa[j] = lds_ld64(&twp[16 * (1 + j)]);
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int kb0 = 1 + 4 * g, nk = g == 3 ? 3 : 4;
                 if (g < 3) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) if (kb0 + 4 + j < 16) twb[j] = twp[16 * (kb0 + 4 + j)];
+                    for (int j = 0; j < 4; j++) if (kb0 + 4 + j < 16) twb[j] = lds_ld64(&twp[16 * (kb0 + 4 + j)]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1280,11 +1303,11 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
         }
         __syncthreads();
 #pragma unroll
-        for (int qq = 0; qq < 16; qq++) { z0[qq] = xbuf2[0][X2W(hi, tb, qq)]; z1[qq] = xbuf2[1][X2W(hi, tb, qq)]; }
+        for (int qq = 0; qq < 16; qq++) { z0[qq] = lds_ld64(&xbuf2[0][X2W(hi, tb, qq)]); z1[qq] = lds_ld64(&xbuf2[1][X2W(hi, tb, qq)]); }
         __syncthreads();
         fft16(z0);
 #pragma unroll
-        for (int kc = 0; kc < 16; kc++) xbuf2[0][kc * 256 + tsw] = z0[R16(kc)];   // Z_q[k] at SPEC_POS(k)
+        for (int kc = 0; kc < 16; kc++) xbuf2[0][kc * 256 + tsw] = z0[R16(kc)];   // Z_q[k] at k
         fft16(z1);
 #pragma unroll
         for (int kc = 0; kc < 16; kc++) xbuf2[1][kc * 256 + tsw] = z1[R16(kc)];
@@ -1308,7 +1331,7 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
         // published spectra (and of their mirrors, descending) is stride-1 across the wave: conflict-free
         // whatever first_bin is.  Writing: the four dB values go through a wave-private 1 KB staging row so
         // that lane l stores bins +4l..+4l+3 with one 16-byte store.  From one iteration to the next the bin
-        // index grows by 1024: positions move by +-1024 (SPEC_POS only looks at bits 1 and 6), twiddles turn by W_16^1.
+        // index grows by 1024: positions move by +-1024, twiddles turn by W_16^1.
         float *o = p.out + (((size_t)stream * p.n_windows + w) * fft_ch + ch) * p.bin_stride;
         {
             float *stg = stage[wv];
@@ -1319,7 +1342,7 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
             for (int e = 0; e < 4; e++) {
                 const uint32_t b = fb + 256u * wv + 64u * e + lane;
                 const uint32_t bq = b & 4095u, mq = (4096u - bq) & 4095u;
-                pb[e] = SPEC_POS(bq); pm[e] = SPEC_POS(mq);
+                pb[e] = bq; pm[e] = mq;
             }
             const v2f rho = {0.92387953251128674f, -0.38268343236508977f};
             const uint32_t n_iter = (4u * ngroups + 1023u) >> 10;
