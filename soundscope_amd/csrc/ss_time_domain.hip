@@ -57,16 +57,27 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
 
 
+// Wave priority per phase of the tile loop (s_setprio at the phase marks): the two K-weighting passes 3, the scan 2, the
+// true-peak conversion and MFMA loop 1, staging / decimation / tile tail 0.  The sixteen waves of a CU never synchronise,
+// so left alone (all at priority 0, oldest first) the four waves of a SIMD drift into the same phase and queue for the
+// same unit; graded priorities let a wave inside a dependent f64 chain (one FMA of latency per step) run through while
+// the waves in the throughput phases (LDS staging, conversion, MFMA operands) fill the issue slots it leaves: measured
+// 1.98-2.01 -> 1.82-1.84 ms at the bench shape (-8 %), profiles/r03_ab_td_wave_priorities.txt; passes alone -3.5 %,
+// passes + true peak at one level -5.6 %, the true-peak phases or staging at the top level, or unprioritised: worse.
+// phase BEHIND mark: 0 decimation, 1 pass 1, 2 scan, 3 pass 2, 4 true-peak conversion, 5 MFMA loop, 6 tile tail, 7 staging
+// (the builtin wants a literal: two priority bits per phase, packed)
+#define SS_TD_PHASE_PRIORITY(mark) __builtin_amdgcn_s_setprio((0x05ECu >> (2 * (mark))) & 3u)      // {0, 3, 2, 3, 1, 1, 0, 0}
+
 // Development build (-DSS_TD_PROF): per-phase shader-clock totals of k_time_domain, summed over all waves
 // (s_memtime at the phase boundaries of the tile loop; read back with ss_debug_td_prof).  Not in release builds.
 #ifdef SS_TD_PROF
 __device__ unsigned long long g_td_prof[16];
 #define SS_PROF_DECL uint64_t pt_ = __builtin_amdgcn_s_memtime(); uint64_t pacc_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define SS_PROF_MARK(i) do { const uint64_t n_ = __builtin_amdgcn_s_memtime(); pacc_[i] += n_ - pt_; pt_ = n_; } while (0)
+#define SS_PROF_MARK(i) do { const uint64_t n_ = __builtin_amdgcn_s_memtime(); pacc_[i] += n_ - pt_; pt_ = n_; SS_TD_PHASE_PRIORITY(i); } while (0)
 #define SS_PROF_END do { if (lane == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 9; i_++) atomicAdd(&g_td_prof[i_], (unsigned long long)pacc_[i_]); atomicAdd(&g_td_prof[15], 1ull); } } while (0)
 #else
 #define SS_PROF_DECL
-#define SS_PROF_MARK(i)
+#define SS_PROF_MARK(i) SS_TD_PHASE_PRIORITY(i)
 #define SS_PROF_END
 #endif
 
