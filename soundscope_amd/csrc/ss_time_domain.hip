@@ -4,6 +4,7 @@
 // arithmetic of ebur128 0.1.10 / spectrum-analyzer 1.7.0 / microfft 0.6.0 as restated in DESIGN.md.
 // Nothing here is translated from the reference: the reference has no GPU code.
 #include "ss_kernels.h"
+#include <atomic>
 #include <cstdlib>
 
 #ifndef SS_TD_WAVES
@@ -194,8 +195,12 @@ __device__ __forceinline__ uint32_t wave_max_nonneg_bits(float v)
 // CT: compile-time channel count (0 = runtime)
 // WAVE: 0 no decimation, 1 fused get_waveform (any bin geometry), 2 the same for an exact-integer samples-per-bin that is
 // a multiple of four (<= 128) with 16-byte aligned tiles (the host checks), 3 the same for 128 < spp <= 1000
-template <int FACTOR, bool RING, int CT, int WAVE>
-__global__ __launch_bounds__(64 * kTdWavesPerBlock, SS_TD_WAVES) void k_time_domain(TdParams p, uint32_t L, uint32_t tile_len,
+// WPS: waves per SIMD the instantiation is register-allocated for.  4 (128 VGPRs, 30-120 bytes of scratch per lane) is what a
+// grid of >= 4096 waves needs; a grid that fits the chip at three waves per SIMD (BASELINE config 5: 64 streams x 34
+// segments = 2176 waves) runs the 3-wave build instead — up to 168 VGPRs, nothing spilled: 1.63-1.72 -> 1.58-1.60 ms there
+// (the same build on the 4096-wave bench grid: 1.85 -> 2.24 ms, it needs a second round of waves).
+template <int FACTOR, bool RING, int CT, int WAVE, int WPS>
+__global__ __launch_bounds__(64 * kTdWavesPerBlock, WPS) void k_time_domain(TdParams p, uint32_t L, uint32_t tile_len,
                                                                                       uint32_t wave_lds_floats, uint32_t halo_frames)
 {
     using Cfg = TpCfg<FACTOR>;
@@ -1107,8 +1112,8 @@ uint32_t td_resident_waves_per_cu(uint32_t C, uint32_t s100, uint32_t halo_frame
     return blocks * kTdWavesPerBlock;
 }
 
-template <int FACTOR, bool RING, int CT, int WAVE>
-static hipError_t td_launch(const TdParams &p, hipStream_t s)
+template <int FACTOR, bool RING, int CT, int WAVE, int WPS>
+static hipError_t td_launch_w(const TdParams &p, hipStream_t s)
 {
     const uint32_t C = p.channels;
     const uint32_t S = p.s100;
@@ -1123,7 +1128,7 @@ static hipError_t td_launch(const TdParams &p, hipStream_t s)
     uint32_t wave_floats = (halo + tile_len) * C + td_slack_floats(C) + kMaxChannels;
     wave_floats = (wave_floats + 3u) & ~3u;
     const size_t lds = (size_t)wave_floats * 4 * kTdWavesPerBlock;
-    auto fn = k_time_domain<FACTOR, RING, CT, WAVE>;
+    auto fn = k_time_domain<FACTOR, RING, CT, WAVE, WPS>;
     static DevicePrep prepared;                     // one per kernel instantiation
     const hipError_t pe = prepare_on_device(prepared, [fn] {
         return hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1134,6 +1139,30 @@ static hipError_t td_launch(const TdParams &p, hipStream_t s)
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * kTdWavesPerBlock), lds, s, p, L, tile_len, wave_floats, halo);
     return hipGetLastError();
+}
+
+// compute units of the current device (256 on MI355X), asked once
+static uint32_t td_device_cus()
+{
+    static std::atomic<uint32_t> cached{0};
+    uint32_t n = cached.load(std::memory_order_relaxed);
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = (uint32_t)v;
+        else n = 256;
+        cached.store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
+template <int FACTOR, bool RING, int CT, int WAVE>
+static hipError_t td_launch(const TdParams &p, hipStream_t s)
+{
+    // a workgroup is four waves, one per SIMD: three workgroups per CU hold the whole grid -> the spill-free build
+    const uint64_t waves = (uint64_t)p.n_streams * p.nseg;
+    const uint64_t blocks = (waves + kTdWavesPerBlock - 1) / kTdWavesPerBlock;
+    if (SS_TD_WAVES == 4 && blocks <= 3ull * td_device_cus()) return td_launch_w<FACTOR, RING, CT, WAVE, 3>(p, s);
+    return td_launch_w<FACTOR, RING, CT, WAVE, SS_TD_WAVES>(p, s);
 }
 
 // Decimation fast path (WAVE = 2): samples per bin spp = len / W is an exact integer multiple of four (<= 128), so
