@@ -187,12 +187,14 @@ constexpr int kPlaneB = 16 * kRowB;
 // in LDS (tui.rs:49-51, :801-821; the column rule is the library's, include/soundscope_hip.h).  A value v <= 0 travels as
 // the bit pattern of 0 - v, which orders like an unsigned integer, so "max v" is one ds_min_u32 per run of bins that share
 // a column (a lane's four consecutive bins usually do); colbuf[row * cols + c] starts at 0xFFFFFFFF = "no bin" = NaN.
+// `side_off` (wave-uniform): the second row rode the transform multiplied by 2^E (its block exponent, see "Two rows, one
+// transform" below); side_off = -E * 20 log10(2) takes the factor out again in dB.
 template <bool LDS_TABLE = false, bool COLS = false>
 __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t first_bin, uint32_t n_bins,
                                                  float db_offset, const float *__restrict__ offpink,
                                                  float *o_mid, float *o_side, bool store_side = true,
                                                  uint32_t *colbuf = nullptr, const uint16_t *bincol = nullptr,
-                                                 uint32_t cols = 0, float gain = 0.0f)
+                                                 uint32_t cols = 0, float gain = 0.0f, float side_off = 0.0f)
 {
     const uint32_t ngroups = (n_bins + 3) >> 2;
     // dB = 10 log10(2) * log2(q) + (db_offset + pink[bin]); an exact zero reads -150 (+ pink): the log operand is
@@ -253,18 +255,22 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
                 qs[e] = fmaf(s2.x, s2.x, s2.y * s2.y);
             }
             const float opv[4] = {op[i].x, op[i].y, op[i].z, op[i].w};
+            // the second row's offsets carry its block exponent (two packed adds per group)
+            const v2f so2 = {side_off, side_off};
+            const v2f osa = v2f{op[i].x, op[i].y} + so2, osb = v2f{op[i].z, op[i].w} + so2;
+            const float ops[4] = {osa.x, osa.y, osb.x, osb.y};
             const float qmin = fminf(fminf(fminf(qm[0], qm[1]), fminf(qm[2], qm[3])), fminf(fminf(qs[0], qs[1]), fminf(qs[2], qs[3])));
             if (__builtin_expect(__ballot(qmin == 0.0f) == 0ull, 1)) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     rm[i][e] = fmaf(__log2f(qm[e]), kDb, opv[e]);
-                    rs[i][e] = fmaf(__log2f(qs[e]), kDb, opv[e]);
+                    rs[i][e] = fmaf(__log2f(qs[e]), kDb, ops[e]);
                 }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     rm[i][e] = fmaf(qm[e] == 0.0f ? lg0 : __log2f(qm[e]), kDb, opv[e]);
-                    rs[i][e] = fmaf(qs[e] == 0.0f ? lg0 : __log2f(qs[e]), kDb, opv[e]);
+                    rs[i][e] = qs[e] == 0.0f ? fmaf(lg0, kDb, opv[e]) : fmaf(__log2f(qs[e]), kDb, ops[e]);      // a zero is -150 whatever the exponent
                 }
             }
         } else {
@@ -321,9 +327,10 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
 // a row whose signal was EXACTLY zero over the whole window — where the reference, which transforms each signal on its own,
 // reports its floor: a buffer of zeros has magnitude 0 in every bin, hence -150 dB (analyzer.rs:20-22).  Dual-mono files
 // (L == R: the side signal is zero) and digital silence in front of a programme (the window pairs of k_fft4096_pairw) are
-// the everyday cases.  The kernels keep a wave-uniform "some sample is non-zero" bit per hop and signal; a window whose row
-// is empty takes this rare path BEHIND the ordinary epilogue and overwrites that row with the floor, -150 dB + pink
-// (exactly what the epilogue writes for a zero magnitude).  Kept out of the epilogue itself: the hot path's registers.
+// the everyday cases.  The kernels know the level of either row of a window (see "Two rows, one transform" below: level 0 =
+// every sample is +-0; a NaN does not count, its row is garbage either way); a window whose row is empty takes this rare
+// path BEHIND the ordinary epilogue and overwrites that row with the floor, -150 dB + pink (exactly what the epilogue
+// writes for a zero magnitude).  Kept out of the epilogue itself: the hot path's registers.
 __device__ __forceinline__ void fft4096_floor_rows(int t, uint32_t n_bins, float db_offset, const float *__restrict__ offpink,
                                                 float *o_first, float *o_second, bool first_zero, bool second_zero)
 {
@@ -363,11 +370,64 @@ __device__ __forceinline__ void fft4096_floor_columns(int t, uint32_t n_bins, fl
     }
 }
 
-// "is this signal exactly zero over the window?" — bit patterns without the sign (a -0.0 is a zero, a NaN is not)
-__device__ __forceinline__ uint32_t absbits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
-// wave-uniform: some lane holds a non-zero pattern
-__device__ __forceinline__ bool wave_any(uint32_t v) { return __ballot(v != 0u) != 0ull; }
-__device__ __forceinline__ uint32_t lds_uniform(const uint32_t *p) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)*p); }
+// ============================================================================
+//  Two rows, one transform: the block exponent of the second row
+//
+//  The packed kernels carry two real signals a, b on one complex transform, z = (a + i b) hann.  Every twiddle multiply
+//  and every (a - i b)-type butterfly rounds relative to |z|, so the rounding noise of BOTH extracted spectra sits about
+//  134 dB under the LOUDER row: a side signal 40 dB under mid came out 0.04 dB off inside its own 70 dB range — where the
+//  reference, which transforms each signal on its own (tui.rs:1505,1515 -> analyzer.rs:55-65), has its noise 134 dB
+//  under the side row's own peak.  The kernels therefore transform  z = (a + i 2^E b) hann  with E chosen per window so
+//  that the two windowed signals have the same level, and take 2^E out again in the epilogue as a dB offset on the second
+//  row (fft4096_epilogue's side_off).  Powers of two are exact: row b comes out as the transform of b itself would, with
+//  rounding noise relative to max(|a|, |2^E b|) = its own level.
+//
+//  Level of a row = its largest windowed sample magnitude, as a bit pattern (non-negative floats order like unsigned
+//  integers, and the difference of two patterns is 2^23 log2 of the ratio to within 0.09: block_exp).
+//    * k_fft4096_ms1 / k_fft4096_pairw (hop 1024) keep, per hop of 1024 frames, the largest RAW magnitude of either signal
+//      (one wave reduction per entering hop and signal, combined across the four waves through LDS behind a barrier the
+//      pass structure already has).  A window is four hops; the two inner ones carry Hann weights in [1/2, 1], the two outer
+//      ones in [0, 1/2].  While the outer hops are at most twice as loud as the inner ones, the windowed level of a row is
+//      within a factor two of its inner hops' raw level and E follows from those (the ordinary case: no extra work).
+//      Otherwise (an onset or a decay inside the window) the workgroup takes the exact path: largest |sample x weight| over
+//      the window for both rows, one more barrier — rare, and uniform across the workgroup.
+//    * The second signal's registers are kept multiplied by 2^E (ms1) or its window weights are (pairw), and rewritten only
+//      when E moves by two or more: the ordinary window pays for the level of the entering hop, four scalings and two
+//      packed adds per group of bins.
+//    * k_fft4096_ms<HS> / k_fft4096_ms_anyhop (other hops: not the reference's cadence) take the exact path every window.
+//  An all-zero row has no level: E stays, and the row reads the reference's floor (fft4096_floor_rows).
+// ============================================================================
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+// maximum over the wave of a non-negative float's bit pattern; the result stands in lane 63
+__device__ __forceinline__ uint32_t wave_umax_lane63(uint32_t v)
+{
+#define SS_UMAX_DPP(ctrl, rows) v = umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xF, true))
+    SS_UMAX_DPP(0x111, 0xF);    // row_shr:1
+    SS_UMAX_DPP(0x112, 0xF);    // row_shr:2
+    SS_UMAX_DPP(0x114, 0xF);    // row_shr:4
+    SS_UMAX_DPP(0x118, 0xF);    // row_shr:8     lane 15 of every row holds its row's maximum
+    SS_UMAX_DPP(0x142, 0xA);    // row_bcast:15  rows 1 and 3 take in rows 0 and 2
+    SS_UMAX_DPP(0x143, 0xC);    // row_bcast:31  rows 2 and 3 take in lane 31: lane 63 holds the wave's
+#undef SS_UMAX_DPP
+    return v;
+}
+// exponent that lifts a row at level b to a row at level a (bit patterns of positive floats)
+__device__ __forceinline__ int block_exp(uint32_t a, uint32_t b)
+{
+    const int e = ((int)a - (int)b + (1 << 22)) >> 23;
+    return e < -60 ? -60 : (e > 60 ? 60 : e);
+}
+__device__ __forceinline__ float exp2i(int e) { return __uint_as_float((uint32_t)(127 + e) << 23); }      // |e| <= 126
+__device__ __forceinline__ float uniform_f(float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
+// side_off of a block exponent
+__device__ __forceinline__ float block_off(int e) { return uniform_f((float)e * -6.02059991327962390f); }
+// the four waves' level pairs (lv[wave][first, second]) -> the workgroup's, in scalar registers
+__device__ __forceinline__ void read_levels2(const uint32_t (*lv)[2], uint32_t &a, uint32_t &b)
+{
+    const uint4 q0 = *reinterpret_cast<const uint4 *>(&lv[0][0]), q1 = *reinterpret_cast<const uint4 *>(&lv[2][0]);
+    a = (uint32_t)__builtin_amdgcn_readfirstlane((int)umax(umax(q0.x, q0.z), umax(q1.x, q1.z)));
+    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)umax(umax(q0.y, q0.w), umax(q1.y, q1.w)));
+}
 
 // HS = hop / 256.  A workgroup iteration transforms TWO consecutive windows: they share the
 // sliding sample registers (16 + HS slots) and every per-thread constant, and every barrier
@@ -386,7 +446,9 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
     // multiples of 4, so every 16-lane read group hits 16 distinct 4-bank slots)
 #define X2W(kb, ka_, tb_) ((kb) * kPlane + (ka_) * kRow + (tb_))
     __shared__ __attribute__((aligned(16))) v2f tw2s[256];                //  2048 B
-    __shared__ uint32_t zflag[2][4];      // [iteration parity][window 0 mid, side, window 1 mid, side]: some sample is non-zero
+    // exact block exponents ("Two rows, one transform"): [wave][window 0 mid, side, window 1 mid, side] = largest windowed
+    // magnitude of that wave's lanes (bit patterns; 0 = the row is empty and reads the floor)
+    __shared__ __attribute__((aligned(16))) uint32_t xlev4[4][4];
 
     const int t = threadIdx.x;
     const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
@@ -426,24 +488,34 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
         df[j] = v.x - v.y;
     }
 
-    if (t < 8) (&zflag[0][0])[t] = 0u;
+    const uint32_t wvid = (uint32_t)__builtin_amdgcn_readfirstlane(t >> 6);
     __syncthreads();
     for (uint32_t w = w_begin; w < w_end; w += 2) {
         const bool two = (w + 1 < w_end);
-        const uint32_t par = ((w - w_begin) >> 1) & 1u;
-        {   // zero-row flags of this pair (read in the epilogue, behind barriers); the other parity's are cleared for the next
-            uint32_t a0 = 0, d0 = 0, a1 = 0, d1 = 0;
+        // levels of the four rows of this pair of windows, exact: largest |sample x weight| over the workgroup (the loop-end
+        // barrier has retired the previous iteration's reads of xlev4)
+        uint32_t X[4];
+        {
+            float x0 = 0.0f, x1 = 0.0f, x2 = 0.0f, x3 = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 16; j++) { a0 |= absbits(sm[j]); d0 |= absbits(df[j]); a1 |= absbits(sm[j + HS]); d1 |= absbits(df[j + HS]); }
-            const bool w0 = wave_any(a0), w1 = wave_any(d0), w2 = wave_any(a1), w3 = wave_any(d1);
-            if ((t & 63) == 0) {
-                if (w0) zflag[par][0] = 1u;
-                if (w1) zflag[par][1] = 1u;
-                if (w2) zflag[par][2] = 1u;
-                if (w3) zflag[par][3] = 1u;
+            for (int j = 0; j < 16; j++) {
+                x0 = fmaxf(x0, fabsf(sm[j] * hw[j])); x1 = fmaxf(x1, fabsf(df[j] * hw[j]));
+                x2 = fmaxf(x2, fabsf(sm[j + HS] * hw[j])); x3 = fmaxf(x3, fabsf(df[j + HS] * hw[j]));
             }
-            if (t == 64) { zflag[par ^ 1u][0] = 0u; zflag[par ^ 1u][1] = 0u; zflag[par ^ 1u][2] = 0u; zflag[par ^ 1u][3] = 0u; }
+            const uint32_t l0 = wave_umax_lane63(__float_as_uint(x0)), l1 = wave_umax_lane63(__float_as_uint(x1));
+            const uint32_t l2 = wave_umax_lane63(__float_as_uint(x2)), l3 = wave_umax_lane63(__float_as_uint(x3));
+            if ((t & 63) == 63) *reinterpret_cast<uint4 *>(xlev4[wvid]) = make_uint4(l0, l1, l2, l3);
+            __syncthreads();
+            const uint4 q0 = *reinterpret_cast<const uint4 *>(xlev4[0]), q1 = *reinterpret_cast<const uint4 *>(xlev4[1]);
+            const uint4 q2 = *reinterpret_cast<const uint4 *>(xlev4[2]), q3 = *reinterpret_cast<const uint4 *>(xlev4[3]);
+            X[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)umax(umax(q0.x, q1.x), umax(q2.x, q3.x)));
+            X[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)umax(umax(q0.y, q1.y), umax(q2.y, q3.y)));
+            X[2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)umax(umax(q0.z, q1.z), umax(q2.z, q3.z)));
+            X[3] = (uint32_t)__builtin_amdgcn_readfirstlane((int)umax(umax(q0.w, q1.w), umax(q2.w, q3.w)));
         }
+        const int E0 = (X[0] != 0u && X[1] != 0u) ? block_exp(X[0], X[1]) : 0;
+        const int E1 = (X[2] != 0u && X[3] != 0u) ? block_exp(X[2], X[3]) : 0;
+        const float sc0 = exp2i(E0), sc1 = exp2i(E1);
         // prefetch the 2*HS new slots of the next pair (consumed after the epilogue)
         float2 nx[2 * HS];
         const bool more = (w + 2 < w_end), more2 = (w + 3 < w_end);
@@ -459,14 +531,14 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
         // right behind the reads, so one window's LDS writes drain while the other's butterflies issue.
         v2f z0[16], z1[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) z0[j] = v2f{sm[j] * hw[j], df[j] * hw[j]};
+        for (int j = 0; j < 16; j++) z0[j] = v2f{sm[j] * hw[j], df[j] * hw[j] * sc0};
         // ---- pass 1 (the loop-end barrier has retired the previous pair's epilogue reads)
         fft16(z0);
         xbuf[0][X1W(0, tb, hi)] = z0[R16(0)];
 #pragma unroll
         for (int ka = 1; ka < 16; ka++) xbuf[0][X1W(ka, tb, hi)] = pk_cmul(z0[R16(ka)], tw1[ka]);
 #pragma unroll
-        for (int j = 0; j < 16; j++) z1[j] = v2f{sm[j + HS] * hw[j], df[j + HS] * hw[j]};
+        for (int j = 0; j < 16; j++) z1[j] = v2f{sm[j + HS] * hw[j], df[j + HS] * hw[j] * sc1};
         fft16(z1);
         xbuf[1][X1W(0, tb, hi)] = z1[R16(0)];
 #pragma unroll
@@ -505,17 +577,14 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
         __syncthreads();
         // ---- epilogue: groups of four consecutive bins per thread, 16-byte stores
         float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
-        fft4096_epilogue(xbuf[0], t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride);
+        fft4096_epilogue(xbuf[0], t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride, true, nullptr, nullptr, 0, 0.0f, block_off(E0));
         if (two) fft4096_epilogue(xbuf[1], t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid + out_win_stride,
-                                  o_mid + out_win_stride + p.bin_stride);
-        {
-            const uint32_t z0 = lds_uniform(&zflag[par][0]), z1 = lds_uniform(&zflag[par][1]);
-            const uint32_t z2 = lds_uniform(&zflag[par][2]), z3 = lds_uniform(&zflag[par][3]);
-            if (__builtin_expect((z0 & z1) == 0u, 0))
-                fft4096_floor_rows(t, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride, z0 == 0u, z1 == 0u);
-            if (__builtin_expect(two && (z2 & z3) == 0u, 0))
-                fft4096_floor_rows(t, p.n_bins, p.db_offset, p.offpink, o_mid + out_win_stride, o_mid + out_win_stride + p.bin_stride, z2 == 0u, z3 == 0u);
-        }
+                                  o_mid + out_win_stride + p.bin_stride, true, nullptr, nullptr, 0, 0.0f, block_off(E1));
+        // a row whose WINDOWED samples are all zero reads the reference's floor (the transform of zeros, analyzer.rs:20-22)
+        if (__builtin_expect(X[0] == 0u || X[1] == 0u, 0))
+            fft4096_floor_rows(t, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride, X[0] == 0u, X[1] == 0u);
+        if (__builtin_expect(two && (X[2] == 0u || X[3] == 0u), 0))
+            fft4096_floor_rows(t, p.n_bins, p.db_offset, p.offpink, o_mid + out_win_stride, o_mid + out_win_stride + p.bin_stride, X[2] == 0u, X[3] == 0u);
         // ---- slide the sample registers by two hops
         if (more) {
 #pragma unroll
@@ -563,12 +632,14 @@ __device__ unsigned long long g_fft_prof[16];
 template <int HS, bool TW6, bool COLS>
 __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchParams p)
 {
+    constexpr int NH = 16 / HS;                                           // hops per window
     __shared__ __attribute__((aligned(16))) v2f xbuf[16 * kPlaneB];       // 34816 B (the published spectrum uses 32768)
     __shared__ __attribute__((aligned(16))) v2f tw2s[256];                //  2048 B
-    // zero-row detection (see fft4096_floor_rows): [window parity][mid, side][wave] = the window for which that wave's slice of
-    // the signal was all zero.  Only waves whose own slice IS zero ever write or read here — the ordinary window costs a few
-    // ORs, two ballots and scalar arithmetic, no LDS traffic and no barrier.
-    __shared__ __attribute__((aligned(16))) uint32_t zslot[2][2][4];
+    // block exponent of the side row ("Two rows, one transform"): hoplev[hop][wave] = (largest |l + r|, largest |l - r|) of that
+    // wave's lanes over one hop, as bit patterns — row 0 is rewritten for every entering hop, rows 1.. serve the run's first
+    // window once; xlev is the exact path's exchange (largest windowed magnitudes of the window)
+    __shared__ __attribute__((aligned(16))) uint32_t hoplev[NH][4][2];
+    __shared__ __attribute__((aligned(16))) uint32_t xlev[4][2];
     // 8192 B: db_offset + pink per retained bin (n_bins <= 2047 at N = 4096).  Columns-only mode (COLS) uses the room for the
     // bins' chart columns (u16 each) and the two rows' column accumulators instead, and reads the table from global memory.
     __shared__ __attribute__((aligned(16))) float offp[2048];
@@ -623,6 +694,7 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
     const int tsw = SPEC_POS(t);
     const size_t out_win_stride = (size_t)2 * p.bin_stride;
     float *outp = p.out + ((size_t)stream * p.n_windows + w_begin) * out_win_stride;
+    // sm = l + r, df = (l - r) * 2^E  (E: the side row's block exponent; the halving of mid/side is in half_window)
     float sm[16], df[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) {
@@ -630,40 +702,66 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
         sm[j] = v.x + v.y;
         df[j] = v.x - v.y;
     }
-    // zero-row detection (see fft4096_epilogue).  Per hop of HS slots: "some lane of this wave holds a non-zero sample", a
-    // wave-uniform bit, so the window's 16 / HS hop bits per signal live in ONE scalar register (bits 0.. mid, bits 8.. side)
-    // and a slide costs 2 HS ORs and two ballots for the new hop — no vector registers are held for it.
-    constexpr int NH = 16 / HS;
-    uint32_t hopmask = 0u;
+    // levels of the first window's hops (afterwards one hop enters per window); an all-zero row — every level 0 — is the
+    // zero-row case of fft4096_floor_rows, known to the whole workgroup without further exchange
+    const uint32_t wvid = (uint32_t)__builtin_amdgcn_readfirstlane(t >> 6);
+    const bool lane63 = (t & 63) == 63;
 #pragma unroll
     for (int g = 0; g < NH; g++) {
-        uint32_t m = 0u, d = 0u;
+        float m = 0.0f, d = 0.0f;
 #pragma unroll
-        for (int q = 0; q < HS; q++) { m |= absbits(sm[g * HS + q]); d |= absbits(df[g * HS + q]); }
-        hopmask |= (wave_any(m) ? 1u : 0u) << g;
-        hopmask |= (wave_any(d) ? 1u : 0u) << (8 + g);
+        for (int q = 0; q < HS; q++) { m = fmaxf(m, fabsf(sm[g * HS + q])); d = fmaxf(d, fabsf(df[g * HS + q])); }
+        const uint32_t wm = wave_umax_lane63(__float_as_uint(m)), wd = wave_umax_lane63(__float_as_uint(d));
+        if (lane63) *reinterpret_cast<uint2 *>(hoplev[g][wvid]) = make_uint2(wm, wd);
     }
-    if (t < 16) (&zslot[0][0][0])[t] = 0xFFFFFFFFu;
     __syncthreads();
-    const uint32_t wvid = (uint32_t)__builtin_amdgcn_readfirstlane(t >> 6);
-    // a wave publishes "my slice of window wnext is empty" (bit 0: mid, bit 1: side) at the slide of the window before it
-    auto publish_zero = [&](uint32_t zbits, uint32_t parity, uint32_t wnext) {
-        if (__builtin_expect(zbits != 0u, 0)) {
-            if ((t & 63) == 0) {
-                if (zbits & 1u) zslot[parity][0][wvid] = wnext;
-                if (zbits & 2u) zslot[parity][1][wvid] = wnext;
-            }
+    uint32_t Pm[NH], Pd[NH];
+#pragma unroll
+    for (int g = 0; g < NH; g++) read_levels2(hoplev[g], Pm[g], Pd[g]);
+    int E = 0;
+    // block exponent of the window now in the registers (hop levels in Pm / Pd); df is rewritten when it moves by two or more
+    auto settle = [&]() {
+        uint32_t am = 0u, ad = 0u, mm = 0u, md = 0u;
+#pragma unroll
+        for (int g = 0; g < NH; g++) { am |= Pm[g]; ad |= Pd[g]; }
+        if (am == 0u || ad == 0u) return;                   // an empty row has no level: it reads the floor, E stays
+#pragma unroll
+        for (int g = 1; g < NH - 1; g++) { mm = umax(mm, Pm[g]); md = umax(md, Pd[g]); }
+        const uint32_t em = umax(Pm[0], Pm[NH - 1]), ed = umax(Pd[0], Pd[NH - 1]);
+        int T;
+        if (mm != 0u && md != 0u && em <= mm + 0x800000u && ed <= md + 0x800000u) {
+            T = block_exp(mm, md);                          // inner hops carry the level of both rows
+        } else {
+            float xm = 0.0f, xd = 0.0f;                     // exact: largest windowed magnitude of either row
+#pragma unroll
+            for (int j = 0; j < 16; j++) { xm = fmaxf(xm, fabsf(sm[j] * hw[j])); xd = fmaxf(xd, fabsf(df[j] * hw[j])); }
+            const uint32_t wm = wave_umax_lane63(__float_as_uint(xm)), wd = wave_umax_lane63(__float_as_uint(xd));
+            if (lane63) *reinterpret_cast<uint2 *>(xlev[wvid]) = make_uint2(wm, wd);
+            __syncthreads();
+            uint32_t Xm, Xd;
+            read_levels2(xlev, Xm, Xd);
+            if (Xm == 0u || Xd == 0u) return;
+            T = E + block_exp(Xm, Xd);                      // (df carries 2^E already)
+            T = T < -60 ? -60 : (T > 60 ? 60 : T);
+        }
+        const int dE = T - E;
+        if (dE >= 2 || dE <= -2) {
+            const float sc = exp2i(dE);
+#pragma unroll
+            for (int j = 0; j < 16; j++) df[j] *= sc;
+            E = T;
         }
     };
-    auto zero_bits = [&]() -> uint32_t { return ((hopmask & 0xFFu) == 0u ? 1u : 0u) | ((hopmask & 0xFF00u) == 0u ? 2u : 0u); };
-    publish_zero(zero_bits(), 0u, w_begin);
+    settle();
     SS_FPROF_DECL
     for (uint32_t w = w_begin; w < w_end; ++w) {
         float2 nx[HS];
         const bool more = (w + 1 < w_end);
-        const uint32_t par = (w - w_begin) & 1u;
         if (COLS && w != w_begin) flush_columns(w - 1);      // (its next atomics are four barriers away)
-        const uint32_t curz = zero_bits();                   // this wave's slice of THIS window (hopmask moves on at the slide)
+        uint32_t am = 0u, ad = 0u;                           // THIS window's rows (the levels move on at the slide)
+#pragma unroll
+        for (int g = 0; g < NH; g++) { am |= Pm[g]; ad |= Pd[g]; }
+        const bool zrow_m = am == 0u, zrow_d = ad == 0u;
         v2f z[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) z[j] = v2f{sm[j] * hw[j], df[j] * hw[j]};
@@ -720,9 +818,24 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
                 for (int j = 0; j < 4; j++) twa[j] = twb[j];
             }
         }
+        // the entering hop (requested a pass ago; the transform's registers are dead here): sums and differences in place of
+        // the raw frames, and their levels to the workgroup — read back behind the next barrier, used at the slide
+        float sn[HS], dn[HS];
+        {
+            float m = 0.0f, d = 0.0f;
+#pragma unroll
+            for (int q = 0; q < HS; q++) {
+                sn[q] = nx[q].x + nx[q].y; dn[q] = nx[q].x - nx[q].y;
+                m = fmaxf(m, fabsf(sn[q])); d = fmaxf(d, fabsf(dn[q]));
+            }
+            const uint32_t wm = wave_umax_lane63(__float_as_uint(m)), wd = wave_umax_lane63(__float_as_uint(d));
+            if (lane63) *reinterpret_cast<uint2 *>(hoplev[0][wvid]) = make_uint2(wm, wd);
+        }
         SS_FPROF_MARK(4);
         __syncthreads();
         SS_FPROF_MARK(5);
+        uint32_t nPm, nPd;
+        read_levels2(hoplev[0], nPm, nPd);
 #pragma unroll
         for (int q = 0; q < 16; q++) z[q] = lds_ld64(&xbuf[X2W(hi, tb, q)]);
         SS_FPROF_MARK(6);
@@ -738,33 +851,25 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
         __syncthreads();
         SS_FPROF_MARK(9);
         SS_PRIO_LO();
+        const float soff = block_off(E);                     // THIS window's side row rode the transform as side * 2^E
         // the sliding registers take the prefetched hop before the epilogue's stores (see fft4096_epilogue)
         if (more) {
 #pragma unroll
             for (int j = 0; j < 16 - HS; j++) { sm[j] = sm[j + HS]; df[j] = df[j + HS]; }
-            uint32_t nm = 0u, nd = 0u;
+            const float scE = exp2i(E);
 #pragma unroll
-            for (int q = 0; q < HS; q++) {
-                sm[16 - HS + q] = nx[q].x + nx[q].y; df[16 - HS + q] = nx[q].x - nx[q].y;
-                nm |= __float_as_uint(sm[16 - HS + q]); nd |= __float_as_uint(df[16 - HS + q]);
-            }
-            nm &= 0x7fffffffu; nd &= 0x7fffffffu;            // (a -0.0 is a zero: the sign is dropped once, after the ORs)
-            hopmask = ((hopmask >> 1) & 0x7F7Fu) | ((wave_any(nm) ? 1u : 0u) << (NH - 1)) | ((wave_any(nd) ? 1u : 0u) << (8 + NH - 1));
-            publish_zero(zero_bits(), par ^ 1u, w + 1);
+            for (int q = 0; q < HS; q++) { sm[16 - HS + q] = sn[q]; df[16 - HS + q] = dn[q] * scE; }
+#pragma unroll
+            for (int g = 0; g < NH - 1; g++) { Pm[g] = Pm[g + 1]; Pd[g] = Pd[g + 1]; }
+            Pm[NH - 1] = nPm; Pd[NH - 1] = nPd;
+            settle();
         }
         float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
-        if (COLS) fft4096_epilogue<false, true>(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, nullptr, nullptr, true, colbuf, bincol, p.cols, cgain);
-        else fft4096_epilogue<true>(xbuf, t, p.first_bin, p.n_bins, p.db_offset, offp, o_mid, o_mid + p.bin_stride);
-        if (__builtin_expect(curz != 0u, 0)) {
-            // my slice is empty: is everybody's?  (every wave of an empty row arrives here and reads the same four slots)
-            bool z0 = false, z1 = false;
-            if (curz & 1u) { const uint4 q = *reinterpret_cast<const uint4 *>(zslot[par][0]); z0 = q.x == w && q.y == w && q.z == w && q.w == w; }
-            if (curz & 2u) { const uint4 q = *reinterpret_cast<const uint4 *>(zslot[par][1]); z1 = q.x == w && q.y == w && q.z == w && q.w == w; }
-            z0 = __builtin_amdgcn_readfirstlane(z0) != 0; z1 = __builtin_amdgcn_readfirstlane(z1) != 0;
-            if (z0 || z1) {
-                if (!COLS) fft4096_floor_rows(t, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride, z0, z1);
-                else fft4096_floor_columns(t, p.n_bins, p.db_offset, p.offpink, colbuf, bincol, p.cols, cgain, z0, z1);
-            }
+        if (COLS) fft4096_epilogue<false, true>(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, nullptr, nullptr, true, colbuf, bincol, p.cols, cgain, soff);
+        else fft4096_epilogue<true>(xbuf, t, p.first_bin, p.n_bins, p.db_offset, offp, o_mid, o_mid + p.bin_stride, true, nullptr, nullptr, 0, 0.0f, soff);
+        if (__builtin_expect(zrow_m || zrow_d, 0)) {
+            if (!COLS) fft4096_floor_rows(t, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride, zrow_m, zrow_d);
+            else fft4096_floor_columns(t, p.n_bins, p.db_offset, p.offpink, colbuf, bincol, p.cols, cgain, zrow_m, zrow_d);
         }
         SS_FPROF_MARK(10);
         __syncthreads();
@@ -777,16 +882,19 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
 }
 
 // One REAL channel (mono buffers, or channel `ch` of an interleaved one) at hop 1024: two consecutive windows w, w + 1
-// ride one complex transform the way mid and side do — z[n] = (x[n] + i x[n + 1024]) hann[n] — so the "mid" row of
+// ride one complex transform the way mid and side do — z[n] = (x[n] + i 2^E x[n + 1024]) hann[n] — so the "mid" row of
 // the epilogue is window w and the "side" row window w + 1, and the whole of k_fft4096_ms1 carries over.  A workgroup
-// walks window PAIRS; the sliding registers hold 20 slots and advance by 8 (2048 frames) per iteration.
+// walks window PAIRS; the sliding registers hold 20 slots and advance by 8 (2048 frames) per iteration.  E is the second
+// window's block exponent ("Two rows, one transform": a fade-in, or a programme behind a quiet passage, puts the two
+// windows at different levels); it lives in the second row's window weights hw2 = 2^E hann.
 __global__ __launch_bounds__(256, SS_FFT_PAIRW_WAVES) void k_fft4096_pairw(FftBatchParams p, uint32_t fft_ch)
 {
     __shared__ __attribute__((aligned(16))) v2f xbuf[16 * kPlaneB];       // 34816 B
     __shared__ __attribute__((aligned(16))) v2f tw2s[256];                //  2048 B
-    // zero-row detection as in k_fft4096_ms1: [pair parity][first, second window][wave] = the pair for which that wave's slice
-    // of the window was all zero (only waves whose own slice is empty ever touch it)
-    __shared__ __attribute__((aligned(16))) uint32_t zslot[2][2][4];
+    // hoplev[hop][wave] = largest |sample| of that wave's lanes over one hop (bit pattern): rows 0, 1 are rewritten for the two
+    // hops that enter per pair, rows 0..4 serve the run's first pair once; xlev[wave] = (first, second) window, exact path
+    __shared__ __attribute__((aligned(16))) uint32_t hoplev[5][4];
+    __shared__ __attribute__((aligned(16))) uint32_t xlev[4][2];
 #define X1W(ka, tb_, ta_) ((ka) * kPlaneB + (tb_) * kRowB + (ta_))
 #define X2W(kb, ka_, tb_) ((kb) * kPlaneB + (ka_) * kRowB + (tb_))
     const int t = threadIdx.x;
@@ -809,9 +917,9 @@ __global__ __launch_bounds__(256, SS_FFT_PAIRW_WAVES) void k_fft4096_pairw(FftBa
     const uint32_t C = p.channels;
     const float *src = p.pcm + ((size_t)stream * p.frames_per_stream + p.first_start + (size_t)pp_begin * 2048u) * C + ch;
     const v2f *twn = reinterpret_cast<const v2f *>(p.tw_n);
-    float hw[16];
+    float hw[16], hw2[16];
 #pragma unroll
-    for (int j = 0; j < 16; j++) hw[j] = p.window[t + 256 * j];           // the full Hann window: no mid/side halving here
+    for (int j = 0; j < 16; j++) hw2[j] = hw[j] = p.window[t + 256 * j];  // the full Hann window: no mid/side halving here
     v2f tw1[16];
     tw1[1] = twn[t]; tw1[2] = twn[2 * t]; tw1[3] = twn[3 * t];
     tw1[4] = twn[4 * t]; tw1[8] = twn[8 * t]; tw1[12] = twn[12 * t];
@@ -825,31 +933,60 @@ __global__ __launch_bounds__(256, SS_FFT_PAIRW_WAVES) void k_fft4096_pairw(FftBa
     const bool two0 = (2u * pp_begin + 1u < n_win);
 #pragma unroll
     for (int j = 0; j < 20; j++) raw[j] = (j < 16 || two0) ? src[(size_t)(t + 256 * j) * C] : 0.0f;
-    // zero-row detection (see fft4096_epilogue and k_fft4096_ms1): one wave-uniform bit per hop of four slots; the first
-    // window is hops 0..3, the second hops 1..4
-    uint32_t hopmask = 0u;
-#pragma unroll
-    for (int g = 0; g < 5; g++)
-        hopmask |= (wave_any(absbits(raw[4 * g]) | absbits(raw[4 * g + 1]) | absbits(raw[4 * g + 2]) | absbits(raw[4 * g + 3])) ? 1u : 0u) << g;
-    if (t < 16) (&zslot[0][0][0])[t] = 0xFFFFFFFFu;
-    __syncthreads();
+    // levels of the five hops of the first pair (the first window is hops 0..3, the second hops 1..4); an all-zero window —
+    // every level 0 — is the zero-row case of fft4096_floor_rows
     const uint32_t wvid = (uint32_t)__builtin_amdgcn_readfirstlane(t >> 6);
-    auto zero_bits = [&]() -> uint32_t { return ((hopmask & 0x0Fu) == 0u ? 1u : 0u) | ((hopmask & 0x1Eu) == 0u ? 2u : 0u); };
-    auto publish_zero = [&](uint32_t zbits, uint32_t parity, uint32_t pnext) {
-        if (__builtin_expect(zbits != 0u, 0)) {
-            if ((t & 63) == 0) {
-                if (zbits & 1u) zslot[parity][0][wvid] = pnext;
-                if (zbits & 2u) zslot[parity][1][wvid] = pnext;
-            }
+    const bool lane63 = (t & 63) == 63;
+    auto hop_level = [&](float a, float b, float c, float d) -> uint32_t {
+        return wave_umax_lane63(__float_as_uint(fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d)))));
+    };
+    auto read_level = [&](const uint32_t *lv) -> uint32_t {
+        const uint4 q = *reinterpret_cast<const uint4 *>(lv);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)umax(umax(q.x, q.y), umax(q.z, q.w)));
+    };
+#pragma unroll
+    for (int g = 0; g < 5; g++) {
+        const uint32_t wl = hop_level(raw[4 * g], raw[4 * g + 1], raw[4 * g + 2], raw[4 * g + 3]);
+        if (lane63) hoplev[g][wvid] = wl;
+    }
+    __syncthreads();
+    uint32_t P[5];
+#pragma unroll
+    for (int g = 0; g < 5; g++) P[g] = read_level(hoplev[g]);
+    int E = 0;
+    // block exponent of the pair now in the registers; hw2 is rewritten when it moves by two or more
+    auto settle = [&]() {
+        if ((P[0] | P[1] | P[2] | P[3]) == 0u || (P[1] | P[2] | P[3] | P[4]) == 0u) return;      // an empty window has no level
+        const uint32_t ma = umax(P[1], P[2]), ea = umax(P[0], P[3]), mb = umax(P[2], P[3]), eb = umax(P[1], P[4]);
+        int T;
+        if (ma != 0u && mb != 0u && ea <= ma + 0x800000u && eb <= mb + 0x800000u) {
+            T = block_exp(ma, mb);
+        } else {
+            float xa = 0.0f, xb = 0.0f;                     // exact: largest windowed magnitude of either window
+#pragma unroll
+            for (int j = 0; j < 16; j++) { xa = fmaxf(xa, fabsf(raw[j] * hw[j])); xb = fmaxf(xb, fabsf(raw[j + 4] * hw[j])); }
+            const uint32_t wa = wave_umax_lane63(__float_as_uint(xa)), wb = wave_umax_lane63(__float_as_uint(xb));
+            if (lane63) *reinterpret_cast<uint2 *>(xlev[wvid]) = make_uint2(wa, wb);
+            __syncthreads();
+            uint32_t Xa, Xb;
+            read_levels2(xlev, Xa, Xb);
+            if (Xa == 0u || Xb == 0u) return;
+            T = block_exp(Xa, Xb);
+        }
+        const int dE = T - E;
+        if (dE >= 2 || dE <= -2) {
+            const float sc = exp2i(T);
+#pragma unroll
+            for (int j = 0; j < 16; j++) hw2[j] = hw[j] * sc;
+            E = T;
         }
     };
-    publish_zero(zero_bits(), 0u, pp_begin);
+    settle();
     for (uint32_t pp = pp_begin; pp < pp_end; ++pp) {
         const bool two = (2u * pp + 1u < n_win);
         const bool more = (pp + 1 < pp_end);
         const bool more2 = more && (2u * pp + 3u < n_win);
-        const uint32_t par = (pp - pp_begin) & 1u;
-        const uint32_t curz = zero_bits();                 // this wave's slices of THIS pair (hopmask moves on at the slide)
+        const bool zrow_a = (P[0] | P[1] | P[2] | P[3]) == 0u, zrow_b = (P[1] | P[2] | P[3] | P[4]) == 0u;     // THIS pair's windows
         float nx[8];
         const float *nsrc = src + ((size_t)(pp - pp_begin) * 2048u + t) * C;
 #pragma unroll
@@ -859,7 +996,7 @@ __global__ __launch_bounds__(256, SS_FFT_PAIRW_WAVES) void k_fft4096_pairw(FftBa
         }
         v2f z[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) z[j] = v2f{raw[j] * hw[j], raw[j + 4] * hw[j]};
+        for (int j = 0; j < 16; j++) z[j] = v2f{raw[j] * hw[j], raw[j + 4] * hw2[j]};
         SS_PRIO_LO();
         fft16(z);
         SS_PRIO_HI();
@@ -899,7 +1036,12 @@ __global__ __launch_bounds__(256, SS_FFT_PAIRW_WAVES) void k_fft4096_pairw(FftBa
                 for (int j = 0; j < 4; j++) twa[j] = twb[j];
             }
         }
+        {   // the two entering hops' levels to the workgroup (read back behind the next barrier, used at the slide)
+            const uint32_t wl0 = hop_level(nx[0], nx[1], nx[2], nx[3]), wl1 = hop_level(nx[4], nx[5], nx[6], nx[7]);
+            if (lane63) { hoplev[0][wvid] = wl0; hoplev[1][wvid] = wl1; }
+        }
         __syncthreads();
+        const uint32_t nP0 = read_level(hoplev[0]), nP1 = read_level(hoplev[1]);
 #pragma unroll
         for (int q = 0; q < 16; q++) z[q] = lds_ld64(&xbuf[X2W(hi, tb, q)]);
         __syncthreads();
@@ -912,22 +1054,16 @@ __global__ __launch_bounds__(256, SS_FFT_PAIRW_WAVES) void k_fft4096_pairw(FftBa
         __syncthreads();
         SS_PRIO_LO();
         float *o_first = outp + (size_t)(pp - pp_begin) * 2u * row_stride;
-        fft4096_epilogue(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_first, o_first + row_stride, two);
-        if (__builtin_expect(curz != 0u, 0)) {
-            bool z0 = false, z1 = false;
-            if (curz & 1u) { const uint4 q = *reinterpret_cast<const uint4 *>(zslot[par][0]); z0 = q.x == pp && q.y == pp && q.z == pp && q.w == pp; }
-            if (curz & 2u) { const uint4 q = *reinterpret_cast<const uint4 *>(zslot[par][1]); z1 = q.x == pp && q.y == pp && q.z == pp && q.w == pp; }
-            z0 = __builtin_amdgcn_readfirstlane(z0) != 0; z1 = __builtin_amdgcn_readfirstlane(z1) != 0;
-            if (z0 || (two && z1)) fft4096_floor_rows(t, p.n_bins, p.db_offset, p.offpink, o_first, o_first + row_stride, z0, two && z1);
-        }
+        fft4096_epilogue(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_first, o_first + row_stride, two, nullptr, nullptr, 0, 0.0f, block_off(E));
+        if (__builtin_expect(zrow_a || (two && zrow_b), 0))
+            fft4096_floor_rows(t, p.n_bins, p.db_offset, p.offpink, o_first, o_first + row_stride, zrow_a, two && zrow_b);
         if (more) {
 #pragma unroll
             for (int j = 0; j < 12; j++) raw[j] = raw[j + 8];
 #pragma unroll
             for (int q = 0; q < 8; q++) raw[12 + q] = nx[q];
-            hopmask = (hopmask >> 2) | ((wave_any(absbits(nx[0]) | absbits(nx[1]) | absbits(nx[2]) | absbits(nx[3])) ? 1u : 0u) << 3) |
-                      ((wave_any(absbits(nx[4]) | absbits(nx[5]) | absbits(nx[6]) | absbits(nx[7])) ? 1u : 0u) << 4);
-            publish_zero(zero_bits(), par ^ 1u, pp + 1);
+            P[0] = P[2]; P[1] = P[3]; P[2] = P[4]; P[3] = nP0; P[4] = nP1;
+            settle();
         }
         __syncthreads();
     }
@@ -952,7 +1088,7 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms_anyhop(FftBatc
 {
     __shared__ __attribute__((aligned(16))) v2f xbuf[16 * kX1Stride];
     __shared__ __attribute__((aligned(16))) v2f tw2s[256];
-    __shared__ uint32_t zflag[2][2];      // [window parity][mid, side]: some sample of the window's signal is non-zero
+    __shared__ __attribute__((aligned(16))) uint32_t xlev[4][2];      // exact block exponent: [wave][mid, side] largest windowed magnitude
     const int t = threadIdx.x;
     const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
     const uint32_t stream = blockIdx.x / groups;
@@ -968,27 +1104,32 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms_anyhop(FftBatc
     const int tb = t & 15, hi = t >> 4;
     const size_t out_win_stride = (size_t)2 * p.bin_stride;
     float *outp = p.out + ((size_t)stream * p.n_windows + w_begin) * out_win_stride;
-    if (t < 4) (&zflag[0][0])[t] = 0u;
+    const uint32_t wvid = (uint32_t)__builtin_amdgcn_readfirstlane(t >> 6);
     __syncthreads();
     for (uint32_t w = w_begin; w < w_end; ++w) {
         v2f z[16];
-        uint32_t am = 0u, ad = 0u;
-        const uint32_t par = (w - w_begin) & 1u;
+        float xm = 0.0f, xd = 0.0f;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const float2 v = src[(size_t)(w - w_begin) * p.hop + t + 256 * j];
             const float hwj = p.half_window[t + 256 * j];
-            const float sv = v.x + v.y, dv = v.x - v.y;
-            am |= absbits(sv); ad |= absbits(dv);
-            z[j] = v2f{sv * hwj, dv * hwj};
+            z[j] = v2f{(v.x + v.y) * hwj, (v.x - v.y) * hwj};
+            xm = fmaxf(xm, fabsf(z[j].x)); xd = fmaxf(xd, fabsf(z[j].y));
         }
+        // exact block exponent of the side row ("Two rows, one transform"); the previous window's reads of xlev lie behind
+        // the barriers of its transform
+        uint32_t Xm, Xd;
         {
-            const bool wm = wave_any(am), wd = wave_any(ad);
-            if ((t & 63) == 0) {
-                if (wm) zflag[par][0] = 1u;
-                if (wd) zflag[par][1] = 1u;
-            }
-            if (t == 64) { zflag[par ^ 1u][0] = 0u; zflag[par ^ 1u][1] = 0u; }      // (uniform addresses: nothing per-lane to keep in a register)
+            const uint32_t wm = wave_umax_lane63(__float_as_uint(xm)), wd = wave_umax_lane63(__float_as_uint(xd));
+            if ((t & 63) == 63) *reinterpret_cast<uint2 *>(xlev[wvid]) = make_uint2(wm, wd);
+            __syncthreads();
+            read_levels2(xlev, Xm, Xd);
+        }
+        const int E = (Xm != 0u && Xd != 0u) ? block_exp(Xm, Xd) : 0;
+        {
+            const float sc = exp2i(E);
+#pragma unroll
+            for (int j = 0; j < 16; j++) z[j].y *= sc;
         }
         fft16(z);
         __syncthreads();
@@ -1012,12 +1153,9 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms_anyhop(FftBatc
         for (int kc = 0; kc < 16; kc++) xbuf[kc * 256 + SPEC_POS(t)] = z[R16(kc)];
         __syncthreads();
         float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
-        fft4096_epilogue(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride);
-        {
-            const uint32_t z0 = lds_uniform(&zflag[par][0]), z1 = lds_uniform(&zflag[par][1]);
-            if (__builtin_expect((z0 & z1) == 0u, 0))
-                fft4096_floor_rows(t, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride, z0 == 0u, z1 == 0u);
-        }
+        fft4096_epilogue(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride, true, nullptr, nullptr, 0, 0.0f, block_off(E));
+        if (__builtin_expect(Xm == 0u || Xd == 0u, 0))
+            fft4096_floor_rows(t, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride, Xm == 0u, Xd == 0u);
     }
 }
 

@@ -3,7 +3,9 @@ its bins lies more than ~60 dB under its window's loudest bin; here the inputs a
   * pure tones WITHOUT noise, bin-centred and off-bin, at N = 4096 and 16384 (Hann side lobes down to the rounding noise);
   * a programme scaled by 2^-20 and 2^-40 (exact scaling: every dB value must move by exactly k * 6.0206 dB);
   * windows of a near-silent passage (x 1e-4) held to the same peak-relative bar as loud ones;
-  * narrow stereo (side 40 dB under mid) and dual mono (L == R, L == -R) through the packed mid/side kernels.
+  * narrow stereo (side 20 .. 120 dB under mid, and the other way round), side-only onsets, level steps, fades and onsets
+    between the two windows of k_fft4096_pairw — every row against its OWN peak (block exponents, DESIGN section 6);
+  * dual mono (L == R, L == -R) through the packed mid/side kernels.
 Bar (conftest.db_close): 0.01 dB for every bin within 70 dB of its row's loudest bin, 1e-4 of that bin's amplitude below.
 """
 import numpy as np
@@ -114,30 +116,129 @@ def test_near_silent_passage_at_the_peak_relative_bar(oracle):
         b.close()
 
 
-@pytest.mark.parametrize("n", [4096, 16384])
-def test_narrow_stereo_rows_share_one_transform(oracle, n):
-    """Mid and side of the packed kernels ride ONE complex transform, so the weaker row's rounding noise is set by the
-    stronger row: with the side signal 40 dB under the mid signal, the side row is held to 0.01 dB down to 70 dB under the
-    PAIR's loudest bin (= 30 dB under its own), and its own-peak figures are printed (DESIGN section 6 quotes them)."""
-    rate, frames = 48000, n + 1024 * 10
-    rng = np.random.default_rng(9)
+def _programme(rng, frames, rate, f0, amp=0.4, noise=0.05):
     t = np.arange(frames) / rate
-    m = (0.4 * np.sin(2 * np.pi * 523.0 * t) + 0.05 * rng.uniform(-1, 1, frames)).astype(np.float32)
-    s = (0.01 * (0.4 * np.sin(2 * np.pi * 1777.0 * t) + 0.05 * rng.uniform(-1, 1, frames))).astype(np.float32)
-    x = np.empty(2 * frames, np.float32); x[0::2] = m + s; x[1::2] = m - s
-    b = ssa.Batch(rate, 2, 1, frames, n, 1024, flags=L.SS_BATCH_FFT)
+    return amp * np.sin(2 * np.pi * f0 * t) + noise * rng.uniform(-1, 1, frames)
+
+
+def _stereo_from_mid_side(m, s):
+    x = np.empty(2 * len(m), np.float32)
+    x[0::2] = (m + s).astype(np.float32); x[1::2] = (m - s).astype(np.float32)
+    return x
+
+
+def _check_every_row(oracle, x, rate, channels, n, hop, tag):
+    """Every window row of the batch spectrum against the oracle at the plain per-row bar (its OWN peak); returns the worst
+    (|d| within 70 dB of the row peak, linear error below) per row index."""
+    frames = len(x) // channels
+    b = ssa.Batch(rate, channels, 1, frames, n, hop, flags=L.SS_BATCH_FFT)
     b.upload(0, x); b.run(); b.sync()
     got = b.fft(0)
-    ref = oracle.analyze_stream(rate, x, n, 1024, want_wave=False)["fft"]
-    own = (0.0, 0.0)
+    if channels == 2:
+        ref = oracle.analyze_stream(rate, x, n, hop, want_wave=False)["fft"]
+    else:
+        lay = b.layout
+        xc = x.reshape(-1, channels)
+        ref = np.empty_like(got, dtype=np.float64)
+        for w in range(lay.n_windows):
+            p0 = (w + 1) * hop                                  # the reference skips the window whose left bound is 0 (tui.rs:1489)
+            for c in range(channels):
+                ref[w, c] = oracle.get_fft(rate, np.ascontiguousarray(xc[p0:p0 + n, c]))[:, 1]
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    worst = np.zeros((got.shape[1], 2))
     for w in range(got.shape[0]):
-        pair_peak = float(ref[w].max())
-        assert db_close(got[w, 0], ref[w, 0]), (n, w, db_report(got[w, 0], ref[w, 0]))
-        assert db_close(got[w, 1], ref[w, 1], peak_db=pair_peak), (n, w)
-        r = db_report(got[w, 1], ref[w, 1])
-        own = (max(own[0], r[0]), max(own[1], r[1]))
-    print(f"\\nN={n}: side row 40 dB under mid, against its OWN peak: worst |d| within 70 dB {own[0]:.4f} dB, linear below {own[1]:.2e}")
+        for c in range(got.shape[1]):
+            assert db_close(got[w, c], ref[w, c]), (tag, n, hop, w, c, db_report(got[w, c], ref[w, c]))
+            worst[c] = np.maximum(worst[c], db_report(got[w, c], ref[w, c]))
     b.close()
+    return worst
+
+
+@pytest.mark.parametrize("n,hop", [(4096, 1024), (4096, 512), (4096, 2048), (4096, 768), (16384, 1024)])
+@pytest.mark.parametrize("under_db", [20, 40, 60, 120, -40])
+def test_narrow_stereo_rows_keep_their_own_bar(oracle, n, hop, under_db):
+    """Mid and side of the packed N = 4096 kernels ride ONE complex transform.  The side signal `under_db` under the mid
+    signal (-40: the MID signal 40 dB under side, L ~ -R) is held to the plain bar against its OWN loudest bin, every window —
+    the reference transforms each signal on its own (tui.rs:1505,1515 -> analyzer.rs:55-65).  The kernels give the weaker row
+    a power-of-two block exponent per window: hop 1024 from the hop levels (k_fft4096_ms1), the other
+    hops from the exact windowed levels (k_fft4096_ms<2>, <8>, _anyhop); N = 16384 transforms each signal alone."""
+    rate, frames = 48000, n + hop * 14
+    rng = np.random.default_rng(9)
+    m = _programme(rng, frames, rate, 523.0)
+    s = _programme(rng, frames, rate, 1777.0) * 10.0 ** (-abs(under_db) / 20.0)
+    if under_db < 0:
+        m, s = s, m
+    worst = _check_every_row(oracle, _stereo_from_mid_side(m, s), rate, 2, n, hop, f"under {under_db}")
+    print(f"\nN={n} hop={hop} side {under_db} dB under mid: mid row worst {worst[0][0]:.5f} dB / {worst[0][1]:.1e}, side row worst {worst[1][0]:.5f} dB / {worst[1][1]:.1e}")
+
+
+@pytest.mark.parametrize("hop", [1024, 512])
+def test_narrow_stereo_pure_tones(oracle, hop):
+    """The same without noise: both rows are pure tones, so each has bins all the way down to 70 dB under its own peak (Hann
+    side lobes), the side row 40 dB under the mid row."""
+    rate, n = 48000, 4096
+    frames = n + hop * 12
+    t = np.arange(frames) / rate
+    m = 0.5 * np.sin(2 * np.pi * (40.37 * rate / n) * t + 0.3)
+    s = 0.005 * np.sin(2 * np.pi * (151.41 * rate / n) * t + 1.1)
+    worst = _check_every_row(oracle, _stereo_from_mid_side(m, s), rate, 2, n, hop, "pure tones")
+    print(f"\nhop={hop} pure tones, side 40 dB under mid: mid {worst[0][0]:.5f} dB / {worst[0][1]:.1e}, side {worst[1][0]:.5f} dB / {worst[1][1]:.1e}")
+
+
+@pytest.mark.parametrize("onset", [1024 * 9 + 1000, 1024 * 9 + 700, 1024 * 9 + 40, 1024 * 10 - 3])
+def test_side_only_onset_inside_a_window(oracle, onset):
+    """A wide (side-only) element that starts abruptly while the centre plays on: for one window the side row's energy sits
+    in the last few samples of the window, under Hann weights near zero — its windowed level is far below what its hop's raw
+    level says.  k_fft4096_ms1 takes the exact path there (largest |sample x weight| of either row).  The decay is the mirror
+    case: the side element stops abruptly, and its tail leaves through the first samples of later windows."""
+    rate, n = 48000, 4096
+    frames = n + 1024 * 24
+    rng = np.random.default_rng(21)
+    m = _programme(rng, frames, rate, 440.0)
+    s = _programme(rng, frames, rate, 2500.0, amp=0.3, noise=0.02)
+    s[:onset] = 0.0                                      # digital silence in the side signal up to the onset ...
+    s[onset + 1024 * 9 + 511:] *= 1e-5                   # ... and an abrupt drop by 100 dB later on
+    _check_every_row(oracle, _stereo_from_mid_side(m, s), rate, 2, n, 1024, f"onset {onset}")
+
+
+def test_side_level_steps_both_ways(oracle):
+    """The block exponent follows the programme: the side signal drops by 50 dB, comes back, and finally exceeds the mid signal by
+    30 dB (the exponent changes sign); every window of both rows at the plain bar."""
+    rate, n = 48000, 4096
+    frames = n + 1024 * 60
+    rng = np.random.default_rng(33)
+    m = _programme(rng, frames, rate, 700.0)
+    s = _programme(rng, frames, rate, 3100.0) * 0.1
+    q = frames // 4
+    s[q:2 * q] *= 10.0 ** (-50 / 20)
+    m[3 * q:] *= 10.0 ** (-50 / 20)
+    _check_every_row(oracle, _stereo_from_mid_side(m, s), rate, 2, n, 1024, "steps")
+
+
+@pytest.mark.parametrize("channels", [1, 6])
+@pytest.mark.parametrize("kind", ["fade_in", "fade_out", "onset", "steps"])
+def test_pair_kernel_windows_at_different_levels(oracle, channels, kind):
+    """k_fft4096_pairw rides two CONSECUTIVE windows of one channel on one transform: a fade (2.5 dB per hop), an abrupt onset
+    at an arbitrary sample and 40 dB level steps put the two windows of a pair at different levels.  Every window at the plain
+    bar against its own peak (the second window of a pair carries a block exponent)."""
+    rate, n = 48000, 4096
+    frames = n + 1024 * 41 + 17
+    rng = np.random.default_rng(55)
+    x = np.empty((frames, channels), np.float32)
+    hops = np.arange(frames) / 1024.0
+    for c in range(channels):
+        y = _programme(rng, frames, rate, 300.0 + 170.0 * c, amp=0.3, noise=0.03)
+        if kind == "fade_in":
+            y *= 10.0 ** (np.minimum(0.0, -90.0 + 2.5 * hops) / 20.0)
+        elif kind == "fade_out":
+            y *= 10.0 ** (np.minimum(0.0, -2.5 * (hops - 8.0 - c)) / 20.0)
+        elif kind == "onset":
+            y[:1024 * 11 + 333 * c + 5] *= 1e-6
+        else:
+            for k in range(0, frames, 1024 * 7):
+                y[k:k + 1024 * 3 + 100 * c] *= 0.01
+        x[:, c] = y.astype(np.float32)
+    _check_every_row(oracle, x.reshape(-1), rate, channels, n, 1024, kind)
 
 
 @pytest.mark.parametrize("n", [4096, 16384])
