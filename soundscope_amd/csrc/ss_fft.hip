@@ -80,6 +80,23 @@ __device__ __forceinline__ v2f pk_mul_mi(v2f a)
     return r;
 }
 
+// a * w.lo (S = 0) or a * w.hi (S = 1) in both halves: one real weight out of a register pair that holds two
+template <int S>
+__device__ __forceinline__ v2f pk_mul_bcast(v2f a, v2f w)
+{
+    v2f r;
+    if (S == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(w));
+    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(w));
+    return r;
+}
+// (l + r, l - r) of one stereo frame (l, r)
+__device__ __forceinline__ v2f pk_sum_diff(v2f f)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(f));
+    return r;
+}
+
 // forward radix-4 butterfly on (a0,a1,a2,a3) in place: A_k = sum_j a_j (-i)^(jk)  — 8 packed adds
 __device__ __forceinline__ void radix4(v2f &a0, v2f &a1, v2f &a2, v2f &a3)
 {
@@ -659,9 +676,10 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
     const float2 *src = reinterpret_cast<const float2 *>(p.pcm) + (size_t)stream * p.frames_per_stream +
                         p.first_start + (size_t)w_begin * p.hop;
     const v2f *twn = reinterpret_cast<const v2f *>(p.tw_n);
-    float hw[16];
+    // the sixteen half-window weights, two to a register pair (one packed multiply windows a frame's sum and difference)
+    v2f hwp[8];
 #pragma unroll
-    for (int j = 0; j < 16; j++) hw[j] = p.half_window[t + 256 * j];
+    for (int j = 0; j < 8; j++) hwp[j] = v2f{p.half_window[t + 256 * (2 * j)], p.half_window[t + 256 * (2 * j + 1)]};
     v2f tw1[16];
     if (TW6) {
         tw1[1] = twn[t]; tw1[2] = twn[2 * t]; tw1[3] = twn[3 * t];
@@ -694,77 +712,103 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
     const int tsw = SPEC_POS(t);
     const size_t out_win_stride = (size_t)2 * p.bin_stride;
     float *outp = p.out + ((size_t)stream * p.n_windows + w_begin) * out_win_stride;
-    // sm = l + r, df = (l - r) * 2^E  (E: the side row's block exponent; the halving of mid/side is in half_window)
-    float sm[16], df[16];
+    // sd[j] = (l + r, (l - r) * 2^E) of frame t + 256 j  (E: the side row's block exponent; the halving of mid/side is in
+    // half_window) — a register pair per frame: windowing is one packed multiply, the slide one 64-bit move
+    v2f sd[16];
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const float2 v = src[t + 256 * j];
-        sm[j] = v.x + v.y;
-        df[j] = v.x - v.y;
-    }
-    // levels of the first window's hops (afterwards one hop enters per window); an all-zero row — every level 0 — is the
-    // zero-row case of fft4096_floor_rows, known to the whole workgroup without further exchange
+    for (int j = 0; j < 16; j++) sd[j] = pk_sum_diff(reinterpret_cast<const v2f *>(src)[t + 256 * j]);
+    auto windowed = [&](int j) -> v2f { return (j & 1) ? pk_mul_bcast<1>(sd[j], hwp[j >> 1]) : pk_mul_bcast<0>(sd[j], hwp[j >> 1]); };
+    // Levels of the first window's hops.  Hop g's wave levels go to row (g + 1) mod NH: rows 1.. are read here, row 0 — the
+    // NEWEST hop — is read at the top of the window loop, where every later window finds the hop that entered at its slide.
     const uint32_t wvid = (uint32_t)__builtin_amdgcn_readfirstlane(t >> 6);
     const bool lane63 = (t & 63) == 63;
 #pragma unroll
     for (int g = 0; g < NH; g++) {
         float m = 0.0f, d = 0.0f;
 #pragma unroll
-        for (int q = 0; q < HS; q++) { m = fmaxf(m, fabsf(sm[g * HS + q])); d = fmaxf(d, fabsf(df[g * HS + q])); }
+        for (int q = 0; q < HS; q++) { m = fmaxf(m, fabsf(sd[g * HS + q].x)); d = fmaxf(d, fabsf(sd[g * HS + q].y)); }
         const uint32_t wm = wave_umax_lane63(__float_as_uint(m)), wd = wave_umax_lane63(__float_as_uint(d));
-        if (lane63) *reinterpret_cast<uint2 *>(hoplev[g][wvid]) = make_uint2(wm, wd);
+        if (lane63) *reinterpret_cast<uint2 *>(hoplev[(g + 1) % NH][wvid]) = make_uint2(wm, wd);
     }
     __syncthreads();
+    // Pm / Pd: levels of the hops of the window in the registers, oldest first; between a slide and the next loop top they
+    // still stand one hop back (entry 0 is the hop that left, the newest is in LDS)
     uint32_t Pm[NH], Pd[NH];
+    Pm[0] = 0u; Pd[0] = 0u;
 #pragma unroll
-    for (int g = 0; g < NH; g++) read_levels2(hoplev[g], Pm[g], Pd[g]);
+    for (int g = 1; g < NH; g++) read_levels2(hoplev[g], Pm[g], Pd[g]);
     int E = 0;
-    // block exponent of the window now in the registers (hop levels in Pm / Pd); df is rewritten when it moves by two or more
-    auto settle = [&]() {
-        uint32_t am = 0u, ad = 0u, mm = 0u, md = 0u;
-#pragma unroll
-        for (int g = 0; g < NH; g++) { am |= Pm[g]; ad |= Pd[g]; }
-        if (am == 0u || ad == 0u) return;                   // an empty row has no level: it reads the floor, E stays
-#pragma unroll
-        for (int g = 1; g < NH - 1; g++) { mm = umax(mm, Pm[g]); md = umax(md, Pd[g]); }
-        const uint32_t em = umax(Pm[0], Pm[NH - 1]), ed = umax(Pd[0], Pd[NH - 1]);
-        int T;
-        if (mm != 0u && md != 0u && em <= mm + 0x800000u && ed <= md + 0x800000u) {
-            T = block_exp(mm, md);                          // inner hops carry the level of both rows
-        } else {
-            float xm = 0.0f, xd = 0.0f;                     // exact: largest windowed magnitude of either row
-#pragma unroll
-            for (int j = 0; j < 16; j++) { xm = fmaxf(xm, fabsf(sm[j] * hw[j])); xd = fmaxf(xd, fabsf(df[j] * hw[j])); }
-            const uint32_t wm = wave_umax_lane63(__float_as_uint(xm)), wd = wave_umax_lane63(__float_as_uint(xd));
-            if (lane63) *reinterpret_cast<uint2 *>(xlev[wvid]) = make_uint2(wm, wd);
-            __syncthreads();
-            uint32_t Xm, Xd;
-            read_levels2(xlev, Xm, Xd);
-            if (Xm == 0u || Xd == 0u) return;
-            T = E + block_exp(Xm, Xd);                      // (df carries 2^E already)
-            T = T < -60 ? -60 : (T > 60 ? 60 : T);
-        }
+    float scE = 1.0f, soffE = 0.0f;     // 2^E, and the dB offset that takes it out of the side row again (rewritten with E)
+    // move the side halves of the registers to exponent T when that is two or more away; returns the factor applied
+    auto rescale = [&](int T) -> float {
         const int dE = T - E;
-        if (dE >= 2 || dE <= -2) {
-            const float sc = exp2i(dE);
+        if (dE < 2 && dE > -2) return 1.0f;
+        const float sc = exp2i(dE);
 #pragma unroll
-            for (int j = 0; j < 16; j++) df[j] *= sc;
-            E = T;
-        }
+        for (int j = 0; j < 16; j++) sd[j].y *= sc;
+        E = T; scE = exp2i(E); soffE = block_off(E);
+        return sc;
     };
-    settle();
+    // at a slide (and here, for the first window): the inner hops of the NEXT window are entries 2.. — its exponent in the
+    // ordinary case, settled a whole iteration before it is needed.  What the loop top still has to ask of the entering hop is
+    // left as two thresholds: `inner_ok` (both rows have inner hops, and the oldest hop is at most twice as loud) and
+    // thr_m / thr_d (twice the inner level).
+    bool inner_ok = false;
+    uint32_t thr_m = 0u, thr_d = 0u;
+    auto presettle = [&]() {
+        uint32_t mm = 0u, md = 0u;
+#pragma unroll
+        for (int g = 2; g < NH; g++) { mm = umax(mm, Pm[g]); md = umax(md, Pd[g]); }
+        thr_m = mm + 0x800000u; thr_d = md + 0x800000u;
+        inner_ok = mm != 0u && md != 0u && Pm[1] <= thr_m && Pd[1] <= thr_d;
+        if (mm != 0u && md != 0u) rescale(block_exp(mm, md));
+    };
+    presettle();
     SS_FPROF_DECL
     for (uint32_t w = w_begin; w < w_end; ++w) {
         float2 nx[HS];
         const bool more = (w + 1 < w_end);
         if (COLS && w != w_begin) flush_columns(w - 1);      // (its next atomics are four barriers away)
-        uint32_t am = 0u, ad = 0u;                           // THIS window's rows (the levels move on at the slide)
-#pragma unroll
-        for (int g = 0; g < NH; g++) { am |= Pm[g]; ad |= Pd[g]; }
-        const bool zrow_m = am == 0u, zrow_d = ad == 0u;
+        // the newest hop's levels (written at the slide, behind the loop-end barrier) are requested in front of the windowing
+        // multiplies, which do not wait for them: the window is formed under the exponent the slide settled on
+        const uint4 lq0 = *reinterpret_cast<const uint4 *>(&hoplev[0][0][0]), lq1 = *reinterpret_cast<const uint4 *>(&hoplev[0][2][0]);
+        __builtin_amdgcn_sched_barrier(0);
         v2f z[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) z[j] = v2f{sm[j] * hw[j], df[j] * hw[j]};
+        for (int j = 0; j < 16; j++) z[j] = windowed(j);
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t nPm = (uint32_t)__builtin_amdgcn_readfirstlane((int)umax(umax(lq0.x, lq0.z), umax(lq1.x, lq1.z)));
+        const uint32_t nPd = (uint32_t)__builtin_amdgcn_readfirstlane((int)umax(umax(lq0.y, lq0.w), umax(lq1.y, lq1.w)));
+#pragma unroll
+        for (int g = 0; g < NH - 1; g++) { Pm[g] = Pm[g + 1]; Pd[g] = Pd[g + 1]; }
+        Pm[NH - 1] = nPm; Pd[NH - 1] = nPd;
+        bool zrow_m = false, zrow_d = false;                 // this window has an all-zero mid / side row
+        // do the inner hops carry the level of both rows (the ordinary case: nothing to do)?
+        if (__builtin_expect(!inner_ok || nPm > thr_m || nPd > thr_d, 0)) {
+            uint32_t am = 0u, ad = 0u;
+#pragma unroll
+            for (int g = 0; g < NH; g++) { am |= Pm[g]; ad |= Pd[g]; }
+            zrow_m = am == 0u; zrow_d = ad == 0u;
+            if (!(zrow_m || zrow_d)) {                       // (an empty row has no level: it reads the floor, E stays)
+                // an onset or a decay inside the window: exact levels, the largest windowed magnitude of either row
+                float xm = 0.0f, xd = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 16; j++) { xm = fmaxf(xm, fabsf(z[j].x)); xd = fmaxf(xd, fabsf(z[j].y)); }
+                const uint32_t wm = wave_umax_lane63(__float_as_uint(xm)), wd = wave_umax_lane63(__float_as_uint(xd));
+                if (lane63) *reinterpret_cast<uint2 *>(xlev[wvid]) = make_uint2(wm, wd);
+                __syncthreads();
+                uint32_t Xm, Xd;
+                read_levels2(xlev, Xm, Xd);
+                if (Xm != 0u && Xd != 0u) {
+                    int T = E + block_exp(Xm, Xd);           // (the side halves carry 2^E already)
+                    T = T < -60 ? -60 : (T > 60 ? 60 : T);
+                    const float sc = rescale(T);
+#pragma unroll
+                    for (int j = 0; j < 16; j++) z[j].y *= sc;
+                }
+            }
+        }
+        const float soff = soffE;                            // this window's side row rides the transform as side * 2^E
         SS_PRIO_LO();
         fft16(z);
         SS_PRIO_HI();
@@ -818,24 +862,9 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
                 for (int j = 0; j < 4; j++) twa[j] = twb[j];
             }
         }
-        // the entering hop (requested a pass ago; the transform's registers are dead here): sums and differences in place of
-        // the raw frames, and their levels to the workgroup — read back behind the next barrier, used at the slide
-        float sn[HS], dn[HS];
-        {
-            float m = 0.0f, d = 0.0f;
-#pragma unroll
-            for (int q = 0; q < HS; q++) {
-                sn[q] = nx[q].x + nx[q].y; dn[q] = nx[q].x - nx[q].y;
-                m = fmaxf(m, fabsf(sn[q])); d = fmaxf(d, fabsf(dn[q]));
-            }
-            const uint32_t wm = wave_umax_lane63(__float_as_uint(m)), wd = wave_umax_lane63(__float_as_uint(d));
-            if (lane63) *reinterpret_cast<uint2 *>(hoplev[0][wvid]) = make_uint2(wm, wd);
-        }
         SS_FPROF_MARK(4);
         __syncthreads();
         SS_FPROF_MARK(5);
-        uint32_t nPm, nPd;
-        read_levels2(hoplev[0], nPm, nPd);
 #pragma unroll
         for (int q = 0; q < 16; q++) z[q] = lds_ld64(&xbuf[X2W(hi, tb, q)]);
         SS_FPROF_MARK(6);
@@ -851,18 +880,21 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
         __syncthreads();
         SS_FPROF_MARK(9);
         SS_PRIO_LO();
-        const float soff = block_off(E);                     // THIS window's side row rode the transform as side * 2^E
-        // the sliding registers take the prefetched hop before the epilogue's stores (see fft4096_epilogue)
+        // the sliding registers take the prefetched hop before the epilogue's stores (see fft4096_epilogue); its levels go to
+        // the workgroup (read at the next loop top), and the next window's ordinary exponent is settled
         if (more) {
 #pragma unroll
-            for (int j = 0; j < 16 - HS; j++) { sm[j] = sm[j + HS]; df[j] = df[j + HS]; }
-            const float scE = exp2i(E);
+            for (int j = 0; j < 16 - HS; j++) sd[j] = sd[j + HS];
+            float m = 0.0f, d = 0.0f;
 #pragma unroll
-            for (int q = 0; q < HS; q++) { sm[16 - HS + q] = sn[q]; df[16 - HS + q] = dn[q] * scE; }
-#pragma unroll
-            for (int g = 0; g < NH - 1; g++) { Pm[g] = Pm[g + 1]; Pd[g] = Pd[g + 1]; }
-            Pm[NH - 1] = nPm; Pd[NH - 1] = nPd;
-            settle();
+            for (int q = 0; q < HS; q++) {
+                const v2f v = pk_sum_diff(v2f{nx[q].x, nx[q].y});
+                m = fmaxf(m, fabsf(v.x)); d = fmaxf(d, fabsf(v.y));
+                sd[16 - HS + q] = v2f{v.x, v.y * scE};
+            }
+            const uint32_t wm = wave_umax_lane63(__float_as_uint(m)), wd = wave_umax_lane63(__float_as_uint(d));
+            if (lane63) *reinterpret_cast<uint2 *>(hoplev[0][wvid]) = make_uint2(wm, wd);
+            presettle();
         }
         float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
         if (COLS) fft4096_epilogue<false, true>(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, nullptr, nullptr, true, colbuf, bincol, p.cols, cgain, soff);
