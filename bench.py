@@ -390,7 +390,8 @@ def main():
                                       "sharded, strong scaling): samples/s are comparable across N, ms_per_step are not",
                        "streams_total": total_streams, "streams_this_rank": count, "windows_per_stream": lay.n_windows, "bins": lay.n_bins,
                        "sharding": f"streams, {world} rank(s)",
-                       "collective": ({"lib": "none", "nranks": 1} if comm is None else {"lib": comm.transport, "nranks": comm.size, "call": "ncclAllReduce(2000, ncclUint64, ncclSum) per step" if comm.transport == "rccl" else "host-staged sum over loopback TCP"}),
+                       "collective": ({"lib": "none", "nranks": 1} if comm is None else {"lib": comm.transport, "nranks": comm.size, "ncclCommCount": comm.size if comm.transport == "rccl" else None,
+                                                                                              "rccl_version": comm.library_version, "call": "ncclAllReduce(2000, ncclUint64, ncclSum) per step" if comm.transport == "rccl" else "host-staged sum over loopback TCP"}),
                        "mode": ["sequential (spectrum kernel, then the time-domain chain)",
                                 "overlap (spectrum kernel on a second HIP stream beside the time-domain chain)",
                                 "time-domain kernel, then the spectrum kernel on a second HIP stream beside the chain's tail (gating / histograms)"][ov_mode],

@@ -98,6 +98,11 @@ int ss_analyzer_configure(ss_analyzer *h, uint32_t channels, uint32_t rate);
  * n must be a power of two in [2, 32768]; cap_pairs >= n/2+1 is always enough. */
 int ss_get_fft(const ss_analyzer *h, const float *samples, size_t n,
                double *out_xy, size_t cap_pairs, size_t *out_n);
+/* payload of the LAST failed ss_get_fft on this handle, so that the binding can rebuild the reference's error value and the
+ * text the TUI prints from it (analyzer.rs:60-65 `?` -> tui.rs:1439-1442):
+ *   SS_ERR_SCALING    -> SpectrumAnalyzerError::ScalingError(a = original magnitude, b = scaled value) of the first bin
+ *   SS_ERR_FREQ_LIMIT -> InvalidFrequencyLimit(ValueAboveNyquist(a = 20000.0)); b = the Nyquist frequency it exceeds */
+int ss_get_fft_error_values(const ss_analyzer *h, float *a, float *b);
 /* get_waveform(samples, waveform_window) — associated fn, no handle
  *                                                            analyzer.rs:107-137
  * out_xy receives (i,min),(i,max) pairs; cap_pairs >= 2*floor(window*1000). */
@@ -350,6 +355,10 @@ double ss_corpus_loudness_range(const uint64_t *st_hist1000);
  *  Rendezvous (one node): rank 0 publishes the RCCL unique id (and its TCP port) in `rendezvous_file`, the other
  *  ranks poll for it.  ss_comm_init_from_env derives rank / world from RANK / WORLD_SIZE and the file name from
  *  the launcher's process id and MASTER_PORT (torchrun as a launcher only), or takes SS_COMM_FILE.
+ *  Environment: RCCL across processes needs HSA_ENABLE_IPC_MODE_LEGACY=0 on hosts whose driver has only dmabuf IPC, and
+ *  the HSA runtime reads it at the process' first HIP call.  Loading the library changes nothing in the environment;
+ *  ss_comm_init (RCCL, world > 1) sets the variable if it is unset — call it before any other entry point that touches
+ *  the GPU, or export the variable in the launcher.
  * ------------------------------------------------------------------------- */
 typedef struct ss_comm ss_comm;
 enum { SS_COMM_RCCL = 0, SS_COMM_HOST_TCP = 1 };
@@ -360,6 +369,8 @@ int ss_comm_rank(const ss_comm *c);
 /* number of ranks as the transport itself reports it (ncclCommCount for RCCL) */
 int ss_comm_size(const ss_comm *c);
 const char *ss_comm_transport_name(const ss_comm *c);
+/* ncclGetVersion's code of the librccl this communicator runs on (e.g. 22707 = 2.27.7); 0 for the host transport */
+int ss_comm_library_version(const ss_comm *c);
 /* small host-buffer collectives (fences and the max-over-ranks clock of the benchmark) */
 int ss_comm_barrier(ss_comm *c);
 int ss_comm_allreduce_u64_sum(ss_comm *c, uint64_t *inout, size_t n);

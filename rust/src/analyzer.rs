@@ -15,6 +15,7 @@ extern "C" {
     fn ss_analyzer_configure(h: *mut SsAnalyzer, channels: u32, rate: u32) -> c_int;
     fn ss_get_fft(h: *const SsAnalyzer, x: *const c_float, n: usize,
                   out_xy: *mut c_double, cap_pairs: usize, out_n: *mut usize) -> c_int;
+    fn ss_get_fft_error_values(h: *const SsAnalyzer, a: *mut c_float, b: *mut c_float) -> c_int;
     fn ss_get_waveform(x: *const c_float, n: usize, window: c_double,
                        out_xy: *mut c_double, cap_pairs: usize, out_n: *mut usize) -> c_int;
     fn ss_add_samples(h: *mut SsAnalyzer, x: *const c_float, n: usize) -> c_int;
@@ -39,17 +40,19 @@ fn ebu_err(rc: c_int) -> ebur128::Error {
 }
 
 /// get_fft's `?` in upstream analyzer.rs:60-65 turns a `SpectrumAnalyzerError` into the eyre report whose text the TUI
-/// prints (tui.rs:1439-1442): the same variants come back here, so the message a user sees does not change.  The C ABI
-/// carries the variant, not its payload: the frequency-limit error can only be the upper bound of Range(20, 20000)
-/// against Nyquist; the scaling error's two values (original, scaled) are not known at this boundary.
-fn fft_err(rc: c_int) -> eyre::Report {
+/// prints (tui.rs:1439-1442): the same variants come back here WITH their payloads (`ss_get_fft_error_values`: the limit
+/// that exceeds Nyquist; the original and the scaled value of the first bin the scaling function spoiled), so the message
+/// a user sees does not change.
+fn fft_err(h: *const SsAnalyzer, rc: c_int) -> eyre::Report {
+    let (mut a, mut b) = (f32::NAN, f32::NAN);
+    if rc == 14 || rc == 15 { unsafe { ss_get_fft_error_values(h, &mut a, &mut b) }; }
     match rc {
         10 => SpectrumAnalyzerError::TooFewSamples.into(),
         11 => SpectrumAnalyzerError::NaNValuesNotSupported.into(),
         12 => SpectrumAnalyzerError::InfinityValuesNotSupported.into(),
         13 => SpectrumAnalyzerError::SamplesLengthNotAPowerOfTwo.into(),
-        14 => SpectrumAnalyzerError::InvalidFrequencyLimit(FrequencyLimitError::ValueAboveNyquist(20000.)).into(),
-        15 => SpectrumAnalyzerError::ScalingError(f32::NAN, f32::NAN).into(),
+        14 => SpectrumAnalyzerError::InvalidFrequencyLimit(FrequencyLimitError::ValueAboveNyquist(a)).into(),
+        15 => SpectrumAnalyzerError::ScalingError(a, b).into(),
         _ => eyre!("soundscope_hip: {}", unsafe { CStr::from_ptr(ss_status_string(rc)) }.to_string_lossy()),
     }
 }
@@ -77,7 +80,7 @@ impl Analyzer {
         let mut n = 0usize;
         let rc = unsafe { ss_get_fft(self.h, samples.as_ptr(), samples.len(),
                                      out.as_mut_ptr() as *mut f64, cap, &mut n) };
-        if rc != 0 { return Err(fft_err(rc)); }
+        if rc != 0 { return Err(fft_err(self.h, rc)); }
         out.truncate(n);
         Ok(out)
     }

@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 # every symbol include/soundscope_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "ss_status_string", "ss_abi_version", "ss_device_count", "ss_set_device", "ss_last_device_error",
-    "ss_analyzer_create", "ss_analyzer_destroy", "ss_analyzer_configure", "ss_get_fft", "ss_get_waveform",
+    "ss_analyzer_create", "ss_analyzer_destroy", "ss_analyzer_configure", "ss_get_fft", "ss_get_fft_error_values", "ss_get_waveform",
     "ss_add_samples", "ss_reset", "ss_get_shortterm_lufs", "ss_get_integrated_lufs", "ss_get_loudness_range",
     "ss_get_true_peak", "ss_sample_rate", "ss_calculate_integrated_lufs", "ss_mid_side",
     "ss_get_momentary_lufs", "ss_get_true_peak_channel", "ss_get_sample_peak_channel",
@@ -37,7 +37,7 @@ SYMBOLS = [
     "ss_batch_set_lengths", "ss_batch_stream_shape", "ss_batch_upload_samples",
     "ss_device_synchronize", "ss_batch_peaks", "ss_batch_geometry_get", "ss_batch_set_overlap",
     "ss_comm_init", "ss_comm_init_from_env", "ss_comm_destroy", "ss_comm_rank", "ss_comm_size",
-    "ss_comm_transport_name", "ss_comm_barrier", "ss_comm_allreduce_u64_sum", "ss_comm_allreduce_f64_max",
+    "ss_comm_transport_name", "ss_comm_library_version", "ss_comm_barrier", "ss_comm_allreduce_u64_sum", "ss_comm_allreduce_f64_max",
     "ss_batch_allreduce_histograms", "ss_batch_traffic_floor",
     "ss_batch_corpus_gate_enqueue", "ss_batch_corpus_gate_read", "ss_batch_checksums", "ss_inspect_filter_state", "ss_batch_set_true_peak_arith", "ss_batch_set_columns_gain",
     "ss_inspect_kweight", "ss_inspect_true_peak", "ss_inspect_hann", "ss_inspect_bins", "ss_inspect_histogram",
@@ -122,6 +122,7 @@ def _bind(lib):
         "ss_analyzer_destroy": (None, [vp]),
         "ss_analyzer_configure": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
         "ss_get_fft": (C.c_int, [vp, f32p, C.c_size_t, f64p, C.c_size_t, szp]),
+        "ss_get_fft_error_values": (C.c_int, [vp, f32p, f32p]),
         "ss_get_waveform": (C.c_int, [f32p, C.c_size_t, C.c_double, f64p, C.c_size_t, szp]),
         "ss_add_samples": (C.c_int, [vp, f32p, C.c_size_t]),
         "ss_reset": (None, [vp]),
@@ -195,6 +196,7 @@ def _bind(lib):
         "ss_comm_rank": (C.c_int, [vp]),
         "ss_comm_size": (C.c_int, [vp]),
         "ss_comm_transport_name": (C.c_char_p, [vp]),
+        "ss_comm_library_version": (C.c_int, [vp]),
         "ss_comm_barrier": (C.c_int, [vp]),
         "ss_comm_allreduce_u64_sum": (C.c_int, [vp, u64p, C.c_size_t]),
         "ss_comm_allreduce_f64_max": (C.c_int, [vp, f64p, C.c_size_t]),

@@ -83,7 +83,15 @@ class Analyzer:
         cap = a.size // 2 + 1
         out = np.empty((max(cap, 1), 2), np.float64)
         n = C.c_size_t(0)
-        _check(L.lib().ss_get_fft(self._h, ap, a.size, out.ctypes.data_as(C.POINTER(C.c_double)), cap, C.byref(n)))
+        rc = L.lib().ss_get_fft(self._h, ap, a.size, out.ctypes.data_as(C.POINTER(C.c_double)), cap, C.byref(n))
+        if rc in (L.SS_ERR_SCALING, L.SS_ERR_FREQ_LIMIT):
+            # the payload of SpectrumAnalyzerError::ScalingError(orig, scaled) / InvalidFrequencyLimit(ValueAboveNyquist(limit))
+            va, vb = C.c_float(0), C.c_float(0)
+            L.lib().ss_get_fft_error_values(self._h, C.byref(va), C.byref(vb))
+            e = AnalyzerError(rc)
+            e.values = (va.value, vb.value)
+            raise e
+        _check(rc)
         return out[:n.value].copy()
 
     # -- analyzer.rs:107-137 (associated function)

@@ -150,7 +150,12 @@ int ss_get_fft(const ss_analyzer *hc, const float *samples, size_t n,
         if (any_inf) return SS_ERR_INFINITY;
     }
     if (!pow2) return SS_ERR_NOT_POW2;
-    if (20000.0f > (float)h->rate / 2.0f) return SS_ERR_FREQ_LIMIT;
+    if (20000.0f > (float)h->rate / 2.0f) {
+        // FrequencyLimit::Range(20., 20000.).verify: InvalidFrequencyLimit(ValueAboveNyquist(max)); the payload is the limit
+        // (the Nyquist frequency rides along as the second value)
+        h->fft_err_a = 20000.0f; h->fft_err_b = (float)h->rate / 2.0f;
+        return SS_ERR_FREQ_LIMIT;
+    }
 
     FftTables *ft; BinTables *bt;
     int rc = get_fft_tables(n, &ft);
@@ -175,17 +180,31 @@ int ss_get_fft(const ss_analyzer *hc, const float *samples, size_t n,
     } else {
         HIPCHK(ssk::launch_fft_generic(p, 0, h->stream));
     }
-    std::vector<float> db(bt->count);
-    HIPCHK(hipMemcpyAsync(db.data(), h->fft_out.p, bt->count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (h->fft_host.size() < bt->count) h->fft_host.resize(bt->count);
+    float *db = h->fft_host.data();
+    HIPCHK(hipMemcpyAsync(db, h->fft_out.p, bt->count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     for (size_t i = 0; i < bt->count; i++)
-        if (std::isnan(db[i]) || std::isinf(db[i])) return SS_ERR_SCALING;
+        if (std::isnan(db[i]) || std::isinf(db[i])) {
+            // ScalingError(original, scaled) of the first bin the scaling function spoiled.  scale_to_dbfs maps a finite
+            // magnitude to a finite value (0 -> -150), so the magnitude itself was +inf (its square overflowed; scaled = +inf)
+            // or NaN (inf - inf inside the transform; scaled = NaN): the dB value read back IS both payload values.
+            h->fft_err_a = db[i]; h->fft_err_b = db[i];
+            return SS_ERR_SCALING;
+        }
     // analyzer.rs:75-102 in f64: + pink compensation, log-x chart position
     for (size_t i = 0; i < bt->count; i++) {
         out_xy[2 * i] = bt->chart_x[i];
         out_xy[2 * i + 1] = (double)db[i] + bt->pink[i];
     }
     if (out_n) *out_n = bt->count;
+    return SS_OK;
+}
+
+int ss_get_fft_error_values(const ss_analyzer *h, float *a, float *b)
+{
+    if (!h || !a || !b) return SS_ERR_INVALID_ARG;
+    *a = h->fft_err_a; *b = h->fft_err_b;
     return SS_OK;
 }
 

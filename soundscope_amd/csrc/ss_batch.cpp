@@ -618,6 +618,7 @@ int ss_batch_traffic_floor(ss_batch *b, uint32_t reps, double *ms_per_launch)
     const ss_batch_config &c = b->cfg;
     const ss_batch_layout &L = b->lay;
     if (!(c.flags & SS_BATCH_FFT) || !b->fft_fast || c.hop_frames != 1024 || !L.n_windows || b->ragged) return SS_ERR_UNSUPPORTED;
+    if (!b->fft.p) return SS_ERR_INVALID_MODE;          // columns-only batches have no spectrum rows to store into
     ssk::FftBatchParams p{};
     p.pcm = b->pcm.p; p.out = b->fft.p;
     p.frames_per_stream = c.frames_per_stream; p.first_start = b->first_start;

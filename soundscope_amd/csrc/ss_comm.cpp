@@ -50,10 +50,12 @@
 namespace {
 
 // RCCL shares device buffers between the ranks' processes through HSA IPC.  Hosts whose driver supports only dmabuf IPC
-// need HSA_ENABLE_IPC_MODE_LEGACY=0 (without it ncclCommInitRank fails with "hipIpcGetMemHandle: invalid argument"); the
-// HSA runtime reads the variable once, when the first HIP call starts it, so the default is set when this library is
-// loaded — a value the user exported is left alone.
-__attribute__((constructor)) void default_hsa_ipc_mode() { ::setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0); }
+// need HSA_ENABLE_IPC_MODE_LEGACY=0 (without it ncclCommInitRank fails with "hipIpcGetMemHandle: invalid argument"), and the
+// HSA runtime reads the variable once, when the first HIP call starts it.  The library does NOT touch the process
+// environment when it is loaded: ss_comm_init (RCCL transport, more than one rank) puts the default in place if the
+// variable is unset — in time when ss_comm_init comes before the process' first HIP call (the order INTEGRATION.md
+// prescribes for launchers; bench.py and the C client export it themselves), harmless otherwise.
+void default_hsa_ipc_mode() { ::setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0); }
 
 constexpr const char *kMagic = "ssc2";
 // SS_COMM_TIMEOUT_S (seconds, default 180): how long a rank waits for the others at the rendezvous and inside ncclCommInitRank
@@ -79,6 +81,7 @@ struct Rccl {
     ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;           // optional
 };
 
 bool rccl_open(Rccl &r, std::string &err)
@@ -95,6 +98,7 @@ bool rccl_open(Rccl &r, std::string &err)
     r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(sym("ncclGetVersion"));
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.CommCount || !r.AllReduce || !r.GetErrorString) {
         err = "librccl lacks an expected nccl* symbol";
         return false;
@@ -362,6 +366,7 @@ int ss_comm_init(int transport, int rank, int world, const char *rendezvous_file
     ncclUniqueId id;
     std::memset(&id, 0, sizeof id);
     if (transport == SS_COMM_RCCL) {
+        if (world > 1) default_hsa_ipc_mode();            // before this call's (possibly the process' first) HIP call
         if (ss_device_count() <= 0) return SS_ERR_DEVICE;
         COMM_HIP(hipGetDevice(&c->device));
         if (!rccl_open(c->rccl, err)) return fail(err);
@@ -478,6 +483,13 @@ int ss_comm_size(const ss_comm *c)
     if (c->world == 1) return 1;
     if (c->rank == 0) { int n = 1; for (int fd : c->peers) if (fd >= 0) n++; return n; }
     return c->world;
+}
+
+int ss_comm_library_version(const ss_comm *c)
+{
+    if (!c || c->transport != SS_COMM_RCCL || !c->rccl.GetVersion) return 0;
+    int v = 0;
+    return c->rccl.GetVersion(&v) == ncclSuccess ? v : 0;
 }
 
 const char *ss_comm_transport_name(const ss_comm *c)

@@ -173,6 +173,10 @@ struct ss_analyzer {
     ssh::DevBuf<uint32_t> counts;
     ssh::DevBuf<double> out2, ring_scratch;
     ssh::DevBuf<float> in, fft_out;
+    // get_fft(&self): the handle is const at the boundary; the read-back buffer (grown, never shrunk: no allocation per call)
+    // and the payload of the last error (ss_get_fft_error_values) are the call's own scratch
+    mutable std::vector<float> fft_host;
+    mutable float fft_err_a = 0.0f, fft_err_b = 0.0f;
     uint64_t ring_frames = 0;
     uint64_t frames_fed = 0;
     static constexpr uint32_t kSubCap = 96;

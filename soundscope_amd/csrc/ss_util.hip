@@ -274,9 +274,16 @@ hipError_t launch_checksum(const void *base, uint64_t words, uint64_t stride_wor
     const uint64_t want = (8192 + n_items - 1) / n_items;          // ... but no more workgroups than fill the chip a few times
     if (per_item > want) per_item = want;
     if (per_item < 1) per_item = 1;
-    hipLaunchKernelGGL(k_checksum, dim3((uint32_t)per_item, n_items), dim3(256), 0, s, static_cast<const uint32_t *>(base), words,
-                       stride_words, out, out_stride);
-    return hipGetLastError();
+    // the item index rides in gridDim.y (at most 65535): larger batches go in slices
+    for (uint32_t i0 = 0; i0 < n_items; i0 += 65535u) {
+        const uint32_t cnt = n_items - i0 < 65535u ? n_items - i0 : 65535u;
+        hipLaunchKernelGGL(k_checksum, dim3((uint32_t)per_item, cnt), dim3(256), 0, s,
+                           static_cast<const uint32_t *>(base) + (size_t)i0 * stride_words, words, stride_words,
+                           out + (size_t)i0 * out_stride, out_stride);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 // ---- measurement utility: the spectrum kernel's HBM traffic with no arithmetic -----------------------------------------

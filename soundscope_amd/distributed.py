@@ -67,6 +67,14 @@ class Comm:
     def transport(self):
         return L.lib().ss_comm_transport_name(self._h).decode()
 
+    @property
+    def library_version(self):
+        """"2.27.7"-style version of the librccl behind an RCCL communicator (ncclGetVersion); None for the host transport."""
+        v = int(L.lib().ss_comm_library_version(self._h))
+        if v <= 0:
+            return None
+        return f"{v // 10000}.{v // 100 % 100}.{v % 100}" if v >= 10000 else f"{v // 1000}.{v // 100 % 10}.{v % 100}"
+
     def barrier(self):
         _check(L.lib().ss_comm_barrier(self._h))
 

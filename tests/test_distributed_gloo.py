@@ -29,3 +29,26 @@ def test_corpus_gate_allreduce_gloo(world):
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert f"GLOO_OK world={world}" in p.stdout
+
+
+def test_bench_two_rank_launch_fails_fast_without_a_gpu():
+    """The driver's N > 1 command line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N`)
+    on a box with no GPU: every rank must leave with a non-zero status and a clear message within seconds — no rank may sit
+    in a rendezvous waiting for a peer that has already given up, and there is no CPU path to fall back to."""
+    import time
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this is the device-less launch check; the GPU box runs bench.py itself")
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    port = 29700 + (os.getpid() % 200)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    t0 = time.time()
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120, cwd=root)
+    took = time.time() - t0
+    out = p.stdout + p.stderr
+    assert p.returncode != 0, out[-2000:]
+    assert took < 60.0, f"the launch took {took:.0f} s to fail"
+    assert out.count("bench.py needs a GPU") == 2, out[-3000:]          # one clear line per rank
+    assert '"metric"' not in p.stdout                                    # and no bench line from a run that measured nothing

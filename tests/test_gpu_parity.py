@@ -85,6 +85,31 @@ def test_get_fft_error_order():
     assert code(np.zeros(1024, np.float32)) == L.SS_ERR_FREQ_LIMIT
 
 
+def test_get_fft_error_payloads(oracle):
+    """The two SpectrumAnalyzerError variants with a payload (analyzer.rs:60-65 -> the text at tui.rs:1439-1442) carry it across
+    the ABI: ValueAboveNyquist(limit) and ScalingError(original, scaled) of the first spoiled bin."""
+    an = ssa.Analyzer()
+    an.create_loudness_meter(2, 32000)
+    with pytest.raises(ssa.AnalyzerError) as e:
+        an.get_fft(np.zeros(1024, np.float32))
+    assert e.value.code == L.SS_ERR_FREQ_LIMIT and e.value.values == (20000.0, 16000.0)
+    an.create_loudness_meter(2, 48000)
+    t = np.arange(4096)
+    for n in (4096, 16384):                                    # generic kernel and k_fft16k
+        x = (3.0e38 * np.sin(2 * np.pi * 100.3 * np.arange(n) / n)).astype(np.float32)     # finite samples, sums overflow
+        with pytest.raises(oracle.OracleError) as oe:
+            oracle.get_fft(48000, x)
+        assert oe.value.code == L.SS_ERR_SCALING
+        with pytest.raises(ssa.AnalyzerError) as e:
+            an.get_fft(x)
+        a, b = e.value.values
+        assert e.value.code == L.SS_ERR_SCALING
+        assert (np.isinf(a) and np.isinf(b) and a > 0 and b > 0) or (np.isnan(a) and np.isnan(b)), (a, b)
+    got = an.get_fft(np.ones(4096, np.float32))               # the handle is fine afterwards
+    assert np.isfinite(got).all()
+    an.close()
+
+
 def test_get_fft_silence_is_minus_150(oracle):
     an = ssa.Analyzer()
     got = an.get_fft(np.zeros(4096, np.float32))

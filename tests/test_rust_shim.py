@@ -19,7 +19,7 @@ RUST_TO_C = {
     "u32": "uint32_t", "c_int": "int", "i32": "int", "usize": "size_t", "c_double": "double", "c_float": "float",
     "*mut SsAnalyzer": "ss_analyzer *", "*const SsAnalyzer": "const ss_analyzer *",
     "*mut *mut SsAnalyzer": "ss_analyzer **", "*const c_float": "const float *", "*mut c_double": "double *",
-    "*mut usize": "size_t *", "*mut f64": "double *", "*const c_char": "const char *",
+    "*mut usize": "size_t *", "*mut f64": "double *", "*const c_char": "const char *", "*mut c_float": "float *",
 }
 
 
@@ -105,12 +105,15 @@ def test_get_fft_errors_map_to_the_crate_variants():
     want = {"SS_ERR_TOO_FEW_SAMPLES": "TooFewSamples", "SS_ERR_NAN": "NaNValuesNotSupported",
             "SS_ERR_INFINITY": "InfinityValuesNotSupported", "SS_ERR_NOT_POW2": "SamplesLengthNotAPowerOfTwo",
             "SS_ERR_FREQ_LIMIT": "InvalidFrequencyLimit", "SS_ERR_SCALING": "ScalingError"}
-    body = re.search(r"fn fft_err\(rc: c_int\) -> eyre::Report \{(.*?)\n\}", src, re.S).group(1)
+    body = re.search(r"fn fft_err\(h: \*const SsAnalyzer, rc: c_int\) -> eyre::Report \{(.*?)\n\}", src, re.S).group(1)
     for name, variant in want.items():
         value = int(re.search(name + r"\s*=\s*(\d+)", hdr).group(1))
         arm = re.search(r"\b%d\s*=>\s*SpectrumAnalyzerError::(\w+)" % value, body)
         assert arm and arm.group(1) == variant, f"status {value} ({name}) must map to SpectrumAnalyzerError::{variant}"
-    assert "return Err(fft_err(rc))" in src and 'eyre!("spectrum analyzer error' not in src
+    assert "return Err(fft_err(self.h, rc))" in src and 'eyre!("spectrum analyzer error' not in src
+    # the two variants with a payload take it from the ABI (no placeholder values)
+    assert "ss_get_fft_error_values(h, &mut a, &mut b)" in body and "ValueAboveNyquist(a)" in body and "ScalingError(a, b)" in body
+    assert "NAN, f32::NAN).into()" not in body and "int ss_get_fft_error_values(const ss_analyzer *h, float *a, float *b);" in hdr
     ebu = re.search(r"fn ebu_err\(rc: c_int\) -> ebur128::Error \{(.*?)\n\}", src, re.S).group(1)
     for name, variant in {"SS_ERR_INVALID_MODE": "InvalidMode", "SS_ERR_INVALID_CHANNEL": "InvalidChannelIndex"}.items():
         value = int(re.search(name + r"\s*=\s*(\d+)", hdr).group(1))
