@@ -124,6 +124,16 @@ def cpu_baseline(batch, rate, fft_n, hop, budget_s=15.0, all_cores_budget_s=8.0)
     return out, check
 
 
+def interpolator_taps_f64(factor):
+    """ebur128's 49-tap Hann-windowed sinc (kept as f32 by the crate), as f64 — restated from the published design, SURVEY A5."""
+    j = np.arange(49, dtype=np.float64)
+    m = j - 24.0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        c = np.where(np.abs(m) > 1e-6, np.sin(m * np.pi / factor) / (m * np.pi / factor), 1.0)
+    c *= 0.5 * (1.0 - np.cos(2.0 * np.pi * j / 48.0))
+    return c.astype(np.float32).astype(np.float64)
+
+
 def self_check(batch, stream, ref):
     """GPU results of the run just timed vs the oracle's for one stream, at the north_star tolerances."""
     got = batch.fft(stream)
@@ -152,6 +162,59 @@ def self_check(batch, stream, ref):
             "fft_max_err_rel_to_row_peak_below": weak_err, "fft_max_err_db_above_-90dB": abs_err,
             "fft_max_err_rel_to_row_peak_below_-90dB": abs_weak, "survey_metric_ok": bool(survey_ok), "integrated_err_lu": lufs_err, "lra_err_lu": lra_err,
             "true_peak_rel_err": tp_rel, "decimation_bit_exact": wave_ok, "ok": bool(ok)}
+
+
+def reference_tick_workload(ssa, L, rate=48000, secs=12, cpu_ticks=60):
+    """The reference's OWN workload, one file and one tick at a time, beside the CPU oracle driven the same way:
+      tick  = analyze_audio_file_samples (tui.rs:1482-1552): get_fft(mid) + get_fft(side) on the last 16384 frames, add_samples of the
+              last 16384 interleaved samples, get_shortterm_lufs — every 1024 frames (2048 interleaved samples, audio_player.rs:65);
+      open  = receive_audio_file (tui.rs:1207-1241): whole-file get_waveform + calculate_integrated_lufs (+ the upload to HBM here)."""
+    from oracle import app_driver
+    out = {"workload": f"reference tick: 1 stream x {secs} s, {rate} Hz stereo, N = 16384 mid + side, 16384-sample LUFS refeed, every 1024 frames "
+                       "(ss_session_tick_file, wall clock of the C call incl. its read-backs) and receive_audio_file (ss_session_open_file)"}
+    frames = rate * secs
+    b = ssa.Batch(rate, 2, 1, frames, 4096, 1024, flags=L.SS_BATCH_LUFS)
+    b.synthesize(0x5EED0000, 0)
+    x = b.download_input(0)
+    b.close()
+    t0 = time.perf_counter(); sess = ssa.FileSession(x, 2, rate); open_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter(); sess2 = ssa.FileSession(x, 2, rate); open2_ms = (time.perf_counter() - t0) * 1e3      # tables and buffers warm
+    sess2.close()
+    positions = list(range(16384 * 2 + 2048, x.size + 1, 2048))
+    ticks = []
+    for k, pos in enumerate(positions):
+        t0 = time.perf_counter()
+        sess.analyze_audio_file_samples(pos)
+        t1 = time.perf_counter()
+        if k >= 20:
+            ticks.append((t1 - t0) * 1e6)
+    last_gpu = (sess.mid_fft.copy(), sess.side_fft.copy(), float(sess.lufs[299]))
+    sess.close()
+    t0 = time.perf_counter(); app = app_driver.FileApp(x, 2, rate); cpu_open_ms = (time.perf_counter() - t0) * 1e3
+    cpu = []
+    for pos in positions[:20 + cpu_ticks]:
+        t0 = time.perf_counter()
+        app.analyze_audio_file_samples(pos)
+        cpu.append((time.perf_counter() - t0) * 1e6)
+    out["gpu_tick_us"] = {"median": float(np.median(ticks)), "p99": float(np.percentile(ticks, 99)), "ticks": len(ticks)}
+    out["cpu_oracle_tick_us"] = {"median": float(np.median(cpu[20:])), "ticks": len(cpu) - 20, "cores": 1,
+                                 "what": "oracle/app_driver.FileApp (the C restatement behind the same driver rules), 1 thread"}
+    out["file_open_ms"] = {"gpu_first": open_ms, "gpu_warm": open2_ms, "cpu_oracle": cpu_open_ms, "seconds": secs}
+    out["budget"] = "8 ms TUI loop + 21.3 ms between ticks at 48 kHz (SURVEY section 6)"
+    # the long file: receive_audio_file only (600 s = 57.6 M samples)
+    try:
+        long_s = 600
+        bl = ssa.Batch(rate, 2, 1, rate * long_s, 4096, 1024, flags=L.SS_BATCH_LUFS)
+        bl.synthesize(0x5EED0001, 0)
+        xl = bl.download_input(0)
+        bl.close()
+        t0 = time.perf_counter(); sl = ssa.FileSession(xl, 2, rate); long_ms = (time.perf_counter() - t0) * 1e3
+        sl.close()
+        t0 = time.perf_counter(); app_driver.FileApp(xl, 2, rate); long_cpu_ms = (time.perf_counter() - t0) * 1e3
+        out["file_open_ms_600s"] = {"gpu": long_ms, "cpu_oracle": long_cpu_ms, "h2d_bytes": int(xl.nbytes)}
+    except Exception as ex:
+        out["file_open_ms_600s"] = {"error": repr(ex)}
+    return out
 
 
 def time_config(ssa, L, rate, channels, streams, frames, fft_n, hop, tp_factor, steps, warmup=1, flags=None, tp_arith=None, cols=0):
@@ -341,6 +404,43 @@ def main():
     if abs(corpus_i - host_i) > 1e-9 or abs(corpus_lra - host_lra) > 1e-9:
         raise SystemExit(f"device corpus gate {corpus_i, corpus_lra} != host {host_i, host_lra}")
 
+    # The reference's true-peak arithmetic is an f32 FIR (ebur128's interpolator: f32 taps, f32 accumulation; analyzer.rs:139-141,
+    # 159-164).  The timed default runs it as an f16x3 split on the matrix cores; the SAME step is timed again with the f32 MFMA
+    # product (ss_batch_set_true_peak_arith), and both modes' peaks of the timed batch are measured against an f64 polyphase
+    # convolution of the same streams (numpy, independent of the oracle): the evidence that the split costs no accuracy.
+    tp_arith = None
+    if comm is None:
+        def tp_error(nstreams=4):
+            worst = 0.0
+            taps = interpolator_taps_f64(4)
+            for i in range(min(nstreams, count)):
+                x = b.download_input(i)
+                tp, _ = b.peaks(i)
+                for c in range(2):
+                    ch = x[c::2].astype(np.float64)
+                    want = max(max(np.abs(np.convolve(ch, taps[ph::4])[:ch.size]).max() for ph in range(4)), np.abs(ch).max())
+                    worst = max(worst, abs(tp[c] - want) / want)
+            return worst
+        err_f16x3 = tp_error()
+        b.set_true_peak_arith(L.SS_TP_ARITH_F32)
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt32 = time.perf_counter() - t1
+        b.sync()
+        err_f32 = tp_error()
+        b.set_true_peak_arith(L.SS_TP_ARITH_F16X3)
+        b.run(); b.sync()
+        tp_arith = {"value_f32_arith": samples_per_step * args.steps / dt32, "ms_per_step_f32_arith": dt32 / args.steps * 1e3,
+                    "max_rel_err_vs_f64_polyphase": {"f16x3_split (timed default)": err_f16x3, "f32_mfma (reference width)": err_f32},
+                    "streams_checked": min(4, count), "bar": 1e-4,
+                    "what": "the same timed step with SS_TP_ARITH_F32; errors of the 4x true peak of the timed batch against an f64 "
+                            "polyphase convolution with the crate's f32 taps (numpy)"}
+
     # per-kernel times: a separate SEQUENTIAL pass (with two kernels sharing the chip a per-kernel HIP-event time
     # would not describe either of them); HIP events on the batch's own stream
     b.timing_enable(True)
@@ -381,6 +481,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32 (f16x3-split MFMA true peak) + f64", "data": "synthetic",
+            "value_f32_arith": tp_arith["value_f32_arith"] if tp_arith else None,
+            "true_peak_arithmetic": tp_arith,
             "config": {"workload": (f"{total_streams} streams in total (BASELINE config 4) sharded over {world} GPU(s)" if strong
                                     else f"{args.streams} streams/GPU (BASELINE config 3)") +
                                    f" x {args.seconds:g} s, {args.rate} Hz stereo f32: mid/side {args.fft_n}-pt Hann FFT "
@@ -456,6 +558,7 @@ def main():
                     e = time_config(ssa, L, 48000, 2, 1, 48000 * secs, 4096, 1024, 0, steps=5)
                     e["workload"] = f"config 2: 1 stream x {secs} s, 48 kHz stereo, N=4096 hop 1024, full path"
                     extra.append(e)
+                extra.append(reference_tick_workload(ssa, L))
                 # config 5: 96 kHz 8-channel, N = 16384 per channel; forced 4x (benchmark) and the crate rule's 2x
                 for tp, name in ((4, "forced 4x true peak"), (0, "rule 2x true peak")):
                     e = time_config(ssa, L, 96000, 8, 64, 960000, 16384, 1024, tp, steps=3)
