@@ -62,6 +62,16 @@ __device__ __forceinline__ v2f pk_cmul(v2f a, v2f w)
         : "=v"(r) : "v"(a), "v"(w), "v"(m));
     return r;
 }
+// a * w for a compile-time constant w held in a scalar register pair (the three constants of fft16: left to the "v"
+// constraint of pk_cmul the compiler copies them into vector registers in front of every use, ten v_mov_b64 per window)
+__device__ __forceinline__ v2f pk_cmul_k(v2f a, v2f w)
+{
+    v2f m, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(m) : "v"(a), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,0]"
+        : "=v"(r) : "v"(a), "s"(w), "v"(m));
+    return r;
+}
 // (a.x + a.y, a.y - a.x) = a - i a      [times R gives a * W16^2]
 __device__ __forceinline__ v2f pk_w2pre(v2f a) { return pk_sub_ib(a, a); }
 // (a.y - a.x, -(a.x + a.y))             [times R gives a * W16^6]
@@ -120,15 +130,15 @@ __device__ __forceinline__ void fft16(v2f (&a)[16])
     radix4(a[2], a[6], a[10], a[14]);
     radix4(a[3], a[7], a[11], a[15]);
     // twiddle a[r + 4p] *= W16^(r p)
-    a[5] = pk_cmul(a[5], w1);            // r=1,p=1: W^1
+    a[5] = pk_cmul_k(a[5], w1);            // r=1,p=1: W^1
     a[9] = pk_w2pre(a[9]) * R;           // r=1,p=2: W^2
-    a[13] = pk_cmul(a[13], w3);          // r=1,p=3: W^3
+    a[13] = pk_cmul_k(a[13], w3);          // r=1,p=3: W^3
     a[6] = pk_w2pre(a[6]) * R;           // r=2,p=1: W^2
     a[10] = pk_mul_mi(a[10]);            // r=2,p=2: W^4 = -i
     a[14] = pk_w6pre(a[14]) * R;         // r=2,p=3: W^6 = (-R,-R)
-    a[7] = pk_cmul(a[7], w3);            // r=3,p=1: W^3
+    a[7] = pk_cmul_k(a[7], w3);            // r=3,p=1: W^3
     a[11] = pk_w6pre(a[11]) * R;         // r=3,p=2: W^6
-    a[15] = pk_cmul(a[15], w9);          // r=3,p=3: W^9 = (-C1, +S1)
+    a[15] = pk_cmul_k(a[15], w9);          // r=3,p=3: W^9 = (-C1, +S1)
     // stage 2: 4-point DFTs over r of a[r + 4p]; result s lands in a[s + 4p] = X[p + 4s]
     radix4(a[0], a[1], a[2], a[3]);
     radix4(a[4], a[5], a[6], a[7]);
