@@ -17,6 +17,8 @@ for a in sys.argv:
         flags = int(a.split('=')[1])
 b = ssa.Batch(48000, 2, streams, 480000, 4096, 1024, flags=flags)
 b.synthesize(0x5EED0000, 0)
+if "--tp-f32" in sys.argv:          # true peak at the reference's width (v_mfma_f32_16x16x4_f32 everywhere)
+    b.set_true_peak_arith(L.SS_TP_ARITH_F32)
 for _ in range(2):
     b.run(); b.sync()
 b.timing_enable(True)
