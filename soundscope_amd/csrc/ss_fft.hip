@@ -275,11 +275,15 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
             float qm[4], qs[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                v2f m2, s2;                                      // 2*M = (zk.x+zm.x, zk.y-zm.y); 2*S ~ (zk.y+zm.y, zk.x-zm.x)
-                asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,0] neg_hi:[0,1]" : "=v"(m2) : "v"(zk[e]), "v"(zm[e]));
-                asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(s2) : "v"(zk[e]), "v"(zm[e]));
-                qm[e] = fmaf(m2.x, m2.x, m2.y * m2.y);
-                qs[e] = fmaf(s2.x, s2.x, s2.y * s2.y);
+                // 2 M = (zk.x + zm.x, zk.y - zm.y), 2 S ~ (zk.y + zm.y, zk.x - zm.x).  Held across the two rows — P = (2M.x, 2S.x)
+                // = zk + zm, Q = (2M.y, 2S.y) — both squared magnitudes are ONE packed multiply and one packed fma,
+                // (|2M|^2, |2S|^2) = P P + Q Q, with the roundings of fmaf(x, x, y * y) per row.
+                v2f P = zk[e] + zm[e], Q, t, qq;
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(Q) : "v"(zk[e]), "v"(zm[e]));
+                asm("v_pk_mul_f32 %0, %1, %1" : "=v"(t) : "v"(Q));
+                asm("v_pk_fma_f32 %0, %1, %1, %2" : "=v"(qq) : "v"(P), "v"(t));
+                qm[e] = qq.x;
+                qs[e] = qq.y;
             }
             const float opv[4] = {op[i].x, op[i].y, op[i].z, op[i].w};
             // the second row's offsets carry its block exponent (two packed adds per group)
