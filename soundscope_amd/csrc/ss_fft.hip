@@ -947,7 +947,7 @@ __global__ __launch_bounds__(256, SS_FFT_PAIRW_WAVES) void k_fft4096_pairw(FftBa
     const uint32_t pairs_per_block = p.windows_per_block >> 1;            // the host keeps windows_per_block even
     const uint32_t n_pairs_max = (p.n_windows + 1) >> 1;
     const uint32_t groups = (n_pairs_max + pairs_per_block - 1) / pairs_per_block;
-    // channels of one run read the same interleaved lines: keep them on one XCD (see k_fft16k_run)
+    // channels of one run read the same interleaved lines: keep them on one XCD (the mapping is spelled out in k_fft16k_run)
     const uint32_t per_xcd = gridDim.x >> 3;
     uint32_t bid = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (bid >= p.n_streams * groups * fft_ch) return;
@@ -1326,21 +1326,33 @@ __global__ __launch_bounds__(512, 2) void k_fft16k(FftBatchParams p, int midside
 //  so a sample is fetched once per run instead of 16 times) and window weights rebuilt from two
 //  resident twiddles, w[n0 + 1024 j] = 1/2 - 1/2 cos(a0 + j pi/8).
 //  Decimation in time by four:  X[b] = A0[b] + W^b A1[b] + W^2b A2[b] + W^3b A3[b],  W = W_16384,
-//  A_r = FFT_4096 of the real sequence xw[4i + r].  Half q (both are carried by every thread) transforms the complex
-//  sequence z_q[i] = (xw[4i + 2q], xw[4i + 2q + 1]) on the radix-16 passes of k_fft4096_ms1; A_{2q}, A_{2q+1}
-//  are its even / odd parts (the mid/side split of the N = 4096 kernel), combined per bin by Horner.
-//  The two halves never exchange data before the epilogue.  MODE 0: mono buffer or channel `ch` of an
-//  interleaved buffer, 1: stereo -> mid/side (audio_player.rs:400-419).
+//  A_r = FFT_4096 of the real sequence xw[4i + r].  Half q transforms the complex sequence
+//  z_q[i] = (xw[4i + 2q], xw[4i + 2q + 1]) on the radix-16 passes of k_fft4096_ms1; A_{2q}, A_{2q+1} are its even / odd
+//  parts (the mid/side split of the N = 4096 kernel), combined per bin by Horner.  The two halves never exchange data
+//  before the epilogue.  Both halves are the SAME signal (its even / odd sample pairs), so the two rows of a transform are
+//  at one level by construction: no block exponent here.  MODE 0: mono buffer or channel `ch` of an interleaved buffer,
+//  1: stereo -> mid/side (audio_player.rs:400-419), one workgroup per signal.
+//
+//  ONE half per thread: threads 0-255 carry half q = 0 (samples 4i, 4i + 1), threads 256-511 half q = 1 (samples 4i + 2,
+//  4i + 3).  Through round 3 every one of 256 threads carried both halves (250 VGPRs, two workgroups = two waves per SIMD);
+//  spread over eight waves a window's 64 KB of sliding samples cost 32 registers per thread, the kernel fits 128 VGPRs and
+//  two workgroups are FOUR waves per SIMD: config 5 7.11 -> 6.89 ms, native stereo 4.66 -> 4.53 ms in one call
+//  (profiles/r04_ab_fft16k_eight_waves.txt).  q is wave-uniform (a wave belongs to one half), so nothing diverges.
 // ============================================================================
+#ifndef SS_RUN8_WAVES
+#define SS_RUN8_WAVES 4
+#endif
 template <bool MIDSIDE>
-__global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_t fft_ch)
+__global__ __launch_bounds__(512, SS_RUN8_WAVES) void k_fft16k_run(FftBatchParams p, uint32_t fft_ch)
 {
     __shared__ __attribute__((aligned(16))) v2f xbuf2[2][16 * kPlaneB];      // 2 x 34816 B
     __shared__ __attribute__((aligned(16))) v2f tw2s[256];                    //  2048 B
-    __shared__ __attribute__((aligned(16))) float stage[4][256];              //  4096 B: 75776 B per workgroup, two per CU
+    __shared__ __attribute__((aligned(16))) float stage[8][256];              //  8192 B: 79872 B per workgroup, two per CU
 #define X1W(ka, tb_, ta_) ((ka) * kPlaneB + (tb_) * kRowB + (ta_))
 #define X2W(kb, ka_, tb_) ((kb) * kPlaneB + (ka_) * kRowB + (tb_))
-    const int t = threadIdx.x;
+    const int q = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));   // which half this wave carries
+    const int t = threadIdx.x & 255;
+    v2f *xbuf = xbuf2[q];
     const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
     // Workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.  The channels of one run read the
     // same interleaved lines, so they must sit on ONE XCD: logical id = (id mod 8) * ceil(total / 8) + id / 8 makes
@@ -1360,44 +1372,36 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
     const float *base = p.pcm + ((size_t)stream * p.frames_per_stream + p.first_start + (size_t)w_begin * 1024u) * C;
     const v2f *tw16k = reinterpret_cast<const v2f *>(p.tw_n);       // W_16384^k, k < 8192
     const v2f *tw4k = reinterpret_cast<const v2f *>(p.tw_core);     // W_4096^k
-    tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[(t & 15) * (t >> 4)];      // [kb][tb]: W_256^(tb kb) at kb * 16 + tb
+    if (threadIdx.x < 256) tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[(t & 15) * (t >> 4)];      // [kb][tb]: W_256^(tb kb) at kb * 16 + tb
 
-    // samples n .. n + 3 of this workgroup's channel (n relative to the run's first window): the two
-    // halves' complex inputs z_0 = (x[n], x[n+1]), z_1 = (x[n+2], x[n+3])
-    auto ld4 = [&](size_t n, v2f &z0, v2f &z1) {
+    // samples n + 2q, n + 2q + 1 of this workgroup's channel (n relative to the run's first window): one complex input of half q
+    auto ld2 = [&](size_t n) -> v2f {
         if (MIDSIDE) {
-            const float2 *f = reinterpret_cast<const float2 *>(base) + n;
-            const float2 a = f[0], b = f[1], c = f[2], d = f[3];
-            if (ch == 0) { z0 = v2f{(a.x + a.y) * 0.5f, (b.x + b.y) * 0.5f}; z1 = v2f{(c.x + c.y) * 0.5f, (d.x + d.y) * 0.5f}; }
-            else { z0 = v2f{(a.x - a.y) * 0.5f, (b.x - b.y) * 0.5f}; z1 = v2f{(c.x - c.y) * 0.5f, (d.x - d.y) * 0.5f}; }
-        } else {
-            const float *f = base + n * C + ch;
-            z0 = v2f{f[0], f[C]};
-            z1 = v2f{f[2 * (size_t)C], f[3 * (size_t)C]};
+            const float2 *f = reinterpret_cast<const float2 *>(base) + n + 2 * q;
+            const float2 a = f[0], b = f[1];
+            return ch == 0 ? v2f{(a.x + a.y) * 0.5f, (b.x + b.y) * 0.5f} : v2f{(a.x - a.y) * 0.5f, (b.x - b.y) * 0.5f};
         }
+        const float *f = base + (n + 2 * q) * C + ch;
+        return v2f{f[0], f[C]};
     };
-    const uint32_t n0 = 4u * (uint32_t)t;           // slot j holds samples n0 + 1024 j .. +3 of the current window
-    v2f raw0[16], raw1[16];
+    const uint32_t n0 = 4u * (uint32_t)t;           // slot j holds samples n0 + 1024 j + 2q, + 1 of the current window
+    v2f raw[16];
 #pragma unroll
-    for (int j = 0; j < 16; j++) ld4((size_t)n0 + 1024u * j, raw0[j], raw1[j]);
-    // Hann weights of slot j: angle a_e + j pi/8, a_e = 2 pi (n0 + e) / 16384, e = 0..3 (table holds (cos, -sin))
-    const v2f wa = tw16k[n0], wb = tw16k[n0 + 1], wc = tw16k[n0 + 2], wd = tw16k[n0 + 3];
-    const v2f hc0 = {-0.5f * wa.x, -0.5f * wb.x}, hs0 = {-0.5f * wa.y, -0.5f * wb.y};   // -1/2 cos a_e, +1/2 sin a_e
-    const v2f hc1 = {-0.5f * wc.x, -0.5f * wd.x}, hs1 = {-0.5f * wc.y, -0.5f * wd.y};
-    const v2f half = {0.5f, 0.5f};
+    for (int j = 0; j < 16; j++) raw[j] = ld2((size_t)n0 + 1024u * j);
+    // Hann weights of slot j: angle a_e + j pi/8, a_e = 2 pi (n0 + 2q + e) / 16384, e = 0, 1 (table holds (cos, -sin)) ...
     // ... except for the two EDGE slots (0 and 15), whose weights are small: rebuilt in f32 they are within 2.4e-7 of the
     // crate's table, which is nothing for a weight of 0.5 but 1e-4 of a weight of 2e-3 — and a window whose only loud
     // samples sit in its last hop (the first window after a near-silent passage) has nothing but such weights under its
-    // energy: 0.012 dB against the oracle there.  Those eight weights come from the table itself (bit-equal to the crate's).
-    const v2f we0a = {p.window[n0], p.window[n0 + 1]}, we0b = {p.window[n0 + 2], p.window[n0 + 3]};
-    const v2f we15a = {p.window[15360u + n0], p.window[15360u + n0 + 1]}, we15b = {p.window[15360u + n0 + 2], p.window[15360u + n0 + 3]};
+    // energy: 0.012 dB against the oracle there.  Those weights come from the table itself (bit-equal to the crate's).
+    const uint32_t ne = n0 + 2u * (uint32_t)q;
+    const v2f wa = tw16k[ne], wb = tw16k[ne + 1];
+    const v2f hc = {-0.5f * wa.x, -0.5f * wb.x}, hs = {-0.5f * wa.y, -0.5f * wb.y};   // -1/2 cos a_e, +1/2 sin a_e
+    const v2f half = {0.5f, 0.5f};
+    const v2f we0 = {p.window[ne], p.window[ne + 1]}, we15 = {p.window[15360u + ne], p.window[15360u + ne + 1]};
     v2f twg[16];
     twg[1] = tw4k[t]; twg[2] = tw4k[2 * t]; twg[3] = tw4k[3 * t];
     twg[4] = tw4k[4 * t]; twg[8] = tw4k[8 * t]; twg[12] = tw4k[12 * t];
     const int tb = t & 15, hi = t >> 4;
-    // (the epilogue below reads bins stride-1 across the wave — 32 consecutive complex values per lane group, conflict-free
-    // wherever they start — so the published spectra stay in plain natural order here)
-    const int tsw = t;
     const uint32_t ngroups = (p.n_bins + 3) >> 2;
     constexpr float kDb = 3.01029995663981195f;
     const float off2 = p.db_offset - 6.02059991327962390f;      // the epilogue carries 2 X
@@ -1406,16 +1410,15 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
     // iteration that wait — vmcnt(0) in the middle of the first radix pass — stood there for the PREVIOUS window's output
     // stores to reach memory.
     asm volatile("" : "+v"(twg[1]), "+v"(twg[2]), "+v"(twg[3]), "+v"(twg[4]), "+v"(twg[8]), "+v"(twg[12]));
-    asm volatile("" ::"v"(we0a), "v"(we0b), "v"(we15a), "v"(we15b));
+    asm volatile("" ::"v"(we0), "v"(we15));
 #pragma unroll
-    for (int j = 0; j < 16; j++) asm volatile("" : "+v"(raw0[j]), "+v"(raw1[j]));
+    for (int j = 0; j < 16; j++) asm volatile("" : "+v"(raw[j]));
     __syncthreads();
 
     for (uint32_t w = w_begin; w < w_end; ++w) {
         const bool more = (w + 1 < w_end);
-        v2f nx0 = {0.0f, 0.0f}, nx1 = {0.0f, 0.0f};
-        v2f z0[16], z1[16];
-        // cos(j pi/8), sin(j pi/8): the Hann weight of slot j is 1/2 - 1/2 (cos a cj - sin a sj)
+        v2f nx = {0.0f, 0.0f};
+        v2f z[16];
         constexpr float cj[16] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.0f,
                                   -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.0f,
                                   -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f, 0.0f,
@@ -1424,45 +1427,30 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
                                   0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.0f,
                                   -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.0f,
                                   -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f};
-        // the two halves are independent problems: every barrier phase carries both (half the barriers
-        // per transform, two instruction streams to cover LDS latency)
+        // (the fourteen rebuilt weights are window-loop invariants: left alone the compiler computes them once, keeps 28 registers
+        // for them across the loop and — at the 128 registers of four waves per SIMD — spills and reloads them every window;
+        // opaque copies of the two seeds keep the rebuild, 28 packed fma, inside the loop)
+        v2f hcw = hc, hsw = hs;
+        asm volatile("" : "+v"(hcw), "+v"(hsw));
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            z0[j] = raw0[j] * (j == 0 ? we0a : (j == 15 ? we15a : half + hc0 * cj[j] + hs0 * sj[j]));
-            z1[j] = raw1[j] * (j == 0 ? we0b : (j == 15 ? we15b : half + hc1 * cj[j] + hs1 * sj[j]));
-        }
-        fft16(z0);
-        xbuf2[0][X1W(0, tb, hi)] = z0[R16(0)];
-#pragma unroll
-        for (int ka = 1; ka < 16; ka++) {
-            v2f v = z0[R16(ka)];
-            if (ka & 3) v = pk_cmul(v, twg[ka & 3]);
-            if (ka & 12) v = pk_cmul(v, twg[ka & 12]);
-            xbuf2[0][X1W(ka, tb, hi)] = v;
-        }
-        fft16(z1);
-        xbuf2[1][X1W(0, tb, hi)] = z1[R16(0)];
+        for (int j = 0; j < 16; j++) z[j] = raw[j] * (j == 0 ? we0 : (j == 15 ? we15 : half + hcw * cj[j] + hsw * sj[j]));
+        fft16(z);
+        xbuf[X1W(0, tb, hi)] = z[R16(0)];
 #pragma unroll
         for (int ka = 1; ka < 16; ka++) {
-            v2f v = z1[R16(ka)];
+            v2f v = z[R16(ka)];
             if (ka & 3) v = pk_cmul(v, twg[ka & 3]);
             if (ka & 12) v = pk_cmul(v, twg[ka & 12]);
-            xbuf2[1][X1W(ka, tb, hi)] = v;
+            xbuf[X1W(ka, tb, hi)] = v;
         }
-        if (more) ld4((size_t)(w + 1 - w_begin) * 1024u + n0 + 1024u * 15u, nx0, nx1);
+        if (more) nx = ld2((size_t)(w + 1 - w_begin) * 1024u + n0 + 1024u * 15u);
         __syncthreads();
 #pragma unroll
-        for (int ta = 0; ta < 16; ta++) { z0[ta] = lds_ld64(&xbuf2[0][X1W(hi, tb, ta)]); z1[ta] = lds_ld64(&xbuf2[1][X1W(hi, tb, ta)]); }
+        for (int ta = 0; ta < 16; ta++) z[ta] = lds_ld64(&xbuf[X1W(hi, tb, ta)]);
         __syncthreads();
-        // Second-pass twiddles W_256^(tb kb): ONE table read serves both halves, the table is laid out [kb][tb] (a lane's
-        // address is tb * 8 + an immediate) and the reads come in batches of four, the next batch requested before the current
-        // one is used.  (Read one at a time, once per half — what the straightforward loop compiles to at this register
-        // pressure — each of the thirty reads per window was waited for on the spot: thirty exposed LDS round trips.)
-        fft16(z0);
-        fft16(z1);
-        xbuf2[0][X2W(0, hi, tb)] = z0[R16(0)];
-        xbuf2[1][X2W(0, hi, tb)] = z1[R16(0)];
-        {
+        fft16(z);
+        xbuf[X2W(0, hi, tb)] = z[R16(0)];
+        {   // second-pass twiddles from the [kb][tb] table, four at a time, the next four requested before the current four are used
             const v2f *twp = tw2s + tb;
             v2f twa[4], twb[4];
 #pragma unroll
@@ -1476,10 +1464,7 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < nk; j++) {
-                    xbuf2[0][X2W(kb0 + j, hi, tb)] = pk_cmul(z0[R16(kb0 + j)], twa[j]);
-                    xbuf2[1][X2W(kb0 + j, hi, tb)] = pk_cmul(z1[R16(kb0 + j)], twa[j]);
-                }
+                for (int j = 0; j < nk; j++) xbuf[X2W(kb0 + j, hi, tb)] = pk_cmul(z[R16(kb0 + j)], twa[j]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 4; j++) twa[j] = twb[j];
@@ -1487,17 +1472,13 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
         }
         __syncthreads();
 #pragma unroll
-        for (int qq = 0; qq < 16; qq++) { z0[qq] = lds_ld64(&xbuf2[0][X2W(hi, tb, qq)]); z1[qq] = lds_ld64(&xbuf2[1][X2W(hi, tb, qq)]); }
+        for (int qq = 0; qq < 16; qq++) z[qq] = lds_ld64(&xbuf[X2W(hi, tb, qq)]);
         __syncthreads();
-        fft16(z0);
+        fft16(z);
 #pragma unroll
-        for (int kc = 0; kc < 16; kc++) xbuf2[0][kc * 256 + tsw] = z0[R16(kc)];   // Z_q[k] at k
-        fft16(z1);
-#pragma unroll
-        for (int kc = 0; kc < 16; kc++) xbuf2[1][kc * 256 + tsw] = z1[R16(kc)];
-        // the epilogue's four twiddles are requested here, in front of the barrier that closes the publish (the transforms'
-        // registers have just died): the loads fly while the workgroup gathers
-        const uint32_t lane = (uint32_t)t & 63u, wv = (uint32_t)t >> 6;
+        for (int kc = 0; kc < 16; kc++) xbuf[kc * 256 + t] = z[R16(kc)];          // Z_q[k] at k (natural order)
+        // the epilogue's twiddles are requested in front of the barrier that closes the publish
+        const uint32_t lane = (uint32_t)threadIdx.x & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         v2f wt[4];
         {
             uint32_t fbq = p.first_bin;
@@ -1506,41 +1487,32 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
             for (int e = 0; e < 4; e++) wt[e] = tw16k[(fbq + 256u * wv + 64u * e + lane) & 8191u];
         }
         __syncthreads();
-        // the prefetched hop is claimed HERE, in front of the epilogue's stores: claimed at the slide behind them, its wait
-        // (loads and stores share vmcnt, in order) would also stand for every store of this window
-        asm volatile("" : "+v"(nx0), "+v"(nx1));
+        asm volatile("" : "+v"(nx));        // the prefetched hop is claimed in front of the epilogue's stores
 
-        // ---- epilogue.  Iteration `it` covers 1024 retained bins, wave wv the 256 of them starting at
-        // 1024 it + 256 wv.  Reading: lane l takes bins +l, +64+l, +128+l, +192+l, so every LDS read of the two
-        // published spectra (and of their mirrors, descending) is stride-1 across the wave: conflict-free
-        // whatever first_bin is.  Writing: the four dB values go through a wave-private 1 KB staging row so
-        // that lane l stores bins +4l..+4l+3 with one 16-byte store.  From one iteration to the next the bin
-        // index grows by 1024: positions move by +-1024, twiddles turn by W_16^1.
+        // ---- epilogue, all eight waves (both spectra are published).  Iteration `it` covers 2048 retained bins, wave wv the 256
+        // of them starting at 2048 it + 256 wv.  Reading: lane l takes bins +l, +64+l, +128+l, +192+l, so every LDS read of the
+        // two published spectra (and of their mirrors, descending) is stride-1 across the wave: conflict-free whatever
+        // first_bin is.  Writing: the four dB values go through a wave-private 1 KB staging row so that lane l stores bins
+        // +4l..+4l+3 with one 16-byte store.  From one iteration to the next the bin index grows by 2048: positions move by
+        // +-2048, twiddles turn by W_16384^2048 = W_8^1.
         float *o = p.out + (((size_t)stream * p.n_windows + w) * fft_ch + ch) * p.bin_stride;
         {
             float *stg = stage[wv];
             uint32_t pb[4], pm[4];
             uint32_t fb = p.first_bin;
-            asm volatile("" : "+s"(fb));        // per-window recomputation: hoisting these 16 registers out of the loop spills
+            asm volatile("" : "+s"(fb));
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const uint32_t b = fb + 256u * wv + 64u * e + lane;
-                const uint32_t bq = b & 4095u, mq = (4096u - bq) & 4095u;
-                pb[e] = bq; pm[e] = mq;
+                pb[e] = b & 4095u; pm[e] = (4096u - (b & 4095u)) & 4095u;
             }
-            const v2f rho = {0.92387953251128674f, -0.38268343236508977f};
-            const uint32_t n_iter = (4u * ngroups + 1023u) >> 10;
-            // the four twiddles are "used" here, in front of the loop: otherwise the wait for their loads lands INSIDE the loop
-            // (its first multiply) as s_waitcnt vmcnt(0), where from the second iteration on it waits for the pink row instead
+            const v2f rho = {0.70710678118654752f, -0.70710678118654752f};
+            const uint32_t n_iter = (4u * ngroups + 2047u) >> 11;
             asm volatile("" : "+v"(wt[0]), "+v"(wt[1]), "+v"(wt[2]), "+v"(wt[3]));
             for (uint32_t it = 0; it < n_iter; it++) {
-                // The iteration's loads first: the pink row of the group this lane will store (a global load: waited for right
-                // where it was issued — behind the arithmetic, in front of the store — it cost a full L2 round trip per
-                // iteration), then all sixteen spectrum values of the lane's four bins (read a bin at a time they cost four
-                // exposed LDS round trips per iteration; the transforms' 64 registers are dead here).
-                const uint32_t g = 256u * it + 64u * wv + lane;        // group of four bins this lane stores
+                const uint32_t g = 512u * it + 64u * wv + lane;        // group of four bins this lane stores
                 float4 pk = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.pink) pk = *reinterpret_cast<const float4 *>(p.pink + 4u * (g < ngroups ? g : ngroups - 1u));   // (clamped, not predicated: no exec-mask branch around the load)
+                if (p.pink) pk = *reinterpret_cast<const float4 *>(p.pink + 4u * (g < ngroups ? g : ngroups - 1u));
                 v2f e0v[4], emv[4], o0v[4], omv[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -1563,8 +1535,8 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
                     const float qv = fmaf(x.x, x.x, x.y * x.y);
                     const float db = fmaf(__log2f(qv), kDb, off2);
                     r[e] = qv == 0.0f ? -150.0f : db;
-                    pb[e] = (pb[e] + 1024u) & 4095u;
-                    pm[e] = (pm[e] - 1024u) & 4095u;
+                    pb[e] = (pb[e] + 2048u) & 4095u;
+                    pm[e] = (pm[e] - 2048u) & 4095u;
                     wt[e] = pk_cmul(wt[e], rho);
                 }
 #pragma unroll
@@ -1577,8 +1549,8 @@ __global__ __launch_bounds__(256, 2) void k_fft16k_run(FftBatchParams p, uint32_
         }
         if (more) {
 #pragma unroll
-            for (int j = 0; j < 15; j++) { raw0[j] = raw0[j + 1]; raw1[j] = raw1[j + 1]; }
-            raw0[15] = nx0; raw1[15] = nx1;
+            for (int j = 0; j < 15; j++) raw[j] = raw[j + 1];
+            raw[15] = nx;
         }
         __syncthreads();                    // epilogue reads are done before the next window's pass-1 writes
     }
@@ -1611,7 +1583,7 @@ hipError_t launch_fft16k_run(FftBatchParams p, int mode, hipStream_t s)
     const uint64_t pairs = (uint64_t)p.n_streams * fft_ch;
     uint32_t groups = 1;
     fft16k_run_geometry(p.n_streams, fft_ch, p.n_windows, &p.windows_per_block, &groups);
-    const dim3 grid((uint32_t)((pairs * groups + 7) & ~(uint64_t)7)), block(256);      // multiple of 8: see the XCD mapping in the kernel
+    const dim3 grid((uint32_t)((pairs * groups + 7) & ~(uint64_t)7)), block(512);      // multiple of 8: see the XCD mapping in the kernel
     if (mode == 1) hipLaunchKernelGGL(k_fft16k_run<true>, grid, block, 0, s, p, fft_ch);
     else hipLaunchKernelGGL(k_fft16k_run<false>, grid, block, 0, s, p, fft_ch);
     return hipGetLastError();
