@@ -1432,8 +1432,18 @@ __global__ __launch_bounds__(512, SS_RUN8_WAVES) void k_fft16k_run(FftBatchParam
         // opaque copies of the two seeds keep the rebuild, 28 packed fma, inside the loop)
         v2f hcw = hc, hsw = hs;
         asm volatile("" : "+v"(hcw), "+v"(hsw));
+        // Slots j and j + 8 sit half a period apart: w[j + 8] = 1 - w[j], so x w[j + 8] = x - x w[j] is one fma on the weight
+        // its partner has built.  The SMALLER weight of a pair is the one that is built (slots 1..3 and 12..14; the edge slots
+        // 0 and 15 come from the table), the larger one — 0.5 or more, where an ulp of 1 does not matter — is derived:
+        // 28 packed instructions for the sixteen products instead of 44.
+        z[0] = raw[0] * we0;   z[8] = raw[8] - raw[8] * we0;
+        z[15] = raw[15] * we15; z[7] = raw[7] - raw[7] * we15;
 #pragma unroll
-        for (int j = 0; j < 16; j++) z[j] = raw[j] * (j == 0 ? we0 : (j == 15 ? we15 : half + hcw * cj[j] + hsw * sj[j]));
+        for (int j = 1; j <= 3; j++) {
+            const v2f wlo = half + hcw * cj[j] + hsw * sj[j], whi = half + hcw * cj[j + 11] + hsw * sj[j + 11];      // slots j and j + 11 = 12..14
+            z[j] = raw[j] * wlo;           z[j + 8] = raw[j + 8] - raw[j + 8] * wlo;
+            z[j + 11] = raw[j + 11] * whi; z[j + 3] = raw[j + 3] - raw[j + 3] * whi;
+        }
         fft16(z);
         xbuf[X1W(0, tb, hi)] = z[R16(0)];
 #pragma unroll
@@ -1520,7 +1530,7 @@ __global__ __launch_bounds__(512, SS_RUN8_WAVES) void k_fft16k_run(FftBatchParam
                     o0v[e] = xbuf2[1][pb[e]]; omv[e] = xbuf2[1][pm[e]];
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                float r[4];
+                float r[4], qv[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const v2f e0 = e0v[e], em = emv[e], o0 = o0v[e], om = omv[e];
@@ -1532,12 +1542,21 @@ __global__ __launch_bounds__(512, SS_RUN8_WAVES) void k_fft16k_run(FftBatchParam
                     v2f x = pk_cmul(a3, wt[e]) + a2;
                     x = pk_cmul(x, wt[e]) + a1;
                     x = pk_cmul(x, wt[e]) + a0;
-                    const float qv = fmaf(x.x, x.x, x.y * x.y);
-                    const float db = fmaf(__log2f(qv), kDb, off2);
-                    r[e] = qv == 0.0f ? -150.0f : db;
-                    pb[e] = (pb[e] + 2048u) & 4095u;
-                    pm[e] = (pm[e] - 2048u) & 4095u;
-                    wt[e] = pk_cmul(wt[e], rho);
+                    qv[e] = fmaf(x.x, x.x, x.y * x.y);
+                    pb[e] ^= 2048u;                                    // +-2048 mod 4096
+                    pm[e] ^= 2048u;
+                }
+                // an exact zero reads -150 (analyzer.rs:20-22): rare, so the wave first asks whether any of its magnitudes is zero
+                if (__builtin_expect(__ballot(fminf(fminf(qv[0], qv[1]), fminf(qv[2], qv[3])) == 0.0f) == 0ull, 1)) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) r[e] = fmaf(__log2f(qv[e]), kDb, off2);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) r[e] = qv[e] == 0.0f ? -150.0f : fmaf(__log2f(qv[e]), kDb, off2);
+                }
+                if (it + 1 < n_iter) {                                 // (the last iteration's turn would not be used)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) wt[e] = pk_cmul(wt[e], rho);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; e++) stg[64 * e + lane] = r[e];
