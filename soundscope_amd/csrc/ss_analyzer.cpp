@@ -32,6 +32,7 @@ SS_HIDDEN int handle_make_meter(ss_analyzer *h, uint32_t channels, uint32_t rate
     HIPCHK(counts.alloc(2));
     HIPCHK(out2.alloc(2));
     HIPCHK(ring_scratch.alloc(128));
+    HIPCHK(hipMemset(ring_scratch.p, 0, 128 * sizeof(double)));      // (k_ring_energy's completion counter starts at zero)
     std::vector<double> w(channels);
     sst::channel_weights(channels, w.data());
     HIPCHK(weights.upload(w));

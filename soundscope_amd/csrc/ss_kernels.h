@@ -152,7 +152,7 @@ hipError_t launch_hist_eval(const uint64_t *hist2000, const double *energies, co
 // mean-square of the filtered ring over the last `frames` frames (handle getters)
 hipError_t launch_ring_energy(const double *ring, uint64_t ring_frames, uint32_t channels,
                               uint64_t end_frame, uint64_t frames, const double *weights,
-                              double *out2 /* energy, loudness */, double *scratch /* >= 96 doubles */,
+                              double *out2 /* energy, loudness */, double *scratch /* >= 97 doubles, the 97th zero before the first launch */,
                               hipStream_t s);
 
 // ---- waveform ---------------------------------------------------------------

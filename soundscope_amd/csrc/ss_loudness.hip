@@ -278,13 +278,16 @@ hipError_t launch_hist_eval(const uint64_t *hist2000, const double *energies, co
 
 // mean square over the last `frames` frames of the filtered ring, channel-weighted
 // (calc_gating_block on the ring "as is": loudness_shortterm / loudness_momentary).
-// Two stages with a fixed reduction shape (bit-reproducible): kRingBlocks partial sums, then one block.
+// Two stages with a fixed reduction shape (bit-reproducible): kRingBlocks partial sums, then one block — in ONE launch: the
+// workgroup that finishes last (a counter behind the partial sums, wrapped back to zero by atomicInc for the next launch)
+// reduces the 96 partial sums.  (Through round 3 the second stage was a launch of its own: one more of a tick's launches.)
 constexpr int kRingBlocks = 96;
 __global__ __launch_bounds__(256) void k_ring_energy(const double *ring, uint64_t ring_frames, uint32_t C,
                                                      uint64_t end_frame, uint64_t frames,
-                                                     const double *weights, double *partial)
+                                                     const double *weights, double *partial, double *out)
 {
     __shared__ double red[256];
+    __shared__ uint32_t is_last;
     double acc = 0.0;
     const uint64_t total = frames * C;
     // ring position of absolute frame f is f % ring_frames; frames before 0 are the zeroed ring
@@ -301,14 +304,17 @@ __global__ __launch_bounds__(256) void k_ring_energy(const double *ring, uint64_
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
-}
-
-__global__ __launch_bounds__(128) void k_ring_final(const double *partial, uint64_t frames, double *out)
-{
-    __shared__ double red[128];
-    red[threadIdx.x] = threadIdx.x < kRingBlocks ? partial[threadIdx.x] : 0.0;
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = red[0];
+        __threadfence();                                                   // the partial sum is visible before the count
+        is_last = atomicInc(reinterpret_cast<unsigned int *>(partial + kRingBlocks), (unsigned int)kRingBlocks - 1u) == (unsigned int)kRingBlocks - 1u;
+    }
     __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    red[threadIdx.x] = threadIdx.x < kRingBlocks ? __builtin_nontemporal_load(partial + threadIdx.x) : 0.0;
+    __syncthreads();
+    // (a 128-wide tree over the 96 partial sums: the shape the second launch had)
     for (int s = 64; s >= 1; s >>= 1) {
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
@@ -320,13 +326,13 @@ __global__ __launch_bounds__(128) void k_ring_final(const double *partial, uint6
     }
 }
 
+// scratch: kRingBlocks partial sums + the completion counter (zero before the first launch, see ss_analyzer.cpp)
 hipError_t launch_ring_energy(const double *ring, uint64_t ring_frames, uint32_t channels,
                               uint64_t end_frame, uint64_t frames, const double *weights,
                               double *out, double *scratch, hipStream_t s)
 {
     hipLaunchKernelGGL(k_ring_energy, dim3(kRingBlocks), dim3(256), 0, s, ring, ring_frames, channels,
-                       end_frame % ring_frames, frames, weights, scratch);
-    hipLaunchKernelGGL(k_ring_final, dim3(1), dim3(128), 0, s, scratch, frames, out);
+                       end_frame % ring_frames, frames, weights, scratch, out);
     return hipGetLastError();
 }
 

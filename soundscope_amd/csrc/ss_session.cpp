@@ -270,10 +270,23 @@ int ss_session_lufs_history(ss_session *s, double *out300)
 }
 
 // analyze_audio_file_samples(pos) (tui.rs:1482-1552) on the resident file
+#ifdef SS_TUNING        // development builds only: where a tick's wall time goes on the host side (tools/probe_tick_host.py)
+#include <chrono>
+static double g_tick_prof[8];
+static inline double tick_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define SS_TICK_T(i) do { const double n_ = tick_now(); g_tick_prof[i] += n_ - t_; t_ = n_; } while (0)
+extern "C" void ss_debug_tick_prof(double *out8, int reset) { for (int i = 0; i < 8; i++) { out8[i] = g_tick_prof[i]; if (reset) g_tick_prof[i] = 0.0; } }
+#else
+#define SS_TICK_T(i)
+#endif
+
 int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side_xy,
                          size_t cap_pairs, ss_tick_result *res)
 {
     SS_ON_DEVICE(s);
+#ifdef SS_TUNING
+    double t_ = tick_now();
+#endif
     if (!s || !s->is_file || !res || !mid_xy || !side_xy) return SS_ERR_INVALID_ARG;
     if (cap_pairs < s->bt->count || cap_pairs < 1) return SS_ERR_CAPACITY;
     ss_analyzer *h = s->an;
@@ -308,6 +321,7 @@ int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side
         }
     }
 
+    SS_TICK_T(0);
     // ---- loudness: the last 16384 interleaved samples, every tick (8x overlap at hop 1024 frames)
     const size_t pos_i = pos_f * s->file_channels;
     const size_t lufs_lb = pos_i > SS_TICK_WINDOW ? pos_i - SS_TICK_WINDOW : 0;
@@ -317,6 +331,7 @@ int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side
         if (pos_i <= s->n_samples && lufs_lb < s->n_samples) {
             res->fed = 1;
             res->add_status = add_samples_impl(h, s->pcm.p + lufs_lb, SS_TICK_WINDOW, true);
+            SS_TICK_T(1);
             if (res->add_status == SS_ERR_DEVICE) return SS_ERR_DEVICE;
             if (!h->meter_ok) {
                 res->shortterm_status = SS_ERR_INVALID_MODE;
@@ -328,8 +343,11 @@ int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side
             }
         }
     }
+    SS_TICK_T(2);
     if (st_launched || res->fed) HIPCHK(hipStreamSynchronize(h->stream));
+    SS_TICK_T(3);
     if (fft_launched) HIPCHK(hipStreamSynchronize(s->fft_stream));
+    SS_TICK_T(4);
 
     if (res->fft_ran) {
         session_emit_spectrum(s, s->stage, fft_launched ? mid_st : (mid_st ? mid_st : SS_OK), mid_xy,
@@ -338,6 +356,7 @@ int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side
     }
     if (res->fed) s->lufs[SS_LUFS_HISTORY - 1] = st_launched ? s->stage_d[1] : 0.0;
     res->shortterm = s->lufs[SS_LUFS_HISTORY - 1];
+    SS_TICK_T(5);
     return SS_OK;
 }
 

@@ -190,6 +190,36 @@ def test_add_samples_streaming_matches_oracle(oracle, rate, slice_samples):
     assert lufs_close(an.get_shortterm_lufs(), m.shortterm())
 
 
+@pytest.mark.parametrize("rate,channels", [(48000, 2), (44100, 2), (96000, 2), (48000, 6), (48000, 1)])
+def test_streaming_tiles_shared_by_four_waves_equal_one_wave(rate, channels):
+    """A streaming call longer than one tile of the time-domain kernel is walked by the four waves of a workgroup, the filter
+    state and the lanes' energy shares handed from tile to tile through LDS (k_time_domain SPLIT); a call of at most one tile
+    runs on one wave.  The same programme fed in tick-sized calls (8192 frames: nine tiles at 48 kHz) and in single-tile
+    calls must leave the same meter: every reading to 1e-9 LU (the hand-over behind the scan is a different rounding of the
+    same state, 1e-16 relative; the energy sums keep their order), the carried state to 1e-9 of its largest component, the
+    sample peak exactly, the true peak to 1e-6 (a tile's f16-split scale looks at the twelve frames in front of it)."""
+    frames = rate * 4 + 123
+    x = make_multich(7 + channels, frames, channels, rate) if channels != 2 else make_stereo(7, frames, rate, level=0.7, gap=True)
+    small = 256                                                     # frames per call: inside one tile at every rate
+    big = 8192
+    a, b = ssa.Analyzer(), ssa.Analyzer()
+    a.create_loudness_meter(channels, rate); b.create_loudness_meter(channels, rate)
+    for off in range(0, frames, big):
+        a.add_samples(x[off * channels:(off + big) * channels])
+        for o2 in range(off, min(off + big, frames), small):
+            b.add_samples(x[o2 * channels:min(o2 + small, off + big, frames) * channels])
+        for name in ("get_shortterm_lufs", "get_momentary_lufs", "get_integrated_lufs", "get_loudness_range"):
+            va, vb = getattr(a, name)(), getattr(b, name)()
+            assert va == vb or abs(va - vb) <= 1e-9, (name, off, va, vb)
+        for c in range(channels):
+            ga, gb = a.filter_state(c), b.filter_state(c)
+            assert np.abs(ga - gb).max() <= 1e-9 * max(np.abs(gb).max(), 1e-300), (off, c, ga, gb)
+            assert a.get_sample_peak_channel(c) == b.get_sample_peak_channel(c)
+            ta, tb = a.get_true_peak_channel(c), b.get_true_peak_channel(c)
+            assert abs(ta - tb) <= 1e-6 * tb, (off, c, ta, tb)
+    a.close(); b.close()
+
+
 def test_tick_driver_quirk_overlapping_refeed(oracle):
     """tui.rs:1528-1543: every tick re-feeds the last 16384 interleaved samples (8x overlap)."""
     rate = 48000

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Where a session tick's wall time goes on the host side (needs a -DSS_TUNING build: ss_debug_tick_prof).
+[0] checks + spectrum enqueue, [1] add_samples enqueue, [2] short-term enqueue + read-back request, [3] wait for the loudness
+stream, [4] wait for the spectrum stream, [5] emitting the two spectra on the host"""
+import ctypes as C, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import soundscope_amd as ssa
+from soundscope_amd import _lib as L
+from conftest import make_stereo
+rate = 48000
+x = make_stereo(1, rate * 12, rate)
+sess = ssa.FileSession(x, 2, rate)
+f = C.CDLL(L.LIB_PATH).ss_debug_tick_prof
+f.argtypes = [C.POINTER(C.c_double), C.c_int]
+out = (C.c_double * 8)()
+pos = list(range(16384 * 2 + 2048, x.size, 2048))
+for p in pos[:20]:
+    sess.analyze_audio_file_samples(p)
+f(out, 1)
+t0 = time.perf_counter()
+for p in pos[20:]:
+    sess.analyze_audio_file_samples(p)
+wall = (time.perf_counter() - t0) / len(pos[20:]) * 1e6
+f(out, 1)
+n = len(pos[20:])
+names = ["checks + spectrum enqueue", "add_samples enqueue", "short-term enqueue + read-back request", "wait: loudness stream",
+         "wait: spectrum stream", "emit spectra (host)"]
+print(f"tick wall (python loop) {wall:.1f} us")
+for i, nm in enumerate(names):
+    print(f"  {out[i] / n:7.1f} us  {nm}")
