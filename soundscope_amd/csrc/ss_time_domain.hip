@@ -417,8 +417,54 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, WPS) void k_time_domain(TdPa
     SS_PREFETCH(pos, seg);
     SS_PROF_DECL
 
+    // ---- fold this wave's results into the stream state (a lambda: a wave without a single tile — an empty segment of a
+    // ragged batch — leaves through it in front of the tile loop, so that the loop itself runs at least once and the compiler
+    // keeps no spare copy of the initial state for a zero-trip path)
+    auto fold_results = [&](const uint32_t ti) {
+    // SPLIT: the carried state (filter, energy shares, history) is the last tile's; its wave writes it, the others only their peaks
+    const bool state_owner = !SPLIT || (ti != 0u && ((ti - 1u) & (uint32_t)(kTdWavesPerBlock - 1)) == wave_in_block) || (ti == 0u && wave_in_block == 0u);
+    if (SPLIT && state_owner && ti != 0u) e_run = sh->e_lane[lane];
+    // energy of the trailing incomplete sub-block: reduce the lanes' shares (streaming calls carry it over)
+    {
+        double e = e_run;
+        for (uint32_t d = 32; d >= 1; d >>= 1) {
+            const double o = __shfl_down(e, d * C, 64);
+            if (lane + d * C < 64u) e += o;
+        }
+        e_run = e;
+    }
+    for (uint32_t d = 32; d >= 1; d >>= 1) {
+        const float o = __shfl_down(sp_run, d * C, 64);
+        if (lane + d * C < 64u) sp_run = fmaxf(sp_run, o);
+    }
+    if (FACTOR != 0 && tp_fixed) {
+        uint32_t lane_f = lane;                          // (rebuilt here: see the rare paths of the true-peak product)
+        asm volatile("" : "+v"(lane_f));
+        atomicMax(&tpk[(lane_f & 15u) % C], __float_as_uint(tp_run));
+    }
+    {
+        uint32_t lane_p = lane;
+        asm volatile("" : "+v"(lane_p));
+        if (lane_p < C) {
+            if (FACTOR != 0) atomicMax(reinterpret_cast<unsigned *>(&st.true_peak[lane_p]), tpk[lane_p]);
+            atomicMax(reinterpret_cast<unsigned *>(&st.sample_peak[lane_p]), __float_as_uint(sp_run));
+        }
+    }
+    if (sg + 1 == p.nseg && state_owner) {               // the last segment owns the carried filter state
+        if (lane_ok && chunk == 0) {             // ... flushed like at the end of every add_frames call (see the sub-block boundary above)
+#pragma unroll
+            for (int q = 0; q < 4; q++) st.v[ch][q] = fabs(cv[q]) < 2.2250738585072014e-308 ? 0.0 : cv[q];
+        }
+        if (lane < C) {
+            st.acc[lane] = e_run;
+            for (int q = 1; q <= kTpHistMax; q++) st.tp_hist[lane][q - 1] = tile[-(int)(q * C) + (int)lane];
+        }
+        if (lane == 0) st.frames_fed = fed0 + n_frames;
+    }
+    };
+    if (seg == 0) { fold_results(0u); return; }
     uint32_t ti = 0;                                    // index of the tile within the call (SPLIT: whose turn it is)
-    while (seg != 0) {
+    do {
         // the tile behind this one
         const uint64_t npos = pos + seg;
         uint32_t noff = off + seg, ntoff = toff + seg;
@@ -454,7 +500,9 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, WPS) void k_time_domain(TdPa
                     }
                 }
                 const float4 *g4 = reinterpret_cast<const float4 *>(g);
-                for (uint32_t i = lane + 64u * (SPLIT ? 0 : kTdPrefetch); i < nv; i += 64u) t4[i] = g4[i];     // SPLIT: no register prefetch (the other waves' tiles lie between)
+                uint32_t lane_s = lane;
+                asm volatile("" : "+v"(lane_s));
+                for (uint32_t i = lane_s + 64u * (SPLIT ? 0 : kTdPrefetch); i < nv; i += 64u) t4[i] = g4[i];   // SPLIT: no register prefetch (the other waves' tiles lie between)
                 done = nv << 2;
             }
             for (uint32_t i = done + lane; i < total; i += 64u) tile[i] = g[i];
@@ -810,7 +858,9 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, WPS) void k_time_domain(TdPa
                     const double o = __shfl_down(e, d * C, 64);
                     if (lane + d * C < 64u) e += o;
                 }
-                if (lane < C) p.subblocks[(size_t)stream * p.sub_stride + (size_t)slot * C + lane] = e;
+                uint32_t lane_e = lane;
+                asm volatile("" : "+v"(lane_e));
+                if (lane_e < C) p.subblocks[(size_t)stream * p.sub_stride + (size_t)slot * C + lane_e] = e;
             }
             e_run = 0.0;
             // ebur128 flushes sub-normal filter state to zero at the end of every internal filter call (restated at
@@ -863,7 +913,12 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, WPS) void k_time_domain(TdPa
                     tp_run = fmaxf(fmaxf(tp_run, fmaxf(fabsf(acc0[0]), fabsf(acc0[1]))), fmaxf(fabsf(acc0[2]), fabsf(acc0[3])));
                     tp_run = fmaxf(fmaxf(tp_run, fmaxf(fabsf(acc1[0]), fabsf(acc1[1]))), fmaxf(fabsf(acc1[2]), fabsf(acc1[3])));
                 }
+                // (rare paths below rebuild what they need from an opaque copy of the lane id: hoisted out of the tile loop their
+                // lane-dependent constants were what the four-waves-per-SIMD build kept in scratch)
                 for (; gi < ngroups; gi++, bp += GS) {                     // odd full group and the masked tail
+                    uint32_t lane_t = lane;
+                    asm volatile("" : "+v"(lane_t));
+                    const int kq = (int)(lane_t >> 4), mrow = (int)(lane_t & 15u);
                     const uint32_t bi = gi * tp_bpg + (uint32_t)mrow / C;
                     const bool col_ok = (gi * 16 + (uint32_t)mrow) < ncol;
                     floatx4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -993,46 +1048,64 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, WPS) void k_time_domain(TdPa
                         auto absmax4 = [](float m, const floatx4 &a) {
                             return fmaxf(fmaxf(fmaxf(m, fabsf(a[0])), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3])));
                         };
-                        const uint32_t nquad = nplanar >> 2;
+#ifndef SS_TD_MFMA_GROUPS4
+#define SS_TD_MFMA_GROUPS4 2      // groups per iteration of this loop in the four-waves-per-SIMD build (the three-waves build: 4)
+#endif
+                        constexpr int NG = (WPS >= 4) ? SS_TD_MFMA_GROUPS4 : 4;              // independent accumulator chains (2 or 4)
+                        constexpr int NGS = NG == 4 ? 2 : 1;
+                        const uint32_t nquad = nplanar >> NGS;
                         if (nquad) {
-                            halfx4 h[4], l[4];
+                            halfx4 h[NG], l[NG];
 #pragma unroll
-                            for (int g = 0; g < 4; g++) { h[g] = ld4(ph, 256 * g); l[g] = ld4(ph, 256 * g + 128); }
+                            for (int g = 0; g < NG; g++) { h[g] = ld4(ph, 256 * g); l[g] = ld4(ph, 256 * g + 128); }
                             for (uint32_t it = 0; it < nquad; it++) {
-                                ph += (it + 1 < nquad) ? 1024 : 0;         // the last iteration re-reads its own operands: nothing past the planes
-                                halfx4 hn[4], ln[4];
+                                ph += (it + 1 < nquad) ? 256 * NG : 0;     // the last iteration re-reads its own operands: nothing past the planes
+                                halfx4 hn[NG], ln[NG];
 #pragma unroll
-                                for (int g = 0; g < 4; g++) { hn[g] = ld4(ph, 256 * g); ln[g] = ld4(ph, 256 * g + 128); }
-                                floatx4 acc[4];
+                                for (int g = 0; g < NG; g++) { hn[g] = ld4(ph, 256 * g); ln[g] = ld4(ph, 256 * g + 128); }
+                                floatx4 acc[NG];
 #pragma unroll
-                                for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_hi, h[g], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                                for (int g = 0; g < NG; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_hi, h[g], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-                                for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_hi, l[g], acc[g], 0, 0, 0);
+                                for (int g = 0; g < NG; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_hi, l[g], acc[g], 0, 0, 0);
 #pragma unroll
-                                for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_lo, h[g], acc[g], 0, 0, 0);
-                                // max |.| of the sixteen results: v_max3 with |abs| source modifiers, eight instructions (through the
-                                // fmaxf / fabsf builtins the compiler quiets every operand first: seventeen).  The s_nop are the six
-                                // wait states a VALU read needs behind a four-pass MFMA write, which inline asm hides from the compiler.
-                                asm volatile("s_nop 5\n\t"
-                                             "v_max3_f32 %0, %0, |%1|, |%2|\n\t"
-                                             "v_max3_f32 %0, %0, |%3|, |%4|\n\t"
-                                             "v_max3_f32 %0, %0, |%5|, |%6|\n\t"
-                                             "v_max3_f32 %0, %0, |%7|, |%8|\n\t"
-                                             "v_max3_f32 %0, %0, |%9|, |%10|\n\t"
-                                             "v_max3_f32 %0, %0, |%11|, |%12|\n\t"
-                                             "v_max3_f32 %0, %0, |%13|, |%14|\n\t"
-                                             "v_max3_f32 %0, %0, |%15|, |%16|"
-                                             : "+v"(m16)
-                                             : "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[0][2]), "v"(acc[0][3]),
-                                               "v"(acc[1][0]), "v"(acc[1][1]), "v"(acc[1][2]), "v"(acc[1][3]),
-                                               "v"(acc[2][0]), "v"(acc[2][1]), "v"(acc[2][2]), "v"(acc[2][3]),
-                                               "v"(acc[3][0]), "v"(acc[3][1]), "v"(acc[3][2]), "v"(acc[3][3]));
+                                for (int g = 0; g < NG; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_lo, h[g], acc[g], 0, 0, 0);
+                                // max |.| of the results: v_max3 with |abs| source modifiers, two instructions per group (through the
+                                // fmaxf / fabsf builtins the compiler quiets every operand first: more than twice as many).  ONE asm
+                                // statement naming every accumulator (so that it cannot be scheduled in front of any of the MFMAs), with
+                                // the wait states a VALU read needs behind an MFMA write inside the string — inline asm hides the hazard
+                                // from the compiler: twelve states between the LAST MFMA and the v_max3 that reads its result (the last
+                                // accumulator is read by the last two v_max3).
+                                if (NG == 4)
+                                    asm volatile("s_nop 5\n\t"
+                                                 "v_max3_f32 %0, %0, |%1|, |%2|\n\t"
+                                                 "v_max3_f32 %0, %0, |%3|, |%4|\n\t"
+                                                 "v_max3_f32 %0, %0, |%5|, |%6|\n\t"
+                                                 "v_max3_f32 %0, %0, |%7|, |%8|\n\t"
+                                                 "v_max3_f32 %0, %0, |%9|, |%10|\n\t"
+                                                 "v_max3_f32 %0, %0, |%11|, |%12|\n\t"
+                                                 "v_max3_f32 %0, %0, |%13|, |%14|\n\t"
+                                                 "v_max3_f32 %0, %0, |%15|, |%16|"
+                                                 : "+v"(m16)
+                                                 : "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[0][2]), "v"(acc[0][3]),
+                                                   "v"(acc[1][0]), "v"(acc[1][1]), "v"(acc[1][2]), "v"(acc[1][3]),
+                                                   "v"(acc[NG - 2][0]), "v"(acc[NG - 2][1]), "v"(acc[NG - 2][2]), "v"(acc[NG - 2][3]),
+                                                   "v"(acc[NG - 1][0]), "v"(acc[NG - 1][1]), "v"(acc[NG - 1][2]), "v"(acc[NG - 1][3]));
+                                else
+                                    asm volatile("s_nop 10\n\t"
+                                                 "v_max3_f32 %0, %0, |%1|, |%2|\n\t"
+                                                 "v_max3_f32 %0, %0, |%3|, |%4|\n\t"
+                                                 "v_max3_f32 %0, %0, |%5|, |%6|\n\t"
+                                                 "v_max3_f32 %0, %0, |%7|, |%8|"
+                                                 : "+v"(m16)
+                                                 : "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[0][2]), "v"(acc[0][3]),
+                                                   "v"(acc[NG - 1][0]), "v"(acc[NG - 1][1]), "v"(acc[NG - 1][2]), "v"(acc[NG - 1][3]));
 #pragma unroll
-                                for (int g = 0; g < 4; g++) { h[g] = hn[g]; l[g] = ln[g]; }
+                                for (int g = 0; g < NG; g++) { h[g] = hn[g]; l[g] = ln[g]; }
                             }
-                            ph += 1024;
+                            ph += 256 * NG;
                         }
-                        for (uint32_t g = nquad << 2; g < nplanar; g++, ph += 256) {      // up to three groups left
+                        for (uint32_t g = nquad << NGS; g < nplanar; g++, ph += 256) {    // up to NG - 1 groups left
                             const halfx4 h0 = ld4(ph, 0), l0 = ld4(ph, 128);
                             floatx4 acc0 = {0.f, 0.f, 0.f, 0.f};
                             acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(a16_hi, h0, acc0, 0, 0, 0);
@@ -1098,42 +1171,10 @@ __global__ __launch_bounds__(64 * kTdWavesPerBlock, WPS) void k_time_domain(TdPa
         seg = nseg_frames;
         ti++;
         SS_PROF_MARK(7);
-    }
+    } while (seg != 0);
     SS_PROF_END;
 
-    // ---- fold this wave's results into the stream state
-    // SPLIT: the carried state (filter, energy shares, history) is the last tile's; its wave writes it, the others only their peaks
-    const bool state_owner = !SPLIT || (ti != 0u && ((ti - 1u) & (uint32_t)(kTdWavesPerBlock - 1)) == wave_in_block) || (ti == 0u && wave_in_block == 0u);
-    if (SPLIT && state_owner && ti != 0u) e_run = sh->e_lane[lane];
-    // energy of the trailing incomplete sub-block: reduce the lanes' shares (streaming calls carry it over)
-    {
-        double e = e_run;
-        for (uint32_t d = 32; d >= 1; d >>= 1) {
-            const double o = __shfl_down(e, d * C, 64);
-            if (lane + d * C < 64u) e += o;
-        }
-        e_run = e;
-    }
-    for (uint32_t d = 32; d >= 1; d >>= 1) {
-        const float o = __shfl_down(sp_run, d * C, 64);
-        if (lane + d * C < 64u) sp_run = fmaxf(sp_run, o);
-    }
-    if (FACTOR != 0 && tp_fixed) atomicMax(&tpk[tp_c], __float_as_uint(tp_run));
-    if (lane < C) {
-        if (FACTOR != 0) atomicMax(reinterpret_cast<unsigned *>(&st.true_peak[lane]), tpk[lane]);
-        atomicMax(reinterpret_cast<unsigned *>(&st.sample_peak[lane]), __float_as_uint(sp_run));
-    }
-    if (sg + 1 == p.nseg && state_owner) {               // the last segment owns the carried filter state
-        if (lane_ok && chunk == 0) {             // ... flushed like at the end of every add_frames call (see the sub-block boundary above)
-#pragma unroll
-            for (int q = 0; q < 4; q++) st.v[ch][q] = fabs(cv[q]) < 2.2250738585072014e-308 ? 0.0 : cv[q];
-        }
-        if (lane < C) {
-            st.acc[lane] = e_run;
-            for (int q = 1; q <= kTpHistMax; q++) st.tp_hist[lane][q - 1] = tile[-(int)(q * C) + (int)lane];
-        }
-        if (lane == 0) st.frames_fed = fed0 + n_frames;
-    }
+    fold_results(ti);
 #undef SS_TILE_FRAMES
 #undef SS_PREFETCH
 }
