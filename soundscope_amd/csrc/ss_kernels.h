@@ -178,6 +178,8 @@ hipError_t launch_mid_side(const float *interleaved, size_t frames, float *mid, 
 // verification utility: out[item * out_stride] += order-independent checksum of words [item * stride_words, + words) (32-bit words)
 hipError_t launch_checksum(const void *base, uint64_t words, uint64_t stride_words, uint32_t n_items, uint64_t *out,
                            uint32_t out_stride, hipStream_t s);
+// clears up to four device buffers (byte counts: multiples of four; null / zero entries are skipped) in one launch
+hipError_t launch_zero4(void *const ptrs[4], const size_t bytes[4], hipStream_t s);
 // measurement utility: k_fft4096_ms1's loads and stores with no arithmetic (same grid, occupancy and addresses)
 hipError_t launch_fft4096_traffic(const FftBatchParams &p, hipStream_t s);
 hipError_t launch_synth(float *pcm, uint32_t n_streams, uint64_t frames, uint32_t channels,

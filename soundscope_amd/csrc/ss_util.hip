@@ -286,6 +286,44 @@ hipError_t launch_checksum(const void *base, uint64_t words, uint64_t stride_wor
     return hipSuccess;
 }
 
+// ---- one launch that clears up to four buffers (a pass's per-stream meter state, histograms, corpus histograms and block
+// counts: four hipMemsetAsync = four fill kernels before; a one-stream pass is launch-bound)
+struct Zero4 { uint32_t *p[4]; uint64_t words[4]; };
+__global__ __launch_bounds__(256) void k_zero4(Zero4 z)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x, nthreads = (uint64_t)gridDim.x * 256;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        uint32_t *p = z.p[b];
+        const uint64_t n = z.words[b];
+        if (!p || !n) continue;
+        if ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
+            const uint64_t n4 = n >> 2;
+            for (uint64_t i = tid; i < n4; i += nthreads) reinterpret_cast<uint4 *>(p)[i] = make_uint4(0u, 0u, 0u, 0u);
+            for (uint64_t i = (n4 << 2) + tid; i < n; i += nthreads) p[i] = 0u;
+        } else {
+            for (uint64_t i = tid; i < n; i += nthreads) p[i] = 0u;
+        }
+    }
+}
+
+hipError_t launch_zero4(void *const ptrs[4], const size_t bytes[4], hipStream_t s)
+{
+    Zero4 z{};
+    uint64_t most = 0;
+    for (int b = 0; b < 4; b++) {
+        if (bytes[b] & 3u) return hipErrorInvalidValue;
+        z.p[b] = static_cast<uint32_t *>(ptrs[b]); z.words[b] = bytes[b] >> 2;
+        if (z.words[b] > most) most = z.words[b];
+    }
+    if (!most) return hipSuccess;
+    uint64_t blocks = (most / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_zero4, dim3((uint32_t)blocks), dim3(256), 0, s, z);
+    return hipGetLastError();
+}
+
 // ---- measurement utility: the spectrum kernel's HBM traffic with no arithmetic -----------------------------------------
 // Same grid, same workgroup size, same LDS footprint (so the same three workgroups per CU), same addresses: every
 // workgroup walks its run of windows, loads the four new 256-frame slots of each window (8-byte loads) and stores the two
