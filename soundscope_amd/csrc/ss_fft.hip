@@ -54,12 +54,15 @@ __device__ __forceinline__ v2f pk_add_ib(v2f a, v2f b)
     return r;
 }
 // a * w (complex): m = (a.y w.y, a.y w.x); r = (a.x w.x - m.x, a.x w.y + m.y)
+// (ONE asm statement for the dependent pair: behind every asm statement whose output the next VALU instruction reads, hipcc
+// pads an s_nop — written as two statements a complex multiply carried two of them, eighty issue slots per window in
+// k_fft4096_ms1; the hardware interlocks a VALU result read by the next VALU instruction by itself)
 __device__ __forceinline__ v2f pk_cmul(v2f a, v2f w)
 {
     v2f m, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(m) : "v"(a), "v"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,0]"
-        : "=v"(r) : "v"(a), "v"(w), "v"(m));
+    asm("v_pk_mul_f32 %1, %2, %3 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,0]"
+        : "=v"(r), "=&v"(m) : "v"(a), "v"(w));
     return r;
 }
 // a * w for a compile-time constant w held in a scalar register pair (the three constants of fft16: left to the "v"
@@ -67,9 +70,9 @@ __device__ __forceinline__ v2f pk_cmul(v2f a, v2f w)
 __device__ __forceinline__ v2f pk_cmul_k(v2f a, v2f w)
 {
     v2f m, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(m) : "v"(a), "s"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,0]"
-        : "=v"(r) : "v"(a), "s"(w), "v"(m));
+    asm("v_pk_mul_f32 %1, %2, %3 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,0]"
+        : "=v"(r), "=&v"(m) : "v"(a), "s"(w));
     return r;
 }
 // (a.x + a.y, a.y - a.x) = a - i a      [times R gives a * W16^2]
