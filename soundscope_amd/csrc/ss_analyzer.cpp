@@ -178,6 +178,15 @@ int ss_get_fft(const ss_analyzer *hc, const float *samples, size_t n,
     if (n == 16384) {
         p.tw_core = ft->core_tw4096; p.tw_256 = ft->core_tw256;
         HIPCHK(ssk::launch_fft16k(p, 0, h->stream));
+    } else if (n == 4096) {
+        // the radix-16 machine of the batch path on one window: k_fft4096_pairw with its second window absent
+        // (through round 3 this size took k_fft_generic's radix-2 passes)
+        p.hop = 1024; p.windows_per_block = 2;
+        p.bin_stride = (uint32_t)((bt->count + 3) & ~(size_t)3);
+        p.db_offset = (float)(10.0 * std::log10(4.0 / (4096.0 * 4096.0)));
+        p.offpink = bt->off4096_dev.p;
+        p.publish_mask = ssk::fft4096_publish_mask(p.first_bin, p.n_bins);
+        HIPCHK(ssk::launch_fft4096_pairw(p, 0, h->stream));
     } else {
         HIPCHK(ssk::launch_fft_generic(p, 0, h->stream));
     }

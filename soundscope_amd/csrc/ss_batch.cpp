@@ -514,17 +514,7 @@ int ss_batch_run(ss_batch *b)
         if (b->fft_fast || b->fft_pairw) {
             p.db_offset = (float)(10.0 * std::log10(4.0 / ((double)c.fft_n * (double)c.fft_n)));
             p.offpink = b->bt->offpink4096_dev.p;
-            {
-                const uint32_t lo = L.first_bin, hi = L.first_bin + L.n_bins - 1;      // retained bins and their mirrors
-                uint32_t mask = 0;
-                for (uint32_t kc = 0; kc < 16; kc++) {
-                    const uint32_t a0 = 256 * kc, a1 = a0 + 255;
-                    const bool direct = a0 <= hi + 3 && a1 >= lo;                       // +3: the last group of four may run past
-                    const bool mirror = a0 <= 4096 - lo && a1 + 3 >= 4096 - hi - 3;
-                    if (direct || mirror) mask |= 1u << kc;
-                }
-                p.publish_mask = mask;
-            }
+            p.publish_mask = ssk::fft4096_publish_mask(L.first_bin, L.n_bins);
             if (b->fft_fast) HIPCHK(ssk::launch_fft4096_ms(p, fft_stream));
             else HIPCHK(ssk::launch_fft4096_pairw(p, b->fft_mode, fft_stream));
         } else {

@@ -372,9 +372,12 @@ __device__ __forceinline__ void fft4096_floor_rows(int t, uint32_t n_bins, float
     const float lg0 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint((-150.0f - db_offset) / kDb)));
     const uint32_t ngroups = (n_bins + 3) >> 2;
     __builtin_amdgcn_s_waitcnt(0);                  // the ordinary stores of these rows have left the wave: these come after them
+    (void)kDb; (void)lg0;
     for (uint32_t g = (uint32_t)t; g < ngroups; g += 256u) {
         const float4 op = *reinterpret_cast<const float4 *>(offpink + 4 * g);
-        const float4 v = make_float4(fmaf(lg0, kDb, op.x), fmaf(lg0, kDb, op.y), fmaf(lg0, kDb, op.z), fmaf(lg0, kDb, op.w));
+        // -150 + pink, with pink = table - offset: EXACTLY -150 where the table carries no compensation (ss_get_fft's, which
+        // adds it in f64 on the host like analyzer.rs:82 — a buffer of zeros must read -150 to the bit there)
+        const float4 v = make_float4(-150.0f + (op.x - db_offset), -150.0f + (op.y - db_offset), -150.0f + (op.z - db_offset), -150.0f + (op.w - db_offset));
         if (first_zero) reinterpret_cast<float4 *>(o_first)[g] = v;
         if (second_zero) reinterpret_cast<float4 *>(o_second)[g] = v;
     }

@@ -152,6 +152,7 @@ int get_bin_tables(uint32_t rate, size_t n, BinTables **out)
         std::vector<float> op(pf.size());
         for (size_t i = 0; i < pf.size(); i++) op[i] = off + pf[i];
         HIPCHK(t->offpink4096_dev.upload(op));
+        HIPCHK(t->off4096_dev.upload(std::vector<float>(pf.size(), off)));
     }
     *out = t.get();
     c.bins[key] = std::move(t);

@@ -81,6 +81,7 @@ struct BinTables {
     std::vector<double> freq, pink, chart_x;
     DevBuf<float> pink_dev;
     DevBuf<float> offpink4096_dev;      // db_offset(4096) + pink, for the N = 4096 kernels
+    DevBuf<float> off4096_dev;          // db_offset(4096) alone (ss_get_fft adds the pink compensation in f64 on the host, analyzer.rs:82)
 };
 
 struct TdTables {

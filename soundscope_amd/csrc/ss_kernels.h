@@ -67,6 +67,20 @@ struct FftBatchParams {
     float gain_db;
 };
 
+// N = 4096 kernels: bit kc set when bins [256 kc, 256 kc + 255] hold a retained bin or the mirror 4096 - k of one (the other
+// blocks of the transform are not published to LDS)
+inline uint32_t fft4096_publish_mask(uint32_t first_bin, uint32_t n_bins)
+{
+    const uint32_t lo = first_bin, hi = first_bin + n_bins - 1;
+    uint32_t mask = 0;
+    for (uint32_t kc = 0; kc < 16; kc++) {
+        const uint32_t a0 = 256 * kc, a1 = a0 + 255;
+        const bool direct = a0 <= hi + 3 && a1 >= lo;                       // +3: the last group of four may run past
+        const bool mirror = a0 <= 4096 - lo && a1 + 3 >= 4096 - hi - 3;
+        if (direct || mirror) mask |= 1u << kc;
+    }
+    return mask;
+}
 // mid/side packed N=4096 kernel (stereo only).  hop must be a multiple of 256.
 hipError_t launch_fft4096_ms(const FftBatchParams &p, hipStream_t s);
 // any power-of-two N in [2, 32768]; mode 0: mono buffers (channels == 1),
