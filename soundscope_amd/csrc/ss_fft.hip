@@ -426,8 +426,8 @@ __device__ __forceinline__ void fft4096_floor_columns(int t, uint32_t n_bins, fl
 //      pass structure already has).  A window is four hops; the two inner ones carry Hann weights in [1/2, 1], the two outer
 //      ones in [0, 1/2].  While the outer hops are at most twice as loud as the inner ones, the windowed level of a row is
 //      within a factor two of its inner hops' raw level and E follows from those (the ordinary case: no extra work).
-//      Otherwise (an onset or a decay inside the window) the workgroup takes the exact path: largest |sample x weight| over
-//      the window for both rows, one more barrier — rare, and uniform across the workgroup.
+//      Otherwise (an onset or a decay inside the window) the workgroup takes the exact path: the windowed energy
+//      sum (sample x weight)^2 of either row (block_exp_energy), one more barrier — rare, and uniform across the workgroup.
 //    * The second signal's registers are kept multiplied by 2^E (ms1) or its window weights are (pairw), and rewritten only
 //      when E moves by two or more: the ordinary window pays for the level of the entering hop, four scalings and two
 //      packed adds per group of bins.
@@ -447,6 +447,37 @@ __device__ __forceinline__ uint32_t wave_umax_lane63(uint32_t v)
     SS_UMAX_DPP(0x143, 0xC);    // row_bcast:31  rows 2 and 3 take in lane 31: lane 63 holds the wave's
 #undef SS_UMAX_DPP
     return v;
+}
+// sum over the wave of a float; the result stands in lane 63 (fixed order: the same bits on every launch)
+__device__ __forceinline__ float wave_fsum_lane63(float v)
+{
+#define SS_FSUM_DPP(ctrl, rows) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rows, 0xF, true))
+    SS_FSUM_DPP(0x111, 0xF);    // row_shr:1
+    SS_FSUM_DPP(0x112, 0xF);    // row_shr:2
+    SS_FSUM_DPP(0x114, 0xF);    // row_shr:4
+    SS_FSUM_DPP(0x118, 0xF);    // row_shr:8     lane 15 of every row holds its row's sum
+    SS_FSUM_DPP(0x142, 0xA);    // row_bcast:15  rows 1 and 3 take in rows 0 and 2
+    SS_FSUM_DPP(0x143, 0xC);    // row_bcast:31  rows 2 and 3 take in lane 31: lane 63 holds the wave's
+#undef SS_FSUM_DPP
+    return v;
+}
+// the same from two windowed ENERGIES (sums of squares): half the exponent of their ratio.  The exact path matches energies,
+// not peaks: a transform's rounding noise in every bin goes with the total energy of what it carries, so a row keeps its own
+// noise floor when the other row, scaled, carries about the same energy — whatever the two crest factors are (a decaying
+// burst under the window's edge beside a steady row: peak-matched, the burst's row sat 18 dB under its partner's spectrum).
+__device__ __forceinline__ int block_exp_energy(uint32_t a, uint32_t b)
+{
+    const int e = ((int)a - (int)b + (1 << 23)) >> 24;
+    return e < -60 ? -60 : (e > 60 ? 60 : e);
+}
+// the four waves' energy pairs (lv[wave][first, second], floats) -> the workgroup's, in scalar registers
+__device__ __forceinline__ void read_energies2(const uint32_t (*lv)[2], uint32_t &a, uint32_t &b)
+{
+    const uint4 q0 = *reinterpret_cast<const uint4 *>(&lv[0][0]), q1 = *reinterpret_cast<const uint4 *>(&lv[2][0]);
+    const float sa = (__uint_as_float(q0.x) + __uint_as_float(q0.z)) + (__uint_as_float(q1.x) + __uint_as_float(q1.z));
+    const float sb = (__uint_as_float(q0.y) + __uint_as_float(q0.w)) + (__uint_as_float(q1.y) + __uint_as_float(q1.w));
+    a = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(sa));
+    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(sb));
 }
 // exponent that lifts a row at level b to a row at level a (bit patterns of positive floats)
 __device__ __forceinline__ int block_exp(uint32_t a, uint32_t b)
@@ -485,7 +516,7 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
     __shared__ __attribute__((aligned(16))) v2f tw2s[256];                //  2048 B
     // exact block exponents ("Two rows, one transform"): [wave][window 0 mid, side, window 1 mid, side] = largest windowed
     // magnitude of that wave's lanes (bit patterns; 0 = the row is empty and reads the floor)
-    __shared__ __attribute__((aligned(16))) uint32_t xlev4[4][4];
+    __shared__ __attribute__((aligned(16))) uint32_t xlev4[4][8];          // [wave][4 peaks, 4 energies]
 
     const int t = threadIdx.x;
     const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
@@ -531,27 +562,45 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
         const bool two = (w + 1 < w_end);
         // levels of the four rows of this pair of windows, exact: largest |sample x weight| over the workgroup (the loop-end
         // barrier has retired the previous iteration's reads of xlev4)
-        uint32_t X[4];
+        uint32_t X[4], G[4];          // peaks (0 = the row is empty) and energies (what the exponent matches, see block_exp_energy)
         {
-            float x0 = 0.0f, x1 = 0.0f, x2 = 0.0f, x3 = 0.0f;
+            float x0 = 0.0f, x1 = 0.0f, x2 = 0.0f, x3 = 0.0f, g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
 #pragma unroll
             for (int j = 0; j < 16; j++) {
-                x0 = fmaxf(x0, fabsf(sm[j] * hw[j])); x1 = fmaxf(x1, fabsf(df[j] * hw[j]));
-                x2 = fmaxf(x2, fabsf(sm[j + HS] * hw[j])); x3 = fmaxf(x3, fabsf(df[j + HS] * hw[j]));
+                const float a0 = sm[j] * hw[j], a1 = df[j] * hw[j], a2 = sm[j + HS] * hw[j], a3 = df[j + HS] * hw[j];
+                x0 = fmaxf(x0, fabsf(a0)); x1 = fmaxf(x1, fabsf(a1)); x2 = fmaxf(x2, fabsf(a2)); x3 = fmaxf(x3, fabsf(a3));
+                g0 = fmaf(a0, a0, g0); g1 = fmaf(a1, a1, g1); g2 = fmaf(a2, a2, g2); g3 = fmaf(a3, a3, g3);
             }
             const uint32_t l0 = wave_umax_lane63(__float_as_uint(x0)), l1 = wave_umax_lane63(__float_as_uint(x1));
             const uint32_t l2 = wave_umax_lane63(__float_as_uint(x2)), l3 = wave_umax_lane63(__float_as_uint(x3));
-            if ((t & 63) == 63) *reinterpret_cast<uint4 *>(xlev4[wvid]) = make_uint4(l0, l1, l2, l3);
+            const float s0 = wave_fsum_lane63(g0), s1 = wave_fsum_lane63(g1), s2 = wave_fsum_lane63(g2), s3 = wave_fsum_lane63(g3);
+            if ((t & 63) == 63) {
+                *reinterpret_cast<uint4 *>(&xlev4[wvid][0]) = make_uint4(l0, l1, l2, l3);
+                *reinterpret_cast<uint4 *>(&xlev4[wvid][4]) = make_uint4(__float_as_uint(s0), __float_as_uint(s1), __float_as_uint(s2), __float_as_uint(s3));
+            }
             __syncthreads();
-            const uint4 q0 = *reinterpret_cast<const uint4 *>(xlev4[0]), q1 = *reinterpret_cast<const uint4 *>(xlev4[1]);
-            const uint4 q2 = *reinterpret_cast<const uint4 *>(xlev4[2]), q3 = *reinterpret_cast<const uint4 *>(xlev4[3]);
+            const uint4 q0 = *reinterpret_cast<const uint4 *>(&xlev4[0][0]), q1 = *reinterpret_cast<const uint4 *>(&xlev4[1][0]);
+            const uint4 q2 = *reinterpret_cast<const uint4 *>(&xlev4[2][0]), q3 = *reinterpret_cast<const uint4 *>(&xlev4[3][0]);
             X[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)umax(umax(q0.x, q1.x), umax(q2.x, q3.x)));
             X[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)umax(umax(q0.y, q1.y), umax(q2.y, q3.y)));
             X[2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)umax(umax(q0.z, q1.z), umax(q2.z, q3.z)));
             X[3] = (uint32_t)__builtin_amdgcn_readfirstlane((int)umax(umax(q0.w, q1.w), umax(q2.w, q3.w)));
+            const uint4 e0 = *reinterpret_cast<const uint4 *>(&xlev4[0][4]), e1 = *reinterpret_cast<const uint4 *>(&xlev4[1][4]);
+            const uint4 e2 = *reinterpret_cast<const uint4 *>(&xlev4[2][4]), e3 = *reinterpret_cast<const uint4 *>(&xlev4[3][4]);
+            auto fs = [](uint32_t a, uint32_t b, uint32_t c, uint32_t d) -> uint32_t {
+                return (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint((__uint_as_float(a) + __uint_as_float(b)) + (__uint_as_float(c) + __uint_as_float(d))));
+            };
+            G[0] = fs(e0.x, e1.x, e2.x, e3.x); G[1] = fs(e0.y, e1.y, e2.y, e3.y);
+            G[2] = fs(e0.z, e1.z, e2.z, e3.z); G[3] = fs(e0.w, e1.w, e2.w, e3.w);
         }
-        const int E0 = (X[0] != 0u && X[1] != 0u) ? block_exp(X[0], X[1]) : 0;
-        const int E1 = (X[2] != 0u && X[3] != 0u) ? block_exp(X[2], X[3]) : 0;
+        // (energies when both are normal numbers, peaks when a square under- or overflowed)
+        auto row_exp = [](uint32_t xa, uint32_t xb, uint32_t ga, uint32_t gb) -> int {
+            if (xa == 0u || xb == 0u) return 0;
+            const bool gok = ga != 0u && gb != 0u && ga < 0x7F800000u && gb < 0x7F800000u;
+            return gok ? block_exp_energy(ga, gb) : block_exp(xa, xb);
+        };
+        const int E0 = row_exp(X[0], X[1], G[0], G[1]);
+        const int E1 = row_exp(X[2], X[3], G[2], G[3]);
         const float sc0 = exp2i(E0), sc1 = exp2i(E1);
         // prefetch the 2*HS new slots of the next pair (consumed after the epilogue)
         float2 nx[2 * HS];
@@ -810,17 +859,17 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
             for (int g = 0; g < NH; g++) { am |= Pm[g]; ad |= Pd[g]; }
             zrow_m = am == 0u; zrow_d = ad == 0u;
             if (!(zrow_m || zrow_d)) {                       // (an empty row has no level: it reads the floor, E stays)
-                // an onset or a decay inside the window: exact levels, the largest windowed magnitude of either row
+                // an onset or a decay inside the window: exact, the windowed ENERGY of either row (see block_exp_energy)
                 float xm = 0.0f, xd = 0.0f;
 #pragma unroll
-                for (int j = 0; j < 16; j++) { xm = fmaxf(xm, fabsf(z[j].x)); xd = fmaxf(xd, fabsf(z[j].y)); }
-                const uint32_t wm = wave_umax_lane63(__float_as_uint(xm)), wd = wave_umax_lane63(__float_as_uint(xd));
-                if (lane63) *reinterpret_cast<uint2 *>(xlev[wvid]) = make_uint2(wm, wd);
+                for (int j = 0; j < 16; j++) { xm = fmaf(z[j].x, z[j].x, xm); xd = fmaf(z[j].y, z[j].y, xd); }
+                const float wm = wave_fsum_lane63(xm), wd = wave_fsum_lane63(xd);
+                if (lane63) *reinterpret_cast<uint2 *>(xlev[wvid]) = make_uint2(__float_as_uint(wm), __float_as_uint(wd));
                 __syncthreads();
                 uint32_t Xm, Xd;
-                read_levels2(xlev, Xm, Xd);
-                if (Xm != 0u && Xd != 0u) {
-                    int T = E + block_exp(Xm, Xd);           // (the side halves carry 2^E already)
+                read_energies2(xlev, Xm, Xd);
+                if (Xm != 0u && Xd != 0u && Xm < 0x7F800000u && Xd < 0x7F800000u) {      // (a square that under- or overflowed: E stays)
+                    int T = E + block_exp_energy(Xm, Xd);    // (the side halves carry 2^E already)
                     T = T < -60 ? -60 : (T > 60 ? 60 : T);
                     const float sc = rescale(T);
 #pragma unroll
@@ -1014,16 +1063,16 @@ __global__ __launch_bounds__(256, SS_FFT_PAIRW_WAVES) void k_fft4096_pairw(FftBa
         if (ma != 0u && mb != 0u && ea <= ma + 0x800000u && eb <= mb + 0x800000u) {
             T = block_exp(ma, mb);
         } else {
-            float xa = 0.0f, xb = 0.0f;                     // exact: largest windowed magnitude of either window
+            float xa = 0.0f, xb = 0.0f;                     // exact: the windowed energy of either window (see block_exp_energy)
 #pragma unroll
-            for (int j = 0; j < 16; j++) { xa = fmaxf(xa, fabsf(raw[j] * hw[j])); xb = fmaxf(xb, fabsf(raw[j + 4] * hw[j])); }
-            const uint32_t wa = wave_umax_lane63(__float_as_uint(xa)), wb = wave_umax_lane63(__float_as_uint(xb));
-            if (lane63) *reinterpret_cast<uint2 *>(xlev[wvid]) = make_uint2(wa, wb);
+            for (int j = 0; j < 16; j++) { const float pa = raw[j] * hw[j], pb = raw[j + 4] * hw[j]; xa = fmaf(pa, pa, xa); xb = fmaf(pb, pb, xb); }
+            const float wa = wave_fsum_lane63(xa), wb = wave_fsum_lane63(xb);
+            if (lane63) *reinterpret_cast<uint2 *>(xlev[wvid]) = make_uint2(__float_as_uint(wa), __float_as_uint(wb));
             __syncthreads();
             uint32_t Xa, Xb;
-            read_levels2(xlev, Xa, Xb);
-            if (Xa == 0u || Xb == 0u) return;
-            T = block_exp(Xa, Xb);
+            read_energies2(xlev, Xa, Xb);
+            if (Xa == 0u || Xb == 0u || Xa >= 0x7F800000u || Xb >= 0x7F800000u) return;      // (a square that under- or overflowed: E stays)
+            T = block_exp_energy(Xa, Xb);
         }
         const int dE = T - E;
         if (dE >= 2 || dE <= -2) {
@@ -1141,6 +1190,7 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms_anyhop(FftBatc
     __shared__ __attribute__((aligned(16))) v2f xbuf[16 * kX1Stride];
     __shared__ __attribute__((aligned(16))) v2f tw2s[256];
     __shared__ __attribute__((aligned(16))) uint32_t xlev[4][2];      // exact block exponent: [wave][mid, side] largest windowed magnitude
+    __shared__ __attribute__((aligned(16))) uint32_t glev[4][2];      //                        ... and windowed energy
     const int t = threadIdx.x;
     const uint32_t groups = (p.n_windows + p.windows_per_block - 1) / p.windows_per_block;
     const uint32_t stream = blockIdx.x / groups;
@@ -1160,24 +1210,32 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms_anyhop(FftBatc
     __syncthreads();
     for (uint32_t w = w_begin; w < w_end; ++w) {
         v2f z[16];
-        float xm = 0.0f, xd = 0.0f;
+        float xm = 0.0f, xd = 0.0f, gm = 0.0f, gd = 0.0f;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const float2 v = src[(size_t)(w - w_begin) * p.hop + t + 256 * j];
             const float hwj = p.half_window[t + 256 * j];
             z[j] = v2f{(v.x + v.y) * hwj, (v.x - v.y) * hwj};
             xm = fmaxf(xm, fabsf(z[j].x)); xd = fmaxf(xd, fabsf(z[j].y));
+            gm = fmaf(z[j].x, z[j].x, gm); gd = fmaf(z[j].y, z[j].y, gd);
         }
         // exact block exponent of the side row ("Two rows, one transform"); the previous window's reads of xlev lie behind
         // the barriers of its transform
-        uint32_t Xm, Xd;
+        uint32_t Xm, Xd, Gm, Gd;
         {
             const uint32_t wm = wave_umax_lane63(__float_as_uint(xm)), wd = wave_umax_lane63(__float_as_uint(xd));
-            if ((t & 63) == 63) *reinterpret_cast<uint2 *>(xlev[wvid]) = make_uint2(wm, wd);
+            const float sm_ = wave_fsum_lane63(gm), sd_ = wave_fsum_lane63(gd);
+            if ((t & 63) == 63) {
+                *reinterpret_cast<uint2 *>(xlev[wvid]) = make_uint2(wm, wd);
+                *reinterpret_cast<uint2 *>(glev[wvid]) = make_uint2(__float_as_uint(sm_), __float_as_uint(sd_));
+            }
             __syncthreads();
             read_levels2(xlev, Xm, Xd);
+            read_energies2(glev, Gm, Gd);
         }
-        const int E = (Xm != 0u && Xd != 0u) ? block_exp(Xm, Xd) : 0;
+        // energies (see block_exp_energy) when both are normal numbers, peaks when a square under- or overflowed
+        const bool gok = Gm != 0u && Gd != 0u && Gm < 0x7F800000u && Gd < 0x7F800000u;
+        const int E = (Xm != 0u && Xd != 0u) ? (gok ? block_exp_energy(Gm, Gd) : block_exp(Xm, Xd)) : 0;
         {
             const float sc = exp2i(E);
 #pragma unroll

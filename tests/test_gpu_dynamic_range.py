@@ -293,3 +293,49 @@ def test_digital_silence_in_front_of_a_programme_pair_kernel(oracle, channels):
                 assert db_close(got[w, c], ref), (channels, w, c, db_report(got[w, c], ref))
     assert n_floor >= 16 * channels
     b.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_level_programmes_every_row_at_its_own_bar(oracle, seed):
+    """Randomised: mid and side programmes whose levels jump independently between 0 and -140 dB (and to exact digital silence)
+    at random sample positions, random hops of the packed N = 4096 kernels — every row of every window against the oracle at the
+    plain bar.  Exercises the ordinary hop-level path, the exact path at the jumps, the rescale in both directions, empty rows
+    next to loud ones and the sign change of the block exponent in one run."""
+    rng = np.random.default_rng(1000 + seed)
+    rate, n = 48000, 4096
+    hop = int(rng.choice([1024, 1024, 1024, 512, 2048, 768]))
+    frames = n + hop * int(rng.integers(20, 40)) + int(rng.integers(0, hop))
+
+    def programme(f0):
+        y = _programme(rng, frames, rate, f0, amp=0.35, noise=0.04)
+        pos = 0
+        while pos < frames:
+            seg = int(rng.integers(300, 6000))
+            r = rng.uniform()
+            g = 0.0 if r < 0.12 else 10.0 ** (-rng.uniform(0, 140) / 20.0)
+            y[pos:pos + seg] *= g
+            pos += seg
+        return y
+
+    m, sd = programme(float(rng.uniform(100, 4000))), programme(float(rng.uniform(100, 8000)))
+    _check_every_row(oracle, _stereo_from_mid_side(m, sd), rate, 2, n, hop, f"random {seed} hop {hop}")
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_level_programmes_pair_kernel(oracle, seed):
+    """The same for k_fft4096_pairw (mono and 3 channels): consecutive windows of one channel at random levels."""
+    rng = np.random.default_rng(2000 + seed)
+    rate, n = 48000, 4096
+    channels = 1 if seed % 2 == 0 else 3
+    frames = n + 1024 * int(rng.integers(24, 40)) + int(rng.integers(0, 1024))
+    x = np.empty((frames, channels), np.float32)
+    for c in range(channels):
+        y = _programme(rng, frames, rate, float(rng.uniform(100, 6000)), amp=0.3, noise=0.03)
+        pos = 0
+        while pos < frames:
+            seg = int(rng.integers(200, 5000))
+            r = rng.uniform()
+            y[pos:pos + seg] *= 0.0 if r < 0.12 else 10.0 ** (-rng.uniform(0, 140) / 20.0)
+            pos += seg
+        x[:, c] = y.astype(np.float32)
+    _check_every_row(oracle, x.reshape(-1), rate, channels, n, 1024, f"random pair {seed}")
