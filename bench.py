@@ -535,13 +535,6 @@ def main():
         else:
             out["cpu_baseline"] = None
         if world == 1 and not args.no_extra:
-            # The reference's own workload first, while the timed batch is still alive: the first session a process opens right
-            # after releasing gigabytes of device memory ticks 45 us slower than any other (133 against 88 us; the HIP runtime's
-            # doing, tools/probe_tick_after_free.py) — a TUI process never frees a 10 GB corpus in front of a tick.
-            try:
-                tick_entry = reference_tick_workload(ssa, L)
-            except Exception as ex:
-                tick_entry = {"workload": "reference tick", "error": repr(ex)}
             b.close()
             extra = []
             try:
@@ -565,7 +558,7 @@ def main():
                     e = time_config(ssa, L, 48000, 2, 1, 48000 * secs, 4096, 1024, 0, steps=5)
                     e["workload"] = f"config 2: 1 stream x {secs} s, 48 kHz stereo, N=4096 hop 1024, full path"
                     extra.append(e)
-                extra.append(tick_entry)
+                extra.append(reference_tick_workload(ssa, L))
                 # config 5: 96 kHz 8-channel, N = 16384 per channel; forced 4x (benchmark) and the crate rule's 2x
                 for tp, name in ((4, "forced 4x true peak"), (0, "rule 2x true peak")):
                     e = time_config(ssa, L, 96000, 8, 64, 960000, 16384, 1024, tp, steps=3)

@@ -31,8 +31,8 @@ SS_HIDDEN int handle_make_meter(ss_analyzer *h, uint32_t channels, uint32_t rate
     HIPCHK(ring.alloc(ring_frames * channels));
     HIPCHK(counts.alloc(2));
     HIPCHK(out2.alloc(2));
-    HIPCHK(ring_scratch.alloc(128));
-    HIPCHK(hipMemset(ring_scratch.p, 0, 128 * sizeof(double)));      // (k_ring_energy's completion counter starts at zero)
+    HIPCHK(ring_scratch.alloc(ssk::kRingScratchDoubles));
+    HIPCHK(hipMemset(ring_scratch.p, 0, ssk::kRingScratchDoubles * sizeof(double)));      // (k_ring_energy's completion counter starts at zero)
     std::vector<double> w(channels);
     sst::channel_weights(channels, w.data());
     HIPCHK(weights.upload(w));
@@ -297,8 +297,11 @@ int ss_mid_side(const float *interleaved, size_t n, float *mid, float *side, siz
 // add_frames_f32 on the handle's meter.  on_device: `samples` already lives in HBM (tick drivers):
 // no staging copy and no synchronisation — everything is only enqueued on the handle's stream.
 }  // extern "C"
-int ssh::add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool on_device)
+int ssh::add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool on_device, ssk::FinalizeParams *deferred,
+                          const ssk::FftBatchParams *tick_fft, bool *tick_fused)
 {
+    if (deferred) deferred->n_streams = 0;
+    if (tick_fused) *tick_fused = false;
     SS_ON_DEVICE(h);
     if (!h) return SS_ERR_INVALID_ARG;
     if (!h->meter_ok) return SS_ERR_INVALID_MODE;
@@ -326,7 +329,8 @@ int ssh::add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool o
         p.subblocks = h->sub.p; p.sub_stride = 0; p.sub_cap = ss_analyzer::kSubCap;
         p.ring = h->ring.p; p.ring_frames = h->ring_frames; p.tp_factor = h->tp_factor;
         p.s100 = (uint32_t)S; p.nseg = 1; p.seg_sub = 0; p.warm_sub = 0;
-        HIPCHK(ssk::launch_time_domain(p, h->stream));
+        const bool with_fft = tick_fft && tick_fused && on_device && take == frames;
+        HIPCHK(ssk::launch_time_domain(p, h->stream, with_fft ? tick_fft : nullptr, with_fft ? tick_fused : nullptr));
         const uint64_t sb0 = h->frames_fed / S, sb1 = (h->frames_fed + take) / S;
         if (sb1 > sb0) {
             ssk::FinalizeParams f{};
@@ -335,7 +339,10 @@ int ssh::add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool o
             f.hist = h->hist.p; f.corpus_hist = nullptr; f.n_streams = 1; f.channels = C;
             f.sub_begin = sb0; f.sub_end = sb1;
             f.out_integrated = nullptr; f.out_lra = nullptr; f.out_counts = h->counts.p;
-            HIPCHK(ssk::launch_finalize(f, h->stream));
+            // a caller that has something shorter to put in front (a tick's short-term reading) launches the gating of a
+            // single-piece call itself, on the same stream
+            if (deferred && on_device && take == frames) *deferred = f;
+            else HIPCHK(ssk::launch_finalize(f, h->stream));
         }
         // the staging buffer is reused by the next piece
         if (!on_device) HIPCHK(hipStreamSynchronize(h->stream));
@@ -360,11 +367,11 @@ void ss_reset(ss_analyzer *h)
 
 // energy of the last `frames` frames of the filtered ring -> out2[1] = loudness (enqueue only)
 }  // extern "C"
-int ssh::ring_loudness_enqueue(ss_analyzer *h, uint64_t frames)
+int ssh::ring_loudness_enqueue(ss_analyzer *h, uint64_t frames, double *out2_dev)
 {
     SS_ON_DEVICE(h);
     HIPCHK(ssk::launch_ring_energy(h->ring.p, h->ring_frames, h->channels, h->frames_fed, frames,
-                                   h->weights.p, h->out2.p, h->ring_scratch.p, h->stream));
+                                   h->weights.p, out2_dev ? out2_dev : h->out2.p, h->ring_scratch.p, h->stream));
     return SS_OK;
 }
 extern "C" {

@@ -187,8 +187,13 @@ namespace ssh {
 // ss_analyzer.cpp: pieces of the handle the batch one-shot and the tick drivers reuse
 SS_HIDDEN int handle_reset(ss_analyzer *h);
 // add_frames_f32 on the handle's meter; on_device: `samples` already lives in HBM (nothing is copied or waited for)
-SS_HIDDEN int add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool on_device);
-SS_HIDDEN int ring_loudness_enqueue(ss_analyzer *h, uint64_t frames);
+// `deferred`: a single-piece device-resident call hands the gating launch (k_finalize_stream) of its new sub-blocks back to the
+// caller instead of enqueueing it (n_streams != 0: launch it with ssk::launch_finalize on h->stream before anything else reads the
+// histograms) — the tick drivers put the short-term reading in front of it
+// `tick_fft` / `tick_fused`: see ssk::launch_time_domain — a tick's spectrum rides the launch of a single-piece call
+SS_HIDDEN int add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool on_device, ssk::FinalizeParams *deferred = nullptr,
+                               const ssk::FftBatchParams *tick_fft = nullptr, bool *tick_fused = nullptr);
+SS_HIDDEN int ring_loudness_enqueue(ss_analyzer *h, uint64_t frames, double *out2_dev = nullptr);   // out2_dev: where (energy, loudness) go — default the handle's device pair; the tick drivers pass mapped pinned memory
 SS_HIDDEN void waveform_shape(size_t n, double waveform_window, size_t *window_out, size_t *bins_out);
 // ss_batch.cpp: Analyzer::calculate_integrated_lufs on a host or device-resident buffer (a one-stream batch pass)
 SS_HIDDEN int integrated_oneshot(uint32_t rate, uint32_t channels, const float *samples, size_t n, bool on_device, double *out);

@@ -139,7 +139,10 @@ struct TdParams {
     const uint64_t *frames_of;    // ragged batches: frames of each stream (nullable = n_frames for all)
     uint32_t tp_f32;              // 1: the factor-4 true peak as the f32 MFMA product everywhere (no f16 split)
 };
-hipError_t launch_time_domain(const TdParams &p, hipStream_t s);
+// tick_fft (streaming calls on the ring only): the one-window mid/side spectrum of a tick (N = 16384, out rows [mid, side]) to
+// run in the SAME launch, beside the loudness call (k_tick); *tick_fused tells whether that happened — if not, only the
+// time-domain kernel was launched and the spectrum is the caller's to launch
+hipError_t launch_time_domain(const TdParams &p, hipStream_t s, const FftBatchParams *tick_fft = nullptr, bool *tick_fused = nullptr);
 // frames per sequential chunk for a channel count (the constant block's m_pow must match)
 uint32_t td_chunk_frames(uint32_t channels, uint32_t s100);
 uint32_t td_resident_waves_per_cu(uint32_t channels, uint32_t s100, uint32_t halo_frames);
@@ -164,9 +167,11 @@ hipError_t launch_finalize(const FinalizeParams &p, hipStream_t s);
 hipError_t launch_hist_eval(const uint64_t *hist2000, const double *energies, const double *bounds,
                             double *out2, hipStream_t s);
 // mean-square of the filtered ring over the last `frames` frames (handle getters)
+constexpr int kRingScratchDoubles = 320;     // 256 partial sums + the completion counter
 hipError_t launch_ring_energy(const double *ring, uint64_t ring_frames, uint32_t channels,
                               uint64_t end_frame, uint64_t frames, const double *weights,
-                              double *out2 /* energy, loudness */, double *scratch /* >= 97 doubles, the 97th zero before the first launch */,
+                              double *out2 /* energy, loudness: device or mapped host memory */,
+                              double *scratch /* kRingScratchDoubles, zero before the first launch */,
                               hipStream_t s);
 
 // ---- waveform ---------------------------------------------------------------

@@ -280,59 +280,80 @@ hipError_t launch_hist_eval(const uint64_t *hist2000, const double *energies, co
 // (calc_gating_block on the ring "as is": loudness_shortterm / loudness_momentary).
 // Two stages with a fixed reduction shape (bit-reproducible): kRingBlocks partial sums, then one block — in ONE launch: the
 // workgroup that finishes last (a counter behind the partial sums, wrapped back to zero by atomicInc for the next launch)
-// reduces the 96 partial sums.  (Through round 3 the second stage was a launch of its own: one more of a tick's launches.)
-constexpr int kRingBlocks = 96;
-__global__ __launch_bounds__(256) void k_ring_energy(const double *ring, uint64_t ring_frames, uint32_t C,
-                                                     uint64_t end_frame, uint64_t frames,
+// reduces the partial sums.  (Through round 3 the second stage was a launch of its own: one more of a tick's launches.)
+// The window is ONE run of ring elements with at most one wrap (frames <= ring_frames), so an element's position is an add and
+// a compare in 32 bits and its channel advances by a constant step: no division in the loop (the first version divided two
+// 64-bit numbers per element — most of its 9.8 us inside a tick).  256 workgroups: a thread takes four or five elements of the
+// three-second window at 48 kHz stereo, all requested before the first is used.
+constexpr int kRingBlocks = 256;
+__global__ __launch_bounds__(256) void k_ring_energy(const double *ring, uint32_t ring_elems, uint32_t C, uint32_t begin_elem,
+                                                     uint32_t total, double frames,
                                                      const double *weights, double *partial, double *out)
 {
     __shared__ double red[256];
     __shared__ uint32_t is_last;
+    constexpr uint32_t kStride = (uint32_t)kRingBlocks * 256u;
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t cstep = kStride % C;
+    uint32_t c = tid % C;
     double acc = 0.0;
-    const uint64_t total = frames * C;
-    // ring position of absolute frame f is f % ring_frames; frames before 0 are the zeroed ring
-    const uint64_t begin = end_frame + ring_frames * 4 - frames;    // keep the subtraction non-negative
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)kRingBlocks * 256) {
-        const uint64_t f = i / C; const uint32_t c = (uint32_t)(i - f * C);
-        const double w = weights[c];
-        const double y = ring[((begin + f) % ring_frames) * C + c];
-        acc = fma(w * y, y, acc);
+    uint32_t i = tid;
+    for (; i + 3u * kStride < total; i += 4u * kStride) {
+        double y[4], w[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t e = begin_elem + i + (uint32_t)q * kStride;
+            if (e >= ring_elems) e -= ring_elems;
+            y[q] = ring[e];
+            w[q] = weights[c];
+            c += cstep; if (c >= C) c -= C;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc = fma(w[q] * y[q], y[q], acc);
     }
-    red[threadIdx.x] = acc;
+    for (; i < total; i += kStride) {
+        uint32_t e = begin_elem + i;
+        if (e >= ring_elems) e -= ring_elems;
+        const double y = ring[e];
+        acc = fma(weights[c] * y, y, acc);
+        c += cstep; if (c >= C) c -= C;
+    }
+    // workgroup sum: shuffle tree inside each wave, then the four wave sums in a fixed order
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_down(acc, d, 64);
+    if ((threadIdx.x & 63u) == 0u) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    for (int s = 128; s >= 1; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
-        partial[blockIdx.x] = red[0];
+        partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
         __threadfence();                                                   // the partial sum is visible before the count
         is_last = atomicInc(reinterpret_cast<unsigned int *>(partial + kRingBlocks), (unsigned int)kRingBlocks - 1u) == (unsigned int)kRingBlocks - 1u;
     }
     __syncthreads();
     if (!is_last) return;
     __threadfence();
-    red[threadIdx.x] = threadIdx.x < kRingBlocks ? __builtin_nontemporal_load(partial + threadIdx.x) : 0.0;
+    red[threadIdx.x] = __builtin_nontemporal_load(partial + threadIdx.x);
     __syncthreads();
-    // (a 128-wide tree over the 96 partial sums: the shape the second launch had)
-    for (int s = 64; s >= 1; s >>= 1) {
+    for (int s = 128; s >= 1; s >>= 1) {
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        const double e = red[0] / (double)frames;
+        const double e = red[0] / frames;
         out[0] = e;
         out[1] = e <= 0.0 ? -INFINITY : 10.0 * log10(e) - 0.691;   // energy_to_loudness
     }
 }
 
-// scratch: kRingBlocks partial sums + the completion counter (zero before the first launch, see ss_analyzer.cpp)
+// scratch: kRingBlocks partial sums + the completion counter (zero before the first launch, see ss_analyzer.cpp).
+// `out` may be device memory or pinned host memory mapped into the device (the tick drivers: no copy behind the kernel).
 hipError_t launch_ring_energy(const double *ring, uint64_t ring_frames, uint32_t channels,
                               uint64_t end_frame, uint64_t frames, const double *weights,
                               double *out, double *scratch, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_ring_energy, dim3(kRingBlocks), dim3(256), 0, s, ring, ring_frames, channels,
-                       end_frame % ring_frames, frames, weights, scratch, out);
+    if (frames == 0 || frames > ring_frames || ring_frames * channels >= (1ull << 31)) return hipErrorInvalidValue;
+    // ring position of absolute frame f is f % ring_frames; frames before 0 are the zeroed ring
+    const uint64_t begin = (end_frame % ring_frames + ring_frames - frames) % ring_frames;
+    hipLaunchKernelGGL(k_ring_energy, dim3(kRingBlocks), dim3(256), 0, s, ring, (uint32_t)(ring_frames * channels), channels,
+                       (uint32_t)(begin * channels), (uint32_t)(frames * channels), (double)frames, weights, scratch, out);
     return hipGetLastError();
 }
 

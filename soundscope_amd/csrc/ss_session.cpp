@@ -17,9 +17,11 @@ struct ss_session {
     DevBuf<float> ms;                   // capture: mid | side (n/2 each)
     DevBuf<float> spec;                 // [2][bin_stride] dB rows of a tick
     DevBuf<float> wave;                 // capture: [bins][2]
-    hipStream_t fft_stream = nullptr;   // the spectrum of a tick runs beside the loudness chain
+    hipEvent_t ev_tick = nullptr;       // behind a file tick's last result (the gating of the new sub-blocks runs after it)
     float *stage = nullptr;             // pinned: 2 * bin_stride floats | wave floats
     double *stage_d = nullptr;          // pinned: short-term loudness (2 doubles)
+    float *stage_dev = nullptr;         // the same two, as the device sees them: the file tick's kernels write their results
+    double *stage_d_dev = nullptr;      // straight into the pinned memory (no copy launch behind them)
     size_t stage_floats = 0;
     FftTables *ft = nullptr;
     BinTables *bt = nullptr;
@@ -74,8 +76,9 @@ int session_common_init(ss_session *s, uint32_t meter_channels, uint32_t rate)
     s->bin_stride = (uint32_t)((s->bt->count + 3) & ~(size_t)3);
     if (s->bin_stride == 0) s->bin_stride = 4;
     HIPCHK(s->spec.alloc((size_t)2 * s->bin_stride));
-    HIPCHK(hipStreamCreateWithFlags(&s->fft_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_tick, hipEventDisableTiming));
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->stage_d), 2 * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->stage_d_dev), s->stage_d, 0));
     return SS_OK;
 }
 
@@ -83,17 +86,19 @@ int session_stage(ss_session *s, size_t floats)
 {
     if (floats <= s->stage_floats) return SS_OK;
     if (s->stage) (void)hipHostFree(s->stage);
-    s->stage = nullptr; s->stage_floats = 0;
+    s->stage = nullptr; s->stage_dev = nullptr; s->stage_floats = 0;
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->stage), floats * sizeof(float), hipHostMallocDefault));
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->stage_dev), s->stage, 0));
     s->stage_floats = floats;
     return SS_OK;
 }
 
-// enqueue the mid/side spectrum of pairs [lb, lb + 16384) of an interleaved pair buffer
-int session_enqueue_fft(ss_session *s, const float *pairs, size_t lb, hipStream_t stream)
+// the mid/side spectrum of pairs [lb, lb + 16384) of an interleaved pair buffer; the two dB rows go to `out`
+// (the session's device rows, or the pinned stage as the device sees it)
+ssk::FftBatchParams session_fft_params(const ss_session *s, const float *pairs, size_t lb, float *out)
 {
     ssk::FftBatchParams p{};
-    p.pcm = pairs; p.out = s->spec.p;
+    p.pcm = pairs; p.out = out;
     p.window = s->ft->window.p; p.half_window = s->ft->half_window.p;
     p.tw_n = s->ft->tw_n.p; p.tw_core = s->ft->core_tw4096; p.tw_256 = s->ft->core_tw256; p.pink = nullptr;
     p.frames_per_stream = 0; p.first_start = lb; p.n_streams = 1; p.channels = 2;
@@ -101,26 +106,53 @@ int session_enqueue_fft(ss_session *s, const float *pairs, size_t lb, hipStream_
     p.first_bin = (uint32_t)s->bt->first; p.n_bins = (uint32_t)s->bt->count; p.bin_stride = s->bin_stride;
     p.windows_per_block = 1;
     p.db_offset = (float)(20.0 * std::log10(4.0 / (double)SS_TICK_WINDOW));
-    HIPCHK(ssk::launch_fft16k(p, 1, stream));
+    return p;
+}
+int session_enqueue_fft(ss_session *s, const float *pairs, size_t lb, hipStream_t stream, float *out)
+{
+    HIPCHK(ssk::launch_fft16k(session_fft_params(s, pairs, lb, out), 1, stream));
     return SS_OK;
 }
 
+// before the synchronisation: the x halves of a chart whose row is on its way (they are the session's constants)
+void session_emit_x(const ss_session *s, int status_in, double *xy)
+{
+    if (status_in) return;
+    const size_t nb = s->bt->count;
+    const double *cx = s->bt->chart_x.data();
+    for (size_t i = 0; i < nb; i++) xy[2 * i] = cx[i];
+}
+
 // after the synchronisation: dB rows in the pinned stage -> (chart_x, dB + pink) pairs, or the (0,0) fallback
+// (x_done: session_emit_x has written the x halves already)
 void session_emit_spectrum(const ss_session *s, const float *row, int status_in, double *xy,
-                           int32_t *status_out, uint32_t *n_out)
+                           int32_t *status_out, uint32_t *n_out, bool x_done = false)
 {
     int st = status_in;
     const size_t nb = s->bt->count;
-    if (!st)
-        for (size_t i = 0; i < nb; i++)
-            if (std::isnan(row[i]) || std::isinf(row[i])) { st = SS_ERR_SCALING; break; }
+    if (!st) {
+        // NaN or infinite anywhere in the row?  (an all-ones exponent; one pass without branches)
+        uint32_t bad = 0;
+        for (size_t i = 0; i < nb; i++) {
+            uint32_t u;
+            std::memcpy(&u, row + i, sizeof u);
+            bad |= (uint32_t)((u & 0x7F800000u) == 0x7F800000u);
+        }
+        if (bad) st = SS_ERR_SCALING;
+    }
     if (st) {
         xy[0] = 0.0; xy[1] = 0.0;                    // vec![(0., 0.)] (tui.rs:1437-1452, :1505-1524)
         *n_out = 1;
     } else {
-        for (size_t i = 0; i < nb; i++) {
-            xy[2 * i] = s->bt->chart_x[i];
-            xy[2 * i + 1] = (double)row[i] + s->bt->pink[i];
+        const double *pk = s->bt->pink.data();
+        if (x_done) {
+            for (size_t i = 0; i < nb; i++) xy[2 * i + 1] = (double)row[i] + pk[i];
+        } else {
+            const double *cx = s->bt->chart_x.data();
+            for (size_t i = 0; i < nb; i++) {
+                xy[2 * i] = cx[i];
+                xy[2 * i + 1] = (double)row[i] + pk[i];
+            }
         }
         *n_out = (uint32_t)nb;
     }
@@ -135,8 +167,8 @@ void ss_session_close(ss_session *s)
 {
     SS_ON_DEVICE(s);
     if (!s) return;
-    if (s->fft_stream) { (void)hipStreamSynchronize(s->fft_stream); (void)hipStreamDestroy(s->fft_stream); }
     if (s->an) ss_analyzer_destroy(s->an);
+    if (s->ev_tick) (void)hipEventDestroy(s->ev_tick);
     if (s->stage) (void)hipHostFree(s->stage);
     if (s->stage_d) (void)hipHostFree(s->stage_d);
     delete s;
@@ -296,8 +328,10 @@ int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side
     bool fft_launched = false, st_launched = false;
     int mid_st = SS_OK, side_st = SS_OK;
 
-    // ---- spectrum: the last 16384 mid / side samples before the playhead
+    // ---- what the tick will run (host-side checks only)
+    // spectrum: the last 16384 mid / side samples before the playhead
     const size_t fft_lb = pos_f > SS_TICK_WINDOW ? pos_f - SS_TICK_WINDOW : 0;     // saturating_sub
+    bool fft_wanted = false;
     if (fft_lb != 0) {
         res->fft_ran = 1;
         const size_t ms_len = s->n_samples / 2;
@@ -308,55 +342,72 @@ int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side
             const int lim = (20000.0f > (float)h->rate / 2.0f) ? SS_ERR_FREQ_LIMIT : SS_OK;
             if (!mid_st) mid_st = lim;
             if (!side_st) side_st = lim;
-            if ((!mid_st || !side_st) && s->bt->count) {
-                // the file is resident and read-only: the spectrum runs on its own stream beside the loudness chain
-                int rc = session_enqueue_fft(s, s->pcm.p, fft_lb, s->fft_stream);
-                if (rc) return rc;
-                HIPCHK(hipMemcpyAsync(s->stage, s->spec.p, (size_t)2 * s->bin_stride * sizeof(float),
-                                      hipMemcpyDeviceToHost, s->fft_stream));
-                fft_launched = true;
-            }
+            fft_wanted = (!mid_st || !side_st) && s->bt->count;
         } else {
             mid_st = side_st = SS_ERR_TOO_FEW_SAMPLES;          // get_fft(&[])
         }
     }
 
     SS_TICK_T(0);
-    // ---- loudness: the last 16384 interleaved samples, every tick (8x overlap at hop 1024 frames)
+    // ---- one stream, one wait.  The spectrum's two workgroups ride the loudness call's launch (k_tick), the short-term reading
+    // waits for it, an event behind that is what the tick waits for, and the gating of the new sub-blocks (histograms, block
+    // counts: nothing a tick reads) runs after the event — long done when the next tick arrives.  (Two streams did the same
+    // until round 4 — when their hardware queues happened to sit on one pipe of the command processor the spectrum did not
+    // start before the time-domain kernel had finished: 98 instead of 65 us for the whole life of such a session,
+    // tools/probe_tick_queues.sh.)  Results land in pinned memory straight from the kernels.
+    bool any_launch = false;
+    const ssk::FftBatchParams fft_p = fft_wanted ? session_fft_params(s, s->pcm.p, fft_lb, s->stage_dev) : ssk::FftBatchParams{};
+    // loudness: the last 16384 interleaved samples, every tick (8x overlap at hop 1024 frames)
     const size_t pos_i = pos_f * s->file_channels;
     const size_t lufs_lb = pos_i > SS_TICK_WINDOW ? pos_i - SS_TICK_WINDOW : 0;
+    ssk::FinalizeParams gating{};
     if (lufs_lb != 0) {
         res->lufs_ran = 1;
         std::memmove(&s->lufs[0], &s->lufs[1], (SS_LUFS_HISTORY - 1) * sizeof(double));
         if (pos_i <= s->n_samples && lufs_lb < s->n_samples) {
             res->fed = 1;
-            res->add_status = add_samples_impl(h, s->pcm.p + lufs_lb, SS_TICK_WINDOW, true);
-            SS_TICK_T(1);
+            bool fused = false;
+            res->add_status = add_samples_impl(h, s->pcm.p + lufs_lb, SS_TICK_WINDOW, true, &gating, fft_wanted ? &fft_p : nullptr, &fused);
             if (res->add_status == SS_ERR_DEVICE) return SS_ERR_DEVICE;
-            if (!h->meter_ok) {
-                res->shortterm_status = SS_ERR_INVALID_MODE;
-            } else {
-                int rc = ring_loudness_enqueue(h, (uint64_t)h->td->host.s100 * 30);
-                if (rc) return rc;
-                HIPCHK(hipMemcpyAsync(s->stage_d, h->out2.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-                st_launched = true;
-            }
+            if (res->add_status == SS_OK) any_launch = true;
+            if (fused) fft_launched = true;
         }
     }
+    SS_TICK_T(1);
+    if (fft_wanted && !fft_launched) {                  // (no loudness call this tick, or one that could not take the spectrum along)
+        HIPCHK(ssk::launch_fft16k(fft_p, 1, h->stream));
+        fft_launched = true; any_launch = true;
+    }
     SS_TICK_T(2);
-    if (st_launched || res->fed) HIPCHK(hipStreamSynchronize(h->stream));
+    if (res->fed) {
+        if (!h->meter_ok) {
+            res->shortterm_status = SS_ERR_INVALID_MODE;
+        } else {
+            // (energy, loudness) written by the kernel into the pinned pair itself
+            int rc = ring_loudness_enqueue(h, (uint64_t)h->td->host.s100 * 30, s->stage_d_dev);
+            if (rc) return rc;
+            st_launched = true; any_launch = true;
+        }
+    }
+    if (any_launch) HIPCHK(hipEventRecord(s->ev_tick, h->stream));
+    if (gating.n_streams) HIPCHK(ssk::launch_finalize(gating, h->stream));
     SS_TICK_T(3);
-    if (fft_launched) HIPCHK(hipStreamSynchronize(s->fft_stream));
+    // while the device works: the x halves of the two charts (they do not depend on it)
+    if (res->fft_ran) {
+        session_emit_x(s, fft_launched ? mid_st : (mid_st ? mid_st : SS_OK), mid_xy);
+        session_emit_x(s, side_st, side_xy);
+    }
     SS_TICK_T(4);
-
+    if (any_launch) HIPCHK(hipEventSynchronize(s->ev_tick));
+    SS_TICK_T(5);
     if (res->fft_ran) {
         session_emit_spectrum(s, s->stage, fft_launched ? mid_st : (mid_st ? mid_st : SS_OK), mid_xy,
-                              &res->mid_status, &res->n_mid);
-        session_emit_spectrum(s, s->stage + s->bin_stride, side_st, side_xy, &res->side_status, &res->n_side);
+                              &res->mid_status, &res->n_mid, true);
+        session_emit_spectrum(s, s->stage + s->bin_stride, side_st, side_xy, &res->side_status, &res->n_side, true);
     }
+    SS_TICK_T(6);
     if (res->fed) s->lufs[SS_LUFS_HISTORY - 1] = st_launched ? s->stage_d[1] : 0.0;
     res->shortterm = s->lufs[SS_LUFS_HISTORY - 1];
-    SS_TICK_T(5);
     return SS_OK;
 }
 
@@ -392,7 +443,7 @@ int ss_session_tick_capture(ss_session *s, const float *latest, size_t n, double
     if (!side_st) side_st = lim;
     bool fft_launched = false;
     if ((!mid_st || !side_st) && s->bt->count) {
-        int rc = session_enqueue_fft(s, s->pcm.p, lb, h->stream);
+        int rc = session_enqueue_fft(s, s->pcm.p, lb, h->stream, s->spec.p);
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(s->stage, s->spec.p, (size_t)2 * s->bin_stride * sizeof(float),
                               hipMemcpyDeviceToHost, h->stream));
@@ -416,9 +467,8 @@ int ss_session_tick_capture(ss_session *s, const float *latest, size_t n, double
     if (!h->meter_ok) {
         res->shortterm_status = SS_ERR_INVALID_MODE;
     } else {
-        int rc = ring_loudness_enqueue(h, (uint64_t)h->td->host.s100 * 30);
+        int rc = ring_loudness_enqueue(h, (uint64_t)h->td->host.s100 * 30, s->stage_d_dev);
         if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(s->stage_d, h->out2.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         st_launched = true;
     }
     HIPCHK(hipStreamSynchronize(h->stream));

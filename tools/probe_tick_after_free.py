@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""The session tick before and after a large batch has been created and destroyed in the same process: the FIRST session
-opened after gigabytes of device memory were released ticks ~45 us slower (133 against 88 us on MI355X / ROCm 7.2); the next one
-is back to normal, with or without a hipDeviceSynchronize in between.  bench.py therefore times the tick before it closes its batch."""
+"""The session tick before and after a large batch has been created and destroyed in the same process.  Through most of
+round 4 "the first session after a big batch" ticked 133 instead of 88 us: not the release of memory — the session's two
+streams had been dealt hardware queues on one pipe of the command processor (tools/probe_tick_queues.sh), which the stream
+churn of a batch made likely.  Since the tick is one launch on one stream (k_tick) the three numbers agree."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, soundscope_amd as ssa
