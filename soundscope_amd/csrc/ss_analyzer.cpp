@@ -61,6 +61,36 @@ int handle_reset(ss_analyzer *h)
     return SS_OK;
 }
 
+int pin_ready(ss_analyzer *h)
+{
+    if (h->pin_d) return SS_OK;
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->pin_in[i]), ss_analyzer::kPinFloats * sizeof(float), hipHostMallocDefault));
+        HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->pin_in_dev[i]), h->pin_in[i], 0));
+        HIPCHK(hipEventCreateWithFlags(&h->pin_ev[i], hipEventDisableTiming));
+    }
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->pin_out), (ss_analyzer::kPinFloats / 2 + 4) * sizeof(float), hipHostMallocDefault));
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->pin_out_dev), h->pin_out, 0));
+    double *d = nullptr;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&d), 2 * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->pin_d_dev), d, 0));
+    h->pin_d = d;                               // (last: "ready" means all of them)
+    return SS_OK;
+}
+
+int pin_acquire(ss_analyzer *h, int *idx)
+{
+    int rc = pin_ready(h);
+    if (rc) return rc;
+    const int i = h->pin_next;
+    if (h->pin_busy[i]) { HIPCHK(hipEventSynchronize(h->pin_ev[i])); h->pin_busy[i] = false; }
+    h->pin_next = i ^ 1;
+    *idx = i;
+    return SS_OK;
+}
+
+void pin_all_free(ss_analyzer *h) { h->pin_busy[0] = h->pin_busy[1] = false; }
+
 }  // namespace ssh
 
 extern "C" {
@@ -76,7 +106,6 @@ int ss_analyzer_create(uint32_t channels, uint32_t rate, ss_analyzer **out)
     h->rate = rate;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(h->in.alloc(32768));
-    HIPCHK(h->fft_out.alloc(16385));
     int rc = handle_make_meter(h.get(), channels, rate);
     if (rc) return rc;
     rc = handle_reset(h.get());
@@ -90,6 +119,12 @@ void ss_analyzer_destroy(ss_analyzer *h)
     SS_ON_DEVICE(h);
     if (!h) return;
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    for (int i = 0; i < 2; i++) {
+        if (h->pin_in[i]) (void)hipHostFree(h->pin_in[i]);
+        if (h->pin_ev[i]) (void)hipEventDestroy(h->pin_ev[i]);
+    }
+    if (h->pin_out) (void)hipHostFree(h->pin_out);
+    if (h->pin_d) (void)hipHostFree(h->pin_d);
     delete h;
 }
 
@@ -166,9 +201,13 @@ int ss_get_fft(const ss_analyzer *hc, const float *samples, size_t n,
     if (bt->count > cap_pairs) return SS_ERR_CAPACITY;
     if (bt->count == 0) return SS_OK;
 
-    HIPCHK(hipMemcpyAsync(h->in.p, samples, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    // the window goes into page-locked memory the kernel reads in place; the dB row comes back the same way
+    int pin = 0;
+    rc = pin_acquire(h, &pin);
+    if (rc) return rc;
+    std::memcpy(h->pin_in[pin], samples, n * sizeof(float));
     ssk::FftBatchParams p{};
-    p.pcm = h->in.p; p.out = h->fft_out.p;
+    p.pcm = h->pin_in_dev[pin]; p.out = h->pin_out_dev;
     p.window = ft->window.p; p.half_window = ft->half_window.p;
     p.tw_n = ft->tw_n.p; p.tw_256 = ft->tw_256.p; p.pink = nullptr;
     p.frames_per_stream = n; p.first_start = 0; p.n_streams = 1; p.channels = 1;
@@ -190,10 +229,9 @@ int ss_get_fft(const ss_analyzer *hc, const float *samples, size_t n,
     } else {
         HIPCHK(ssk::launch_fft_generic(p, 0, h->stream));
     }
-    if (h->fft_host.size() < bt->count) h->fft_host.resize(bt->count);
-    float *db = h->fft_host.data();
-    HIPCHK(hipMemcpyAsync(db, h->fft_out.p, bt->count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    pin_all_free(h);
+    const float *db = h->pin_out;
     for (size_t i = 0; i < bt->count; i++)
         if (std::isnan(db[i]) || std::isinf(db[i])) {
             // ScalingError(original, scaled) of the first bin the scaling function spoiled.  scale_to_dbfs maps a finite
@@ -317,6 +355,16 @@ int ssh::add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool o
     // 30-block history a short-term block needs
     const uint64_t piece_frames = 32 * S;
     uint64_t frames = n / C, done = 0;
+    // a tick-sized host buffer: copied into page-locked memory the kernel reads in place, and the call returns behind its
+    // launches (the event tells the next user of that buffer when the kernel is through with it)
+    int pin = -1;
+    if (!on_device && n <= ss_analyzer::kPinFloats && frames <= piece_frames) {
+        rc = pin_acquire(h, &pin);
+        if (rc) return rc;
+        std::memcpy(h->pin_in[pin], samples, n * sizeof(float));
+        samples = h->pin_in_dev[pin];
+        on_device = true;
+    }
     while (done < frames) {
         const uint64_t take = frames - done < piece_frames ? frames - done : piece_frames;
         if (!on_device) {
@@ -348,6 +396,10 @@ int ssh::add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool o
         if (!on_device) HIPCHK(hipStreamSynchronize(h->stream));
         h->frames_fed += take;
         done += take;
+    }
+    if (pin >= 0) {
+        HIPCHK(hipEventRecord(h->pin_ev[pin], h->stream));
+        h->pin_busy[pin] = true;
     }
     return SS_OK;
 }
@@ -382,12 +434,13 @@ static int ring_loudness(ss_analyzer *h, uint64_t frames, double *out)
     if (!h || !out) return SS_ERR_INVALID_ARG;
     if (!h->meter_ok) return SS_ERR_INVALID_MODE;
     if (frames > h->ring_frames) return SS_ERR_INVALID_MODE;
-    int rc = ring_loudness_enqueue(h, frames);
+    int rc = pin_ready(h);
     if (rc) return rc;
-    double r[2];
-    HIPCHK(hipMemcpyAsync(r, h->out2.p, sizeof r, hipMemcpyDeviceToHost, h->stream));
+    rc = ring_loudness_enqueue(h, frames, h->pin_d_dev);        // (energy, loudness) straight into page-locked memory
+    if (rc) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
-    *out = r[1];
+    pin_all_free(h);
+    *out = h->pin_d[1];
     return SS_OK;
 }
 
@@ -413,9 +466,12 @@ static int hist_eval(ss_analyzer *h, double r[2])
     const double *he, *hb;
     int rc = get_hist_tables(&he, &hb);
     if (rc) return rc;
-    HIPCHK(ssk::launch_hist_eval(h->hist.p, he, hb, h->out2.p, h->stream));
-    HIPCHK(hipMemcpyAsync(r, h->out2.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    rc = pin_ready(h);
+    if (rc) return rc;
+    HIPCHK(ssk::launch_hist_eval(h->hist.p, he, hb, h->pin_d_dev, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    pin_all_free(h);
+    r[0] = h->pin_d[0]; r[1] = h->pin_d[1];
     return SS_OK;
 }
 

@@ -173,19 +173,34 @@ struct ss_analyzer {
     ssh::DevBuf<double> weights;
     ssh::DevBuf<uint32_t> counts;
     ssh::DevBuf<double> out2, ring_scratch;
-    ssh::DevBuf<float> in, fft_out;
-    // get_fft(&self): the handle is const at the boundary; the read-back buffer (grown, never shrunk: no allocation per call)
-    // and the payload of the last error (ss_get_fft_error_values) are the call's own scratch
-    mutable std::vector<float> fft_host;
+    ssh::DevBuf<float> in;
+    // get_fft(&self): the handle is const at the boundary; the payload of the last error (ss_get_fft_error_values) and the
+    // page-locked mailboxes below are the call's own scratch
     mutable float fft_err_a = 0.0f, fft_err_b = 0.0f;
     uint64_t ring_frames = 0;
     uint64_t frames_fed = 0;
     static constexpr uint32_t kSubCap = 96;
+    // Small calls — a tick through the Analyzer API: get_fft x 2, add_samples, get_shortterm_lufs on 16384 samples — move no
+    // data with copy commands (a pageable 64 KB hipMemcpyAsync and a read-back cost more than the kernel between them): the
+    // samples are copied by the host into page-locked memory that the kernel reads in place, and results are written by the
+    // kernels into page-locked memory.  Two input buffers, so that add_samples returns behind its launch (an event says when
+    // a buffer's kernel has read it); every call that waits for the stream frees both.
+    static constexpr size_t kPinFloats = 32768;
+    float *pin_in[2] = {nullptr, nullptr}, *pin_in_dev[2] = {nullptr, nullptr};
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    bool pin_busy[2] = {false, false};
+    int pin_next = 0;
+    float *pin_out = nullptr, *pin_out_dev = nullptr;       // kPinFloats / 2 + 1 dB values
+    double *pin_d = nullptr, *pin_d_dev = nullptr;          // a getter's pair of doubles
 };
 
 namespace ssh {
 // ss_analyzer.cpp: pieces of the handle the batch one-shot and the tick drivers reuse
 SS_HIDDEN int handle_reset(ss_analyzer *h);
+// the handle's page-locked mailboxes (allocated at first use); pin_acquire: an input buffer no kernel is still reading
+SS_HIDDEN int pin_ready(ss_analyzer *h);
+SS_HIDDEN int pin_acquire(ss_analyzer *h, int *idx);
+SS_HIDDEN void pin_all_free(ss_analyzer *h);           // behind a hipStreamSynchronize of h->stream
 // add_frames_f32 on the handle's meter; on_device: `samples` already lives in HBM (nothing is copied or waited for)
 // `deferred`: a single-piece device-resident call hands the gating launch (k_finalize_stream) of its new sub-blocks back to the
 // caller instead of enqueueing it (n_streams != 0: launch it with ssk::launch_finalize on h->stream before anything else reads the
