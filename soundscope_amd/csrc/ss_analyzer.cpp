@@ -336,10 +336,10 @@ int ss_mid_side(const float *interleaved, size_t n, float *mid, float *side, siz
 // no staging copy and no synchronisation — everything is only enqueued on the handle's stream.
 }  // extern "C"
 int ssh::add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool on_device, ssk::FinalizeParams *deferred,
-                          const ssk::FftBatchParams *tick_fft, bool *tick_fused)
+                          TickExtras *tick)
 {
     if (deferred) deferred->n_streams = 0;
-    if (tick_fused) *tick_fused = false;
+    if (tick) tick->fused = false;
     SS_ON_DEVICE(h);
     if (!h) return SS_ERR_INVALID_ARG;
     if (!h->meter_ok) return SS_ERR_INVALID_MODE;
@@ -377,8 +377,20 @@ int ssh::add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool o
         p.subblocks = h->sub.p; p.sub_stride = 0; p.sub_cap = ss_analyzer::kSubCap;
         p.ring = h->ring.p; p.ring_frames = h->ring_frames; p.tp_factor = h->tp_factor;
         p.s100 = (uint32_t)S; p.nseg = 1; p.seg_sub = 0; p.warm_sub = 0;
-        const bool with_fft = tick_fft && tick_fused && on_device && take == frames;
-        HIPCHK(ssk::launch_time_domain(p, h->stream, with_fft ? tick_fft : nullptr, with_fft ? tick_fused : nullptr));
+        const bool with_tick = tick && tick->fft && on_device && take == frames;
+        const uint64_t st_frames = S * 30;                              // the short-term window (3 s)
+        if (with_tick && tick->shortterm_out && take <= st_frames && st_frames <= h->ring_frames &&
+            h->ring_frames * C < (1ull << 31)) {
+            // the window ends with this call: frames [fed + take - st_frames, fed + take); the part in front of the call is the
+            // ring workgroups' (frames before 0 are the zeroed ring)
+            const uint64_t end_new = h->frames_fed + take;
+            const uint64_t begin = (end_new % h->ring_frames + h->ring_frames - st_frames) % h->ring_frames;
+            p.st_out = tick->shortterm_out; p.st_scratch = h->ring_scratch.p + ssk::kRingTickScratch; p.st_weights = h->weights.p;
+            p.st_frames = (double)st_frames;
+            p.st_begin_elem = (uint32_t)(begin * C); p.st_old_total = (uint32_t)((st_frames - take) * C);
+            p.st_blocks = ssk::kRingTickBlocks;
+        }
+        HIPCHK(ssk::launch_time_domain(p, h->stream, with_tick ? tick->fft : nullptr, with_tick ? &tick->fused : nullptr));
         const uint64_t sb0 = h->frames_fed / S, sb1 = (h->frames_fed + take) / S;
         if (sb1 > sb0) {
             ssk::FinalizeParams f{};

@@ -1139,7 +1139,8 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms_anyhop(FftBatc
 // ============================================================================
 __global__ __launch_bounds__(512, 2) void k_fft16k(FftBatchParams p, int midside, uint32_t fft_ch)
 {
-    fft16k_window(p, midside, fft_ch, blockIdx.x);          // (ss_fft_dev.h: the tick kernel of ss_time_domain.hip runs the same body)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kFft16kLdsBytes];
+    fft16k_window(p, midside, fft_ch, blockIdx.x, lds);     // (ss_fft_dev.h: the tick kernel of ss_time_domain.hip runs the same body)
 }
 
 // ============================================================================

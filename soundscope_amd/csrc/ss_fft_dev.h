@@ -162,13 +162,16 @@ constexpr int kPlane = 16 * kRow;   // 288 complex per outer index; 16 planes = 
 //  Threads 0-255 run q = 0, threads 256-511 run q = 1; the mirror 8192-b has the parity of b, so each
 //  half only mirrors inside its own published spectrum.  midside 0: mono buffer or channel `ch` of an interleaved one,
 //  1: stereo -> mid/side (audio_player.rs:400-419).  `bid`: (stream, window, channel) index of this workgroup.
+//  `lds`: kFft16kLdsBytes of workgroup memory, 16-byte aligned (k_fft16k's own static array; the tick kernel's dynamic block, which
+//  its other workgroups use for the loudness call's tiles — a kernel's LDS is the largest need, not the sum).
 //  The epilogue asks for the twiddles (and pink values) of eight of a thread's bins before it uses the first: a tick runs
 //  TWO of these workgroups on an otherwise idle chip, and one exposed memory round trip per bin was most of its 17 us.
 // ============================================================================
-__device__ __forceinline__ void fft16k_window(const FftBatchParams &p, int midside, uint32_t fft_ch, uint32_t bid)
+constexpr int kFft16kLdsBytes = (2 * 16 * kPlane + 256) * 8;                // 75776
+__device__ __forceinline__ void fft16k_window(const FftBatchParams &p, int midside, uint32_t fft_ch, uint32_t bid, void *lds)
 {
-    __shared__ __attribute__((aligned(16))) v2f xbuf2[2][16 * kPlane];       // 2 x 36864 B
-    __shared__ __attribute__((aligned(16))) v2f tw2s[256];
+    v2f (*const xbuf2)[16 * kPlane] = reinterpret_cast<v2f (*)[16 * kPlane]>(lds);      // [2][16 * kPlane]: 2 x 36864 B
+    v2f *const tw2s = reinterpret_cast<v2f *>(lds) + 2 * 16 * kPlane;                    // [256]
 #define X1W(ka, tb_, ta_) ((ka) * kX1Stride + (tb_) + 16 * (ta_))
 #define X2W(kb, ka_, tb_) ((kb) * kPlane + (ka_) * kRow + (tb_))
     const int q = threadIdx.x >> 8;                 // which half-problem

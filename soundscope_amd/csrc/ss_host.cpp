@@ -171,6 +171,10 @@ int get_td_tables(uint32_t rate, int factor, uint32_t channels, TdTables **out)
     std::memset(&k, 0, sizeof k);
     sst::kweight_design((double)rate, k.b, k.a);
     for (int s = 0; s < 8; s++) sst::kweight_transition_pow(k.a, (uint64_t)ssk::td_chunk_frames(channels, (rate + 5) / 10) << s, k.m_pow[s]);
+    for (int s = 0; s < 8; s++) sst::kweight_transition_pow(k.a, (uint64_t)ssk::td_split_chunk_frames(channels, (rate + 5) / 10) << s, k.m_pow_split[s]);
+    for (int nstep = 0; nstep < 68; nstep++) sst::kweight_transition_pow(k.a, (uint64_t)nstep, k.m_step_split[nstep]);
+    for (int cidx = 0; cidx < 64; cidx++)
+        sst::kweight_transition_pow(k.a, (uint64_t)ssk::td_split_chunk_frames(channels, (rate + 5) / 10) * (uint64_t)(cidx + 1), k.m_chunk_split[cidx]);
     k.tp_factor = factor;
     k.tp_len = 0;
     if (factor) {

@@ -205,9 +205,16 @@ SS_HIDDEN void pin_all_free(ss_analyzer *h);           // behind a hipStreamSync
 // `deferred`: a single-piece device-resident call hands the gating launch (k_finalize_stream) of its new sub-blocks back to the
 // caller instead of enqueueing it (n_streams != 0: launch it with ssk::launch_finalize on h->stream before anything else reads the
 // histograms) — the tick drivers put the short-term reading in front of it
-// `tick_fft` / `tick_fused`: see ssk::launch_time_domain — a tick's spectrum rides the launch of a single-piece call
+// `tick`: what a tick wants to ride the launch of a single-piece device-resident call (ssk::launch_time_domain / k_tick): its
+// spectrum, and the short-term reading of the window that ends with the call; `fused` tells whether both did — if not, neither
+// was launched
+struct TickExtras {
+    const ssk::FftBatchParams *fft = nullptr;   // nullptr: no spectrum this tick (then nothing is fused)
+    double *shortterm_out = nullptr;            // (energy, loudness), device-visible; nullptr: no reading wanted
+    bool fused = false;
+};
 SS_HIDDEN int add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool on_device, ssk::FinalizeParams *deferred = nullptr,
-                               const ssk::FftBatchParams *tick_fft = nullptr, bool *tick_fused = nullptr);
+                               TickExtras *tick = nullptr);
 SS_HIDDEN int ring_loudness_enqueue(ss_analyzer *h, uint64_t frames, double *out2_dev = nullptr);   // out2_dev: where (energy, loudness) go — default the handle's device pair; the tick drivers pass mapped pinned memory
 SS_HIDDEN void waveform_shape(size_t n, double waveform_window, size_t *window_out, size_t *bins_out);
 // ss_batch.cpp: Analyzer::calculate_integrated_lufs on a host or device-resident buffer (a one-stream batch pass)

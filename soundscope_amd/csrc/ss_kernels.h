@@ -97,6 +97,10 @@ void fft16k_run_geometry(uint32_t n_streams, uint32_t fft_ch, uint32_t n_windows
 struct TdConst {                 // one per (rate, true-peak factor), device resident
     double b[5], a[5];
     double m_pow[8][16];         // (A^L)^(2^k), A = zero-input transition, L = td_chunk_frames(C)
+    double m_pow_split[8][16];   // the same for L = td_split_chunk_frames(C): streaming calls shared by a workgroup's waves (SPLIT)
+    double m_step_split[68][16]; // A^n, n = 0 .. 67 (same coordinates): the partial last chunk of a SPLIT tile (n < L <= 65)
+    double m_chunk_split[64][16];// (A^L)^(c + 1) for chunk c of a SPLIT tile: what the state in front of the tile adds to the state
+                                 // behind chunk c — applied when that state arrives, behind a scan that ran without it
     float tp[3][kTpHistMax];     // polyphase branches 1..factor-1, coefficient of x[n - t]
     int32_t tp_factor;           // 0, 2, 4
     int32_t tp_len;              // taps per branch (12 or 24)
@@ -138,13 +142,23 @@ struct TdParams {
     uint32_t halo_frames;        // frames kept in front of each tile: >= longest bin, multiple of 4
     const uint64_t *frames_of;    // ragged batches: frames of each stream (nullable = n_frames for all)
     uint32_t tp_f32;              // 1: the factor-4 true peak as the f32 MFMA product everywhere (no f16 split)
+    // a tick's short-term reading inside the same launch (k_tick only; st_out == nullptr: off).  The window of st_frames frames
+    // ends with this call; the st_old_total ring elements from st_begin_elem on are the part in front of the call.
+    double *st_out;               // (energy, loudness): device or mapped host memory
+    double *st_scratch;           // kRingTickBlocks partial sums + the count of finished workgroups (zero between launches)
+    const double *st_weights;     // [channels]
+    double st_frames;
+    uint32_t st_begin_elem, st_old_total, st_blocks;
 };
 // tick_fft (streaming calls on the ring only): the one-window mid/side spectrum of a tick (N = 16384, out rows [mid, side]) to
-// run in the SAME launch, beside the loudness call (k_tick); *tick_fused tells whether that happened — if not, only the
-// time-domain kernel was launched and the spectrum is the caller's to launch
+// run in the SAME launch, beside the loudness call (k_tick), together with the short-term reading if p.st_out is set;
+// *tick_fused tells whether that happened — if not, only the time-domain kernel was launched (p.st_out ignored) and the spectrum
+// and the reading are the caller's to launch
 hipError_t launch_time_domain(const TdParams &p, hipStream_t s, const FftBatchParams *tick_fft = nullptr, bool *tick_fused = nullptr);
 // frames per sequential chunk for a channel count (the constant block's m_pow must match)
 uint32_t td_chunk_frames(uint32_t channels, uint32_t s100);
+// the same for a streaming call whose tiles are shared by the waves of one workgroup (SPLIT): see ss_time_domain.hip
+uint32_t td_split_chunk_frames(uint32_t channels, uint32_t s100);
 uint32_t td_resident_waves_per_cu(uint32_t channels, uint32_t s100, uint32_t halo_frames);
 
 struct FinalizeParams {
@@ -167,7 +181,9 @@ hipError_t launch_finalize(const FinalizeParams &p, hipStream_t s);
 hipError_t launch_hist_eval(const uint64_t *hist2000, const double *energies, const double *bounds,
                             double *out2, hipStream_t s);
 // mean-square of the filtered ring over the last `frames` frames (handle getters)
-constexpr int kRingScratchDoubles = 320;     // 256 partial sums + the completion counter
+constexpr int kRingScratchDoubles = 320;     // k_ring_energy: 256 partial sums + the completion counter; k_tick: kRingTickBlocks + 1 from kRingTickScratch on
+constexpr int kRingTickScratch = 264;        // where a tick launch keeps ITS partial sums and count (the two kernels never share a slot)
+constexpr int kRingTickBlocks = 32;          // workgroups of a tick launch that sum the ring (at most 64: one lane of the last wave each)
 hipError_t launch_ring_energy(const double *ring, uint64_t ring_frames, uint32_t channels,
                               uint64_t end_frame, uint64_t frames, const double *weights,
                               double *out2 /* energy, loudness: device or mapped host memory */,

@@ -366,11 +366,13 @@ int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side
         std::memmove(&s->lufs[0], &s->lufs[1], (SS_LUFS_HISTORY - 1) * sizeof(double));
         if (pos_i <= s->n_samples && lufs_lb < s->n_samples) {
             res->fed = 1;
-            bool fused = false;
-            res->add_status = add_samples_impl(h, s->pcm.p + lufs_lb, SS_TICK_WINDOW, true, &gating, fft_wanted ? &fft_p : nullptr, &fused);
+            TickExtras extras;
+            extras.fft = fft_wanted ? &fft_p : nullptr;
+            extras.shortterm_out = s->stage_d_dev;
+            res->add_status = add_samples_impl(h, s->pcm.p + lufs_lb, SS_TICK_WINDOW, true, &gating, &extras);
             if (res->add_status == SS_ERR_DEVICE) return SS_ERR_DEVICE;
             if (res->add_status == SS_OK) any_launch = true;
-            if (fused) fft_launched = true;
+            if (extras.fused) { fft_launched = true; st_launched = true; }
         }
     }
     SS_TICK_T(1);
@@ -379,7 +381,7 @@ int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side
         fft_launched = true; any_launch = true;
     }
     SS_TICK_T(2);
-    if (res->fed) {
+    if (res->fed && !st_launched) {                     // (the reading did not ride the tick launch)
         if (!h->meter_ok) {
             res->shortterm_status = SS_ERR_INVALID_MODE;
         } else {

@@ -77,10 +77,22 @@ __device__ unsigned long long g_td_prof[16];
 #define SS_PROF_DECL uint64_t pt_ = __builtin_amdgcn_s_memtime(); uint64_t pacc_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define SS_PROF_MARK(i) do { const uint64_t n_ = __builtin_amdgcn_s_memtime(); pacc_[i] += n_ - pt_; pt_ = n_; SS_TD_PHASE_PRIORITY(i); } while (0)
 #define SS_PROF_END do { if (lane == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 9; i_++) atomicAdd(&g_td_prof[i_], (unsigned long long)pacc_[i_]); atomicAdd(&g_td_prof[15], 1ull); } } while (0)
+#elif defined(SS_TD_TRACE)
+// Development build (-DSS_TD_TRACE): the timeline of ONE streaming call shared by a workgroup's waves (SPLIT) — for every tile the
+// 100 MHz clock at its phase boundaries (slots 0-7: the marks of the tile loop; 8 tile taken up, 9 state of the tile in front
+// received, 10 energy shares received, 11 the wave's start, 12 the wave's end; read back with ss_debug_td_trace)
+__device__ unsigned long long g_td_trace[32][16];
+#define SS_TRACE(slot) do { if (SPLIT && lane == 0 && ti < 32u) g_td_trace[ti][slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define SS_PROF_DECL const unsigned long long tr_start_ = __builtin_amdgcn_s_memrealtime();
+#define SS_PROF_MARK(i) do { SS_TRACE(i); SS_TD_PHASE_PRIORITY(i); } while (0)
+#define SS_PROF_END do { if (SPLIT && lane == 0 && wave_in_block < 8u) { g_td_trace[wave_in_block][11] = tr_start_; g_td_trace[wave_in_block][12] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define SS_PROF_DECL
 #define SS_PROF_MARK(i) SS_TD_PHASE_PRIORITY(i)
 #define SS_PROF_END
+#endif
+#ifndef SS_TRACE
+#define SS_TRACE(slot)
 #endif
 
 template <int FACTOR>
@@ -213,7 +225,56 @@ struct TdShare {
                                          // leaves the tile's end state in its last chunk's lanes), behind the second pass otherwise
     double carry[kMaxChannels][4];       // DF-II state behind the last published tile
     double e_lane[64];                   // lane (chunk, channel)'s share of the current sub-block's energy
+    double call_e[kTdSplitWaves];        // a tick's short-term reading: the waves' weighted energy of the whole call
+    uint32_t waves_done;                 // waves whose share stands in call_e
 };
+
+// A tick's short-term reading, first part (k_tick's workgroups behind the loudness call's): the weighted energy of the ring over
+// the frames of the window that lie IN FRONT of this call — which the call does not touch, so these workgroups run beside it.
+// One run of ring elements with at most one wrap, like k_ring_energy (ss_loudness.hip); block r of `blocks` leaves its partial
+// sum in scratch[r] and counts itself in behind it.
+__device__ __forceinline__ void ring_window_partial(const TdParams &p, uint32_t r)
+{
+    __shared__ double red[kTdSplitWaves];
+    const uint32_t stride = p.st_blocks * 64u * kTdSplitWaves;
+    const uint32_t tid = r * 64u * kTdSplitWaves + threadIdx.x;
+    const uint32_t C = p.channels;
+    const uint32_t ring_elems = (uint32_t)(p.ring_frames * C);
+    const uint32_t cstep = stride % C;
+    uint32_t c = tid % C;
+    double acc = 0.0;
+    uint32_t i = tid;
+    for (; i + 3u * stride < p.st_old_total; i += 4u * stride) {
+        double y[4], w[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t e = p.st_begin_elem + i + (uint32_t)q * stride;
+            if (e >= ring_elems) e -= ring_elems;
+            y[q] = p.ring[e];
+            w[q] = p.st_weights[c];
+            c += cstep; if (c >= C) c -= C;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc = fma(w[q] * y[q], y[q], acc);
+    }
+    for (; i < p.st_old_total; i += stride) {
+        uint32_t e = p.st_begin_elem + i;
+        if (e >= ring_elems) e -= ring_elems;
+        const double y = p.ring[e];
+        acc = fma(p.st_weights[c] * y, y, acc);
+        c += cstep; if (c >= C) c -= C;
+    }
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_down(acc, d, 64);
+    if ((threadIdx.x & 63u) == 0u) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < kTdSplitWaves; w++) t += red[w];
+        p.st_scratch[r] = t;
+        __threadfence();                                                   // the partial sum is visible before the count
+        atomicAdd(reinterpret_cast<unsigned int *>(p.st_scratch + kRingTickBlocks), 1u);
+    }
+}
 
 template <int FACTOR, bool RING, int CT, int WAVE, int WPS, bool SPLIT = false>
 __global__ __launch_bounds__(64 * (SPLIT ? kTdSplitWaves : kTdWavesPerBlock), WPS) void k_time_domain(TdParams p, uint32_t L, uint32_t tile_len,
@@ -235,12 +296,29 @@ __global__ __launch_bounds__(64 * kTdSplitWaves, 3) void k_tick(TdParams p, uint
                                                                  uint32_t halo_frames, FftBatchParams fp, uint32_t fft_blocks)
 {
     if (blockIdx.x < fft_blocks) {
-        fft16k_window(fp, 1, fft_blocks, blockIdx.x);
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef SS_TD_TRACE
+        const unsigned long long f0_ = __builtin_amdgcn_s_memrealtime();
+#endif
+        fft16k_window(fp, 1, fft_blocks, blockIdx.x, smem);
+#ifdef SS_TD_TRACE
+        if (threadIdx.x == 0) { g_td_trace[30 + (blockIdx.x & 1u)][0] = f0_; g_td_trace[30 + (blockIdx.x & 1u)][1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+        return;
+    }
+    if (blockIdx.x > fft_blocks) {
+#ifdef SS_TD_TRACE
+        const unsigned long long r0_ = __builtin_amdgcn_s_memrealtime();
+#endif
+        ring_window_partial(p, blockIdx.x - fft_blocks - 1u);
+#ifdef SS_TD_TRACE
+        if (threadIdx.x == 0 && blockIdx.x == fft_blocks + 1u) { g_td_trace[29][0] = r0_; g_td_trace[29][1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
         return;
     }
     constexpr bool RING = true, SPLIT = true;
     constexpr int WAVE = 0, WPS = 3;
-    const uint32_t block_id = blockIdx.x - fft_blocks;
+    const uint32_t block_id = 0u;
 #include "ss_td_body.inc"
 }
 
@@ -308,6 +386,35 @@ uint32_t td_chunk_frames(uint32_t C, uint32_t s100)
     return best;
 }
 
+// Chunk length of a streaming call shared by the eight waves of a workgroup (SPLIT).  A different trade from the batch's: what
+// counts is the length of the chain, and a wave that has to take a second tile waits for its first one's true-peak product
+// before it can even stage it.
+uint32_t td_split_chunk_frames(uint32_t C, uint32_t s100)
+{
+#ifdef SS_TUNING        // development builds only: force the chunk length of SPLIT calls
+    if (const char *e = std::getenv("SS_TD_LSPLIT")) { const int v = std::atoi(e); if (v >= 8 && v <= 128) return (uint32_t)v; }
+#endif
+    // The smallest chunk length that cuts the sub-block into whole tiles of whole chunks, lets a tick-sized call (16384 / C
+    // frames, tui.rs:1539) fit ONE round of the eight waves whatever its alignment, and fits the LDS; otherwise the batch's.
+    // (48 kHz stereo: 40 -> tiles of 1200 frames, at most eight per tick, 16.4 us for the call where L = 30 — nine or ten tiles
+    // of 960, wave 0 taking a second one behind its first one's true-peak product — takes 22.7; partial chunks are poison: a
+    // tile that ends inside a chunk runs the unbatched loops, L = 35 / 38 / 45: 84-98 us, tools/sweep_tick_lsplit.sh.)
+    const uint32_t nch = 64u / C;
+    const uint32_t n_tick = 16384u / C;
+    for (uint32_t L : {25u, 30u, 33u, 35u, 40u, 45u, 49u, 50u, 55u, 60u, 65u}) {
+        const uint32_t cap = nch * L;
+        const uint32_t pieces = (s100 + cap - 1) / cap;
+        const uint32_t tile_len = (s100 + pieces - 1) / pieces;
+        if (tile_len > cap || tile_len * pieces != s100 || tile_len % L) continue;
+        if ((n_tick - 1u) / tile_len + 2u > (uint32_t)kTdSplitWaves) continue;
+        uint32_t wave_floats = ((uint32_t)kTdHaloFrames + tile_len) * C + td_slack_floats(C) + kMaxChannels;
+        wave_floats = (wave_floats + 3u) & ~3u;
+        if ((size_t)wave_floats * 4 * kTdSplitWaves + sizeof(TdShare) > 160 * 1024) continue;
+        return L;
+    }
+    return td_chunk_frames(C, s100);
+}
+
 // waves of k_time_domain one CU holds at once (LDS per wave grows with the channel count and the decimation halo)
 uint32_t td_resident_waves_per_cu(uint32_t C, uint32_t s100, uint32_t halo_frames)
 {
@@ -332,7 +439,7 @@ static hipError_t td_launch_w(const TdParams &p, hipStream_t s)
 {
     const uint32_t C = p.channels;
     const uint32_t S = p.s100;
-    const uint32_t L = td_chunk_frames(C, S);
+    const uint32_t L = SPLIT ? td_split_chunk_frames(C, S) : td_chunk_frames(C, S);
     const uint32_t nch = 64u / C;
     const uint32_t cap = nch * L;                                   // frames one wave can scan at once
     const uint32_t pieces = (S + cap - 1) / cap;                    // equal tiles per sub-block
@@ -367,7 +474,7 @@ static hipError_t td_launch_tick(const TdParams &p, const FftBatchParams &fp, hi
     *fused = false;
     const uint32_t C = p.channels;
     const uint32_t S = p.s100;
-    const uint32_t L = td_chunk_frames(C, S);
+    const uint32_t L = td_split_chunk_frames(C, S);
     const uint32_t cap = (64u / C) * L;
     const uint32_t pieces = (S + cap - 1) / cap;
     uint32_t tile_len = (S + pieces - 1) / pieces;
@@ -375,7 +482,8 @@ static hipError_t td_launch_tick(const TdParams &p, const FftBatchParams &fp, hi
     const uint32_t halo = (uint32_t)kTdHaloFrames;
     uint32_t wave_floats = (halo + tile_len) * C + td_slack_floats(C) + kMaxChannels;
     wave_floats = (wave_floats + 3u) & ~3u;
-    const size_t lds = (size_t)wave_floats * 4 * kTdSplitWaves + sizeof(TdShare);
+    size_t lds = (size_t)wave_floats * 4 * kTdSplitWaves + sizeof(TdShare);
+    if (lds < (size_t)kFft16kLdsBytes) lds = kFft16kLdsBytes;           // (the spectrum's workgroups use the same dynamic block)
     auto fn = k_tick<FACTOR, CT>;
     static DevicePrep prepared;
     static std::atomic<size_t> static_lds{0};
@@ -390,7 +498,8 @@ static hipError_t td_launch_tick(const TdParams &p, const FftBatchParams &fp, hi
     if (pe != hipSuccess) return pe;
     if (lds + static_lds.load(std::memory_order_relaxed) > 160 * 1024) return hipSuccess;     // not fused: the caller launches both
     const uint32_t fft_blocks = 2;                                      // mid, side
-    hipLaunchKernelGGL(fn, dim3(fft_blocks + 1), dim3(64 * kTdSplitWaves), lds, s, p, L, tile_len, wave_floats, halo, fp, fft_blocks);
+    hipLaunchKernelGGL(fn, dim3(fft_blocks + 1 + (p.st_out ? p.st_blocks : 0u)), dim3(64 * kTdSplitWaves), lds, s, p, L, tile_len, wave_floats,
+                       halo, fp, fft_blocks);
     *fused = true;
     return hipGetLastError();
 }
@@ -474,7 +583,9 @@ static hipError_t td_launch_c(const TdParams &p, hipStream_t s, const FftBatchPa
                                                      : td_launch_tick<FACTOR, 0>(p, *tick_fft, s, fused);
                 if (e != hipSuccess || *fused) return e;
             }
-            return p.channels == 2 ? td_launch_w<FACTOR, RING, 2, 0, 3, true>(p, s) : td_launch_w<FACTOR, RING, 0, 0, 3, true>(p, s);
+            TdParams q = p;
+            q.st_out = nullptr;                                          // (the reading needs k_tick's ring workgroups)
+            return p.channels == 2 ? td_launch_w<FACTOR, RING, 2, 0, 3, true>(q, s) : td_launch_w<FACTOR, RING, 0, 0, 3, true>(q, s);
         }
     }
     return p.channels == 2 ? td_launch<FACTOR, RING, 2, 0>(p, s) : td_launch<FACTOR, RING, 0, 0>(p, s);
@@ -497,6 +608,12 @@ hipError_t launch_time_domain(const TdParams &p, hipStream_t s, const FftBatchPa
 
 }  // namespace ssk
 
+#ifdef SS_TD_TRACE
+extern "C" int ss_debug_td_trace(unsigned long long *out512)
+{
+    return hipMemcpyFromSymbol(out512, HIP_SYMBOL(ssk::g_td_trace), 32 * 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef SS_TD_PROF
 // development builds only: [0..7] phase clocks (stage, decimate, pass 1, scan, pass 2, tp convert (+ f32 remainder), tp product,
 // tile tail), [15] waves counted; reset != 0 clears the totals after reading
