@@ -32,7 +32,7 @@ def check_tick(res, ref, sess, app):
     assert lufs_close(res.shortterm, ref["shortterm"])
 
 
-@pytest.mark.parametrize("rate,seconds", [(48000, 6.0), (44100, 4.3), (96000, 2.6), (32000, 3.1)])
+@pytest.mark.parametrize("rate,seconds", [(48000, 6.0), (44100, 4.3), (96000, 2.6), (32000, 3.1), (192000, 3.4), (88200, 1.1)])
 def test_file_session_matches_reference_driver(oracle, rate, seconds):
     from oracle.app_driver import FileApp
     frames = int(rate * seconds)
