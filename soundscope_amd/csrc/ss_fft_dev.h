@@ -283,6 +283,13 @@ __device__ __forceinline__ void fft16k_window(const FftBatchParams &p, int midsi
             o[idx] = r + pk[m];
         }
     }
+    if (p.done_flag) {
+        // every wave completes its own stores system-wide (a workgroup barrier alone does not wait for vector stores), then one
+        // lane tells the host: whoever sees the flag sees the row
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(p.done_flag + ch, p.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 #undef X1W
 #undef X2W
 }

@@ -65,6 +65,10 @@ struct FftBatchParams {
     const double *integrated;    // per stream: gain = -13 - (float)integrated (tui.rs:1234); nullptr: gain_db for all
     uint32_t cols;               // 1 .. 512
     float gain_db;
+    // one-window N = 16384 kernel (a tick): when set, the workgroup of channel ch stores done_value into done_flag[ch] behind its
+    // row — in host-visible memory, so that the host can take the row while the rest of the launch is still running
+    uint32_t *done_flag;
+    uint32_t done_value;
 };
 
 // N = 4096 kernels: bit kc set when bins [256 kc, 256 kc + 255] hold a retained bin or the mirror 4096 - k of one (the other

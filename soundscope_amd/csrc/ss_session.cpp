@@ -22,6 +22,8 @@ struct ss_session {
     double *stage_d = nullptr;          // pinned: short-term loudness (2 doubles)
     float *stage_dev = nullptr;         // the same two, as the device sees them: the file tick's kernels write their results
     double *stage_d_dev = nullptr;      // straight into the pinned memory (no copy launch behind them)
+    uint32_t *row_flag = nullptr, *row_flag_dev = nullptr;      // pinned: [mid, side] = the tick whose row stands in `stage`
+    uint32_t tick_seq = 0;              // file ticks so far (the value the spectrum's workgroups store into row_flag)
     size_t stage_floats = 0;
     FftTables *ft = nullptr;
     BinTables *bt = nullptr;
@@ -79,6 +81,9 @@ int session_common_init(ss_session *s, uint32_t meter_channels, uint32_t rate)
     HIPCHK(hipEventCreateWithFlags(&s->ev_tick, hipEventDisableTiming));
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->stage_d), 2 * sizeof(double), hipHostMallocDefault));
     HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->stage_d_dev), s->stage_d, 0));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->row_flag), 2 * sizeof(uint32_t), hipHostMallocDefault));
+    s->row_flag[0] = s->row_flag[1] = 0u;
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->row_flag_dev), s->row_flag, 0));
     return SS_OK;
 }
 
@@ -112,6 +117,20 @@ int session_enqueue_fft(ss_session *s, const float *pairs, size_t lb, hipStream_
 {
     HIPCHK(ssk::launch_fft16k(session_fft_params(s, pairs, lb, out), 1, stream));
     return SS_OK;
+}
+
+// wait (bounded: about 200 us) until a spectrum workgroup has stored `seq` behind its row
+bool wait_row_flag(const uint32_t *flag, uint32_t seq)
+{
+    for (int spin = 0; spin < 64; spin++) {
+        for (int k = 0; k < 256; k++) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return true;
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#endif
+        }
+    }
+    return false;
 }
 
 // before the synchronisation: the x halves of a chart whose row is on its way (they are the session's constants)
@@ -171,6 +190,7 @@ void ss_session_close(ss_session *s)
     if (s->ev_tick) (void)hipEventDestroy(s->ev_tick);
     if (s->stage) (void)hipHostFree(s->stage);
     if (s->stage_d) (void)hipHostFree(s->stage_d);
+    if (s->row_flag) (void)hipHostFree(s->row_flag);
     delete s;
 }
 
@@ -356,7 +376,9 @@ int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side
     // start before the time-domain kernel had finished: 98 instead of 65 us for the whole life of such a session,
     // tools/probe_tick_queues.sh.)  Results land in pinned memory straight from the kernels.
     bool any_launch = false;
-    const ssk::FftBatchParams fft_p = fft_wanted ? session_fft_params(s, s->pcm.p, fft_lb, s->stage_dev) : ssk::FftBatchParams{};
+    ssk::FftBatchParams fft_p = fft_wanted ? session_fft_params(s, s->pcm.p, fft_lb, s->stage_dev) : ssk::FftBatchParams{};
+    const uint32_t seq = ++s->tick_seq ? s->tick_seq : ++s->tick_seq;          // (never 0: the flags' initial value)
+    fft_p.done_flag = s->row_flag_dev; fft_p.done_value = seq;
     // loudness: the last 16384 interleaved samples, every tick (8x overlap at hop 1024 frames)
     const size_t pos_i = pos_f * s->file_channels;
     const size_t lufs_lb = pos_i > SS_TICK_WINDOW ? pos_i - SS_TICK_WINDOW : 0;
@@ -400,14 +422,31 @@ int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side
         session_emit_x(s, side_st, side_xy);
     }
     SS_TICK_T(4);
-    if (any_launch) HIPCHK(hipEventSynchronize(s->ev_tick));
-    SS_TICK_T(5);
-    if (res->fft_ran) {
-        session_emit_spectrum(s, s->stage, fft_launched ? mid_st : (mid_st ? mid_st : SS_OK), mid_xy,
-                              &res->mid_status, &res->n_mid, true);
-        session_emit_spectrum(s, s->stage + s->bin_stride, side_st, side_xy, &res->side_status, &res->n_side, true);
+    // The spectrum's two workgroups are done long before the loudness call's: each tells so through a flag in pinned memory
+    // behind its row, and the y halves of its chart are written while the rest of the launch is still running.  (A bounded
+    // wait: if the flags do not show up — memory that is not host-coherent would deliver them with the end of the kernel —
+    // the rows are taken behind the event as before.)
+    bool mid_done = false, side_done = false;
+    if (res->fft_ran && fft_launched) {
+        if (wait_row_flag(&s->row_flag[0], seq)) {
+            session_emit_spectrum(s, s->stage, mid_st, mid_xy, &res->mid_status, &res->n_mid, true);
+            mid_done = true;
+            if (wait_row_flag(&s->row_flag[1], seq)) {
+                session_emit_spectrum(s, s->stage + s->bin_stride, side_st, side_xy, &res->side_status, &res->n_side, true);
+                side_done = true;
+            }
+        }
     }
+    SS_TICK_T(5);
+    if (any_launch) HIPCHK(hipEventSynchronize(s->ev_tick));
     SS_TICK_T(6);
+    if (res->fft_ran) {
+        if (!mid_done)
+            session_emit_spectrum(s, s->stage, fft_launched ? mid_st : (mid_st ? mid_st : SS_OK), mid_xy,
+                                  &res->mid_status, &res->n_mid, true);
+        if (!side_done)
+            session_emit_spectrum(s, s->stage + s->bin_stride, side_st, side_xy, &res->side_status, &res->n_side, true);
+    }
     if (res->fed) s->lufs[SS_LUFS_HISTORY - 1] = st_launched ? s->stage_d[1] : 0.0;
     res->shortterm = s->lufs[SS_LUFS_HISTORY - 1];
     return SS_OK;

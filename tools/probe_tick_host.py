@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Where a session tick's wall time goes on the host side (needs a -DSS_TUNING build: ss_debug_tick_prof).
 [0] host-side checks, [1] tick launch (loudness call + spectrum), [2] separate spectrum launch (if any), [3] short-term enqueue + event + gating enqueue,
-[4] x halves of the two charts (the device working), [5] wait for the event, [6] y halves of the two charts"""
+[4] x halves of the two charts (the device working), [5] the rows' flags + y halves (the loudness call still running),
+[6] wait for the event"""
 import ctypes as C, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,7 +27,7 @@ wall = (time.perf_counter() - t0) / len(pos[20:]) * 1e6
 f(out, 1)
 n = len(pos[20:])
 names = ["host-side checks", "tick launch", "separate spectrum launch", "short-term enqueue + event + gating", "x halves (host)",
-         "wait: event", "y halves (host)"]
+         "row flags + y halves", "wait: event"]
 print(f"tick wall (python loop) {wall:.1f} us")
 for i, nm in enumerate(names):
     print(f"  {out[i] / n:7.1f} us  {nm}")
