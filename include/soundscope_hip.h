@@ -108,7 +108,10 @@ int ss_get_fft_error_values(const ss_analyzer *h, float *a, float *b);
  * out_xy receives (i,min),(i,max) pairs; cap_pairs >= 2*floor(window*1000). */
 int ss_get_waveform(const float *samples, size_t n, double waveform_window,
                     double *out_xy, size_t cap_pairs, size_t *out_n);
-/* add_samples(&mut self, samples)                            analyzer.rs:139-141 */
+/* add_samples(&mut self, samples)                            analyzer.rs:139-141
+ * `samples` is copied before the call returns (the caller may reuse it at once).  A call of tick size (n <= 32768) returns
+ * behind its launches, without waiting for the device: the status covers the arguments and the meter's state (the reference's
+ * own error cases); every getter waits for the samples fed before it, and a device fault surfaces there as SS_ERR_DEVICE. */
 int ss_add_samples(ss_analyzer *h, const float *samples, size_t n);
 /* reset(&mut self)                                           analyzer.rs:143-145 */
 void ss_reset(ss_analyzer *h);
