@@ -104,7 +104,7 @@ int ss_analyzer_create(uint32_t channels, uint32_t rate, ss_analyzer **out)
     std::unique_ptr<ss_analyzer, decltype(&ss_analyzer_destroy)> h(new ss_analyzer(), &ss_analyzer_destroy);
     h->device = current_device();
     h->rate = rate;
-    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(stream_acquire(&h->stream));
     HIPCHK(h->in.alloc(32768));
     int rc = handle_make_meter(h.get(), channels, rate);
     if (rc) return rc;
@@ -118,7 +118,7 @@ void ss_analyzer_destroy(ss_analyzer *h)
 {
     SS_ON_DEVICE(h);
     if (!h) return;
-    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); stream_release(h->stream); }
     for (int i = 0; i < 2; i++) {
         if (h->pin_in[i]) (void)hipHostFree(h->pin_in[i]);
         if (h->pin_ev[i]) (void)hipEventDestroy(h->pin_ev[i]);

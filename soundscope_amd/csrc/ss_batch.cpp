@@ -118,7 +118,7 @@ int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
         if (rc) return rc;
     }
     if (cfg->true_peak_factor != 0 && cfg->true_peak_factor != 2 && cfg->true_peak_factor != 4) return SS_ERR_INVALID_ARG;
-    HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    HIPCHK(stream_acquire(&b->stream));
     ss_batch_layout &L = b->lay;
     L.input_bytes = (uint64_t)cfg->n_streams * F * C * sizeof(float);
     HIPCHK(b->pcm.alloc((size_t)cfg->n_streams * F * C));
@@ -274,11 +274,11 @@ void ss_batch_destroy(ss_batch *b)
     SS_ON_DEVICE(b);
     if (!b) return;
     if (b->stream) { (void)hipStreamSynchronize(b->stream); }
-    if (b->stream2) { (void)hipStreamSynchronize(b->stream2); (void)hipStreamDestroy(b->stream2); }
+    if (b->stream2) { (void)hipStreamSynchronize(b->stream2); stream_release(b->stream2); }
     if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
     if (b->ev_join) (void)hipEventDestroy(b->ev_join);
     for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
-    if (b->stream) (void)hipStreamDestroy(b->stream);
+    if (b->stream) stream_release(b->stream);
     delete b;
 }
 
@@ -731,7 +731,7 @@ int ss_batch_set_overlap(ss_batch *b, int enable)
     SS_ON_DEVICE(b);
     if (!b) return SS_ERR_INVALID_ARG;
     if (enable && !b->stream2) {
-        HIPCHK(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
+        HIPCHK(stream_acquire(&b->stream2));
         HIPCHK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
     }

@@ -48,6 +48,27 @@ Ctx &ctx()
     return *slot;
 }
 
+hipError_t stream_acquire(hipStream_t *out)
+{
+    Ctx &c = ctx();
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        if (!c.idle_streams.empty()) { *out = c.idle_streams.back(); c.idle_streams.pop_back(); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+void stream_release(hipStream_t s)
+{
+    if (!s) return;
+    Ctx &c = ctx();
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        if (c.idle_streams.size() < 8) { c.idle_streams.push_back(s); return; }
+    }
+    (void)hipStreamDestroy(s);
+}
+
 Scratch &scratch()
 {
     thread_local std::map<int, std::unique_ptr<Scratch>> per_device;

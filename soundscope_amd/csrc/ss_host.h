@@ -97,10 +97,17 @@ struct Ctx {
     std::map<std::pair<uint32_t, size_t>, std::unique_ptr<BinTables>> bins;
     std::map<std::pair<uint32_t, uint32_t>, std::unique_ptr<TdTables>> td;   // (rate, factor | channels << 8)
     DevBuf<double> hist_energies, hist_bounds;
+    // idle streams of handles and batches that were destroyed (stream_acquire / stream_release)
+    std::vector<hipStream_t> idle_streams;
 };
 
 // the table cache of the calling thread's current device
 SS_HIDDEN Ctx &ctx();
+// Streams of handles, sessions and batches come from a per-device pool: hipStreamCreateWithFlags costs 1.7-18 ms and
+// hipStreamDestroy 1.5 ms on this stack (rocprofv3 --hip-trace over six session opens: 52 of their 70 ms, tools/probe_open_hipapi.sh)
+// — a file open made two of each.  stream_release takes an IDLE stream (the caller has synchronised it).
+SS_HIDDEN hipError_t stream_acquire(hipStream_t *out);
+SS_HIDDEN void stream_release(hipStream_t s);
 SS_HIDDEN int current_device();
 
 // Scratch of the handle-less entry points (ss_get_waveform, ss_mid_side, ss_pcm_decode): one set per calling
