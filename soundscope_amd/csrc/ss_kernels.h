@@ -214,6 +214,11 @@ hipError_t launch_render_spectrum(const float *rows, uint32_t bin_stride, uint32
 hipError_t launch_render_waveform(const float *wave, uint64_t wave_stride, uint32_t n_points, uint32_t n_streams,
                                   uint32_t x_min, uint32_t x_max, uint32_t cols, float *out, hipStream_t s);
 hipError_t launch_mid_side(const float *interleaved, size_t frames, float *mid, float *side, hipStream_t s);
+// pairs of an interleaved buffer whose mid or side value ((l + r) / 2, (l - r) / 2 in f32) is NaN or infinite — normally none:
+// the tick drivers' index for the crate's NaN / infinity rejection.  cls bits: 1 mid NaN, 2 mid inf, 4 side NaN, 8 side inf.
+// *count (zeroed by the launcher) counts ALL such pairs; the first `cap` to arrive are listed (in no particular order).
+struct NonFinitePair { unsigned long long index; uint32_t cls; uint32_t pad; };
+hipError_t launch_nonfinite_pairs(const float *interleaved, size_t pairs, uint32_t *count, NonFinitePair *list, uint32_t cap, hipStream_t s);
 // verification utility: out[item * out_stride] += order-independent checksum of words [item * stride_words, + words) (32-bit words)
 hipError_t launch_checksum(const void *base, uint64_t words, uint64_t stride_words, uint32_t n_items, uint64_t *out,
                            uint32_t out_stride, hipStream_t s);

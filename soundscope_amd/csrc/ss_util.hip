@@ -80,6 +80,32 @@ hipError_t launch_mid_side(const float *interleaved, size_t frames, float *mid, 
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void k_nonfinite_pairs(const float2 *in, size_t pairs, uint32_t *count, NonFinitePair *list, uint32_t cap)
+{
+    const size_t stride = (size_t)gridDim.x * 256u;
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < pairs; i += stride) {
+        const float2 v = in[i];
+        const float m = (v.x + v.y) * 0.5f, sd = (v.x - v.y) * 0.5f;
+        uint32_t c = 0;
+        if (m != m) c |= 1u; else if (fabsf(m) == INFINITY) c |= 2u;
+        if (sd != sd) c |= 4u; else if (fabsf(sd) == INFINITY) c |= 8u;
+        if (c) {
+            const uint32_t slot = atomicAdd(count, 1u);
+            if (slot < cap) list[slot] = NonFinitePair{(unsigned long long)i, c, 0u};
+        }
+    }
+}
+
+hipError_t launch_nonfinite_pairs(const float *interleaved, size_t pairs, uint32_t *count, NonFinitePair *list, uint32_t cap, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(uint32_t), s);
+    if (e != hipSuccess || !pairs) return e;
+    const size_t want = (pairs + 1023) / 1024;                      // four pairs per thread or more
+    hipLaunchKernelGGL(k_nonfinite_pairs, dim3((uint32_t)(want < 4096 ? want : 4096)), dim3(256), 0, s,
+                       reinterpret_cast<const float2 *>(interleaved), pairs, count, list, cap);
+    return hipGetLastError();
+}
+
 // ============================================================================
 //  Render-side reductions (tui.rs:49-51, :801-821, :664-681)
 //  Spectrum: y + gain, clamped to the chart's [-100, 0] dB, reduced to chart columns on the log-x axis
