@@ -201,6 +201,8 @@ struct WaveParams {
     float *out; uint64_t out_stride;       // [stream][W][2] f32 (min, max)
     const uint64_t *samples_of;   // ragged batches: interleaved samples / bins of each stream (nullable)
     const uint32_t *window_of;
+    uint32_t mid_of_pairs;        // 1: `pcm` holds n_samples stereo PAIRS and the signal decimated is their mid, (l + r) / 2
+                                  // (audio_player.rs:400-419 on the fly: the capture tick's chart, tui.rs:1453-1455)
 };
 hipError_t launch_waveform(const WaveParams &p, hipStream_t s);
 

@@ -36,10 +36,20 @@ __global__ __launch_bounds__(256) void k_waveform(WaveParams p)
     if (start >= p.n_samples) return;            // `break`: this and all later bins produce no point
     const float *x = p.pcm + (size_t)stream * p.stream_stride;
     float mn = __builtin_nanf(""), mx = __builtin_nanf("");
-    for (uint64_t j = start + lane16; j < end; j += 16) {
-        const float v = x[j];
-        mn = fminf(mn, v);
-        mx = fmaxf(mx, v);
+    if (p.mid_of_pairs) {
+        const float2 *xp = reinterpret_cast<const float2 *>(x);
+        for (uint64_t j = start + lane16; j < end; j += 16) {
+            const float2 f = xp[j];
+            const float v = (f.x + f.y) / 2.0f;
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+        }
+    } else {
+        for (uint64_t j = start + lane16; j < end; j += 16) {
+            const float v = x[j];
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+        }
     }
 #pragma unroll
     for (int ofs = 8; ofs >= 1; ofs >>= 1) {

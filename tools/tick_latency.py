@@ -55,3 +55,16 @@ for tick in range(60):
     if tick >= 10:
         t_cap.append(t1 - t0)
 print("capture tick (30 s ring upload + 15 s waveform):", f(t_cap))
+# the same with the snapshot in memory the caller has page-locked once (ss_host_register): the upload is a DMA, not a staged copy
+import ctypes as C
+from soundscope_amd import _lib as L
+if L.lib().ss_host_register(ring.ctypes.data_as(C.c_void_p), ring.nbytes) == L.SS_OK:
+    t_cap = []
+    for tick in range(60):
+        t0 = time.perf_counter()
+        cap.analyze_microphone_input(ring)
+        t1 = time.perf_counter()
+        if tick >= 10:
+            t_cap.append(t1 - t0)
+    print("capture tick, page-locked snapshot             :", f(t_cap))
+    L.lib().ss_host_unregister(ring.ctypes.data_as(C.c_void_p))
