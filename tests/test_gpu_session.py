@@ -138,3 +138,34 @@ def test_session_argument_errors():
     sess = ssa.CaptureSession(2, 48000)
     with pytest.raises(ssa.AnalyzerError):
         sess.analyze_microphone_input(np.zeros(1000, np.float32))      # not the 30*rate ring
+
+
+def test_tick_launch_soak_against_the_separate_calls():
+    """Three thousand ticks of the one-launch file tick (k_tick: spectrum + loudness call + short-term reading, rows flagged early)
+    against the same ticks through the Analyzer's own methods (separate kernels, separate reductions): the spectra are the same
+    arithmetic on the same samples, the short-term loudness the same sum in another order."""
+    rate = 48000
+    x = make_stereo(4242, rate * 64, rate=rate, level=0.5)
+    mid, side = ssa.get_mid_and_side_samples(x)
+    sess = ssa.FileSession(x, 2, rate)
+    an = ssa.Analyzer(); an.create_loudness_meter(2, rate)
+    worst_st = 0.0
+    n = 0
+    for pos in range(16384 * 2 + 2048, x.size + 1, 2048):
+        res = sess.analyze_audio_file_samples(pos)
+        pf = pos // 2
+        an.add_samples(x[pos - 16384:pos])
+        st = an.get_shortterm_lufs()
+        assert res.fft_ran and res.fed and res.mid_status == 0 and res.side_status == 0
+        if n % 7 == 0:                                           # (the spectra of every seventh tick: they cost the most here)
+            m = an.get_fft(mid[pf - 16384:pf]); sd = an.get_fft(side[pf - 16384:pf])
+            assert np.array_equal(sess.mid_fft, m), pos
+            assert np.array_equal(sess.side_fft, sd), pos
+        if np.isinf(st) or np.isinf(res.shortterm):
+            assert st == res.shortterm
+        else:
+            worst_st = max(worst_st, abs(st - res.shortterm))
+        n += 1
+    assert n > 2900
+    assert worst_st <= 1e-9, worst_st
+    sess.close()
