@@ -59,14 +59,15 @@ def programme(seed):
             if abs(gp - want) > 1e-4 * max(want, 1e-30): return f"seed {seed} ch {c}: true peak {gp} vs {want}"
     return worst
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-bad = 0
-tot = {"st": 0.0, "mom": 0.0, "state": 0.0}
-for seed in range(first, first + n):
-    r = programme(seed)
-    if isinstance(r, str):
-        print("FAIL", r, flush=True); bad += 1
-    else:
-        for k in tot: tot[k] = max(tot[k], r[k])
-print(f"{n} programmes, {bad} failed; worst differences: short-term {tot['st']:.1e} LU, momentary {tot['mom']:.1e} LU, state {tot['state']:.1e}")
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bad = 0
+    tot = {"st": 0.0, "mom": 0.0, "state": 0.0}
+    for seed in range(first, first + n):
+        r = programme(seed)
+        if isinstance(r, str):
+            print("FAIL", r, flush=True); bad += 1
+        else:
+            for k in tot: tot[k] = max(tot[k], r[k])
+    print(f"{n} programmes, {bad} failed; worst differences: short-term {tot['st']:.1e} LU, momentary {tot['mom']:.1e} LU, state {tot['state']:.1e}")
