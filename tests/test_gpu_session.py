@@ -110,7 +110,7 @@ def test_file_session_short_file(oracle):
     assert np.allclose(sess.lufs, app.lufs, atol=TOL_DB)
 
 
-@pytest.mark.parametrize("rate,channels", [(48000, 2), (44100, 2), (48000, 1)])
+@pytest.mark.parametrize("rate,channels", [(48000, 2), (44100, 2), (48000, 1), (96000, 2), (32000, 2), (88200, 1)])
 def test_capture_session_matches_reference_driver(oracle, rate, channels):
     from oracle.app_driver import CaptureApp
     sess = ssa.CaptureSession(channels, rate)
@@ -182,3 +182,30 @@ def test_randomised_tick_programme_against_the_restated_app(oracle, seed):
     spec.loader.exec_module(mod)
     r = mod.programme(seed)
     assert r is None, r
+
+
+def test_capture_session_non_finite_samples(oracle):
+    """A NaN pair in the chart's part of the ring, then an infinite pair inside the newest window: the chart keeps the crate's
+    min / max semantics, the spectra fall back like the reference's, the meter's reading goes NaN with it."""
+    from oracle.app_driver import CaptureApp
+    rate = 48000
+    sess = ssa.CaptureSession(2, rate)
+    app = CaptureApp(2, rate)
+    base = make_stereo(77, 15 * rate, rate=rate, level=0.4)
+    for case in range(3):
+        ring = base.copy()
+        if case >= 1: ring[2 * 100000] = np.nan                         # far from the newest window: only the chart sees it
+        if case >= 2: ring[ring.size - 2 * 5000 + 1] = np.inf           # inside the newest 16384 pairs
+        res = sess.analyze_microphone_input(ring)
+        ref = app.analyze_microphone_input(ring)
+        for key in ("mid_status", "side_status", "add_status", "shortterm_status"):
+            assert getattr(res, key) == ref[key], (case, key, getattr(res, key), ref[key])
+        assert np.array_equal(sess.microphone_input_chart, app.microphone_input_chart, equal_nan=True), case
+        for got, want in ((sess.mid_fft, app.mid_fft), (sess.side_fft, app.side_fft)):
+            assert got.shape == want.shape, case
+            if want.shape[0] > 1:
+                assert db_close(got[:, 1], want[:, 1], TOL_DB), case
+            else:
+                assert np.array_equal(got, want), case
+        a, b = res.shortterm, ref["shortterm"]
+        assert (np.isnan(a) and np.isnan(b)) or lufs_close(a, b), (case, a, b)
