@@ -941,7 +941,7 @@ def test_real_channel_window_pair_kernel(oracle, channels, frames):
 @pytest.mark.parametrize("seed", [3, 14, 27, 230, 442, 686, 744, 1133])
 def test_randomised_streaming_programme_against_oracle(oracle, seed):
     """tools/fuzz_streaming.py's programmes (random rate, channel count and call lengths, level jumps, silences), a few seeds of
-    the 1650 it has been run on — among them the five that sit closest to its bars."""
+    the 4650 it has been run on — among them the five that sit closest to its bars."""
     import importlib.util, os
     spec = importlib.util.spec_from_file_location(
         "fuzz_streaming", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_streaming.py"))

@@ -174,7 +174,7 @@ def test_tick_launch_soak_against_the_separate_calls():
 @pytest.mark.parametrize("seed", [0, 7, 19, 42, 228, 247, 273])
 def test_randomised_tick_programme_against_the_restated_app(oracle, seed):
     """tools/fuzz_ticks.py's programmes (random file with level jumps, silences, NaN / infinite pairs; playback, seeks, positions
-    past both ends, restarts), a few seeds of the 600 it has been run on."""
+    past both ends, restarts), a few seeds of the 3100 it has been run on."""
     import importlib.util, os
     spec = importlib.util.spec_from_file_location(
         "fuzz_ticks", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_ticks.py"))
