@@ -41,6 +41,7 @@ SS_HIDDEN int handle_make_meter(ss_analyzer *h, uint32_t channels, uint32_t rate
     h->state.swap(state); h->hist.swap(hist); h->sub.swap(sub); h->ring.swap(ring); h->counts.swap(counts);
     h->out2.swap(out2); h->ring_scratch.swap(ring_scratch); h->weights.swap(weights);
     h->meter_ok = true;
+    h->change_count++;
     return SS_OK;
 }
 
@@ -58,6 +59,7 @@ int handle_reset(ss_analyzer *h)
     HIPCHK(hipMemsetAsync(h->ring.p, 0, h->ring.n * sizeof(double), h->stream));
     HIPCHK(hipMemsetAsync(h->counts.p, 0, 2 * sizeof(uint32_t), h->stream));
     h->frames_fed = 0;
+    h->change_count++;
     return SS_OK;
 }
 
@@ -355,6 +357,7 @@ int ssh::add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool o
     // 30-block history a short-term block needs
     const uint64_t piece_frames = 32 * S;
     uint64_t frames = n / C, done = 0;
+    h->change_count++;                                  // (whatever happens below: cached readings are of the past)
     // a tick-sized host buffer: copied into page-locked memory the kernel reads in place, and the call returns behind its
     // launches (the event tells the next user of that buffer when the kernel is through with it)
     int pin = -1;
@@ -478,12 +481,14 @@ static int hist_eval(ss_analyzer *h, double r[2])
     const double *he, *hb;
     int rc = get_hist_tables(&he, &hb);
     if (rc) return rc;
+    if (h->eval_stamp == h->change_count) { r[0] = h->eval_cache[0]; r[1] = h->eval_cache[1]; return SS_OK; }
     rc = pin_ready(h);
     if (rc) return rc;
     HIPCHK(ssk::launch_hist_eval(h->hist.p, he, hb, h->pin_d_dev, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     pin_all_free(h);
-    r[0] = h->pin_d[0]; r[1] = h->pin_d[1];
+    r[0] = h->eval_cache[0] = h->pin_d[0]; r[1] = h->eval_cache[1] = h->pin_d[1];
+    h->eval_stamp = h->change_count;
     return SS_OK;
 }
 
@@ -515,10 +520,16 @@ static int read_peaks(ss_analyzer *h, uint32_t ch, double *sample_pk, double *tr
     if (!h) return SS_ERR_INVALID_ARG;
     if (!h->meter_ok) return SS_ERR_INVALID_MODE;
     if (ch >= h->channels) return SS_ERR_INVALID_CHANNEL;
-    float sp, tp;
-    HIPCHK(hipMemcpyAsync(&sp, &h->state.p->sample_peak[ch], sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(&tp, &h->state.p->true_peak[ch], sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->peaks_stamp != h->change_count) {
+        // every channel's sample and true peak in one copy (they stand side by side in the state)
+        static_assert(offsetof(ssk::TdState, true_peak) == offsetof(ssk::TdState, sample_peak) + sizeof(float) * ssk::kMaxChannels,
+                      "sample_peak and true_peak are read as one block");
+        HIPCHK(hipMemcpyAsync(h->peaks_cache, &h->state.p->sample_peak[0], sizeof h->peaks_cache, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        pin_all_free(h);
+        h->peaks_stamp = h->change_count;
+    }
+    const float sp = h->peaks_cache[ch], tp = h->peaks_cache[ssk::kMaxChannels + ch];
     if (sample_pk) *sample_pk = (double)sp;
     if (true_pk) *true_pk = (double)(tp > sp ? tp : sp);    // true_peak(): max(true, sample)
     return SS_OK;

@@ -187,6 +187,13 @@ struct ss_analyzer {
     uint64_t ring_frames = 0;
     uint64_t frames_fed = 0;
     static constexpr uint32_t kSubCap = 96;
+    // The reference's render loop asks for the integrated loudness, the loudness range and the true peak on EVERY frame (tui.rs:917,
+    // :950, :969; a frame every 8 ms, a tick every 21): a reading is taken from the device once per state of the meter —
+    // `change_count` moves with every feed, reset and re-configuration — and handed out from here until the state moves again.
+    uint64_t change_count = 1;
+    uint64_t eval_stamp = 0, peaks_stamp = 0;
+    double eval_cache[2] = {0.0, 0.0};                       // (integrated, range) at eval_stamp
+    float peaks_cache[2 * ssk::kMaxChannels] = {};          // sample peaks | true peaks at peaks_stamp
     // Small calls — a tick through the Analyzer API: get_fft x 2, add_samples, get_shortterm_lufs on 16384 samples — move no
     // data with copy commands (a pageable 64 KB hipMemcpyAsync and a read-back cost more than the kernel between them): the
     // samples are copied by the host into page-locked memory that the kernel reads in place, and results are written by the

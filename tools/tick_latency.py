@@ -68,3 +68,11 @@ if L.lib().ss_host_register(ring.ctypes.data_as(C.c_void_p), ring.nbytes) == L.S
             t_cap.append(t1 - t0)
     print("capture tick, page-locked snapshot             :", f(t_cap))
     L.lib().ss_host_unregister(ring.ctypes.data_as(C.c_void_p))
+# the getters of the reference's render loop (tui.rs:917, :950, :969: every frame): first reading of a meter state, then repeats
+t_first, t_rep = [], []
+for k in range(40):
+    an.add_samples(x[:16384])
+    t0 = time.perf_counter(); an.get_integrated_lufs(); an.get_true_peak(); an.get_loudness_range(); t1 = time.perf_counter()
+    an.get_integrated_lufs(); an.get_true_peak(); an.get_loudness_range(); t2 = time.perf_counter()
+    t_first.append(t1 - t0); t_rep.append(t2 - t1)
+print("render-loop getters (integrated + true peak + range): first reading of a state", f(t_first), "| again", f(t_rep))
