@@ -949,3 +949,38 @@ def test_randomised_streaming_programme_against_oracle(oracle, seed):
     spec.loader.exec_module(mod)
     r = mod.programme(seed)
     assert not isinstance(r, str), r
+
+
+def test_getter_readings_follow_the_meter_state(oracle):
+    """The handle serves repeated getter calls of one meter state from a cached reading (the reference's render loop asks on every
+    frame): every feed, reset and re-configuration must move it."""
+    from oracle import pyoracle as po
+    rate = 48000
+    x = make_stereo(31, rate * 4, rate=rate, level=0.5)
+    an = ssa.Analyzer(); an.create_loudness_meter(2, rate)
+    mm = po.Meter(2, rate)
+
+    def same():
+        for _ in range(2):                                   # twice: the second call is the cached one
+            gi, oi = an.get_integrated_lufs(), mm.integrated()
+            assert (np.isinf(gi) and gi == oi) or abs(gi - oi) <= 1e-6, (gi, oi)
+            gr, orr = an.get_loudness_range(), mm.loudness_range()
+            assert abs(gr - orr) <= 1e-6, (gr, orr)
+            tl, tr = an.get_true_peak()
+            for got, c in ((tl, 0), (tr, 1)):
+                want = max(mm.true_peak(c), mm.sample_peak(c))
+                assert abs(got - want) <= 1e-4 * max(want, 1e-30), (got, want)
+
+    same()                                                   # nothing fed yet
+    for k in range(6):
+        sl = x[k * 2 * rate // 2:(k + 1) * 2 * rate // 2] * (0.2 + 0.15 * k)
+        an.add_samples(sl); mm.add_frames(sl)
+        same()
+    an.reset(); mm.reset()
+    same()
+    an.add_samples(x[:rate]); mm.add_frames(x[:rate])
+    same()
+    an.create_loudness_meter(2, 44100); mm = po.Meter(2, 44100)
+    same()
+    an.add_samples(x[:3 * 44100]); mm.add_frames(x[:3 * 44100])
+    same()
