@@ -73,6 +73,7 @@ int pin_ready(ss_analyzer *h)
     }
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->pin_out), (ss_analyzer::kPinFloats / 2 + 4) * sizeof(float), hipHostMallocDefault));
     HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->pin_out_dev), h->pin_out, 0));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->pin_peaks), 2 * ssk::kMaxChannels * sizeof(float), hipHostMallocDefault));
     double *d = nullptr;
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&d), 2 * sizeof(double), hipHostMallocDefault));
     HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->pin_d_dev), d, 0));
@@ -126,6 +127,7 @@ void ss_analyzer_destroy(ss_analyzer *h)
         if (h->pin_ev[i]) (void)hipEventDestroy(h->pin_ev[i]);
     }
     if (h->pin_out) (void)hipHostFree(h->pin_out);
+    if (h->pin_peaks) (void)hipHostFree(h->pin_peaks);
     if (h->pin_d) (void)hipHostFree(h->pin_d);
     delete h;
 }
@@ -473,22 +475,36 @@ int ss_get_momentary_lufs(ss_analyzer *h, double *out)
     return ring_loudness(h, (uint64_t)h->td->host.s100 * 4, out);
 }
 
+// integrated loudness + loudness range (one histogram evaluation) and every channel's peaks (one copy), behind ONE wait: the
+// readings of the current meter state, kept in the handle until the state moves
+static int refresh_readings(ss_analyzer *h)
+{
+    if (h->eval_stamp == h->change_count && h->peaks_stamp == h->change_count) return SS_OK;
+    const double *he, *hb;
+    int rc = get_hist_tables(&he, &hb);
+    if (rc) return rc;
+    rc = pin_ready(h);
+    if (rc) return rc;
+    static_assert(offsetof(ssk::TdState, true_peak) == offsetof(ssk::TdState, sample_peak) + sizeof(float) * ssk::kMaxChannels,
+                  "sample_peak and true_peak are read as one block");
+    HIPCHK(ssk::launch_hist_eval(h->hist.p, he, hb, h->pin_d_dev, h->stream));
+    HIPCHK(hipMemcpyAsync(h->pin_peaks, &h->state.p->sample_peak[0], 2 * ssk::kMaxChannels * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    pin_all_free(h);
+    h->eval_cache[0] = h->pin_d[0]; h->eval_cache[1] = h->pin_d[1];
+    std::memcpy(h->peaks_cache, h->pin_peaks, sizeof h->peaks_cache);
+    h->eval_stamp = h->peaks_stamp = h->change_count;
+    return SS_OK;
+}
+
 static int hist_eval(ss_analyzer *h, double r[2])
 {
     SS_ON_DEVICE(h);
     if (!h) return SS_ERR_INVALID_ARG;
     if (!h->meter_ok) return SS_ERR_INVALID_MODE;
-    const double *he, *hb;
-    int rc = get_hist_tables(&he, &hb);
+    int rc = refresh_readings(h);
     if (rc) return rc;
-    if (h->eval_stamp == h->change_count) { r[0] = h->eval_cache[0]; r[1] = h->eval_cache[1]; return SS_OK; }
-    rc = pin_ready(h);
-    if (rc) return rc;
-    HIPCHK(ssk::launch_hist_eval(h->hist.p, he, hb, h->pin_d_dev, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    pin_all_free(h);
-    r[0] = h->eval_cache[0] = h->pin_d[0]; r[1] = h->eval_cache[1] = h->pin_d[1];
-    h->eval_stamp = h->change_count;
+    r[0] = h->eval_cache[0]; r[1] = h->eval_cache[1];
     return SS_OK;
 }
 
@@ -520,15 +536,8 @@ static int read_peaks(ss_analyzer *h, uint32_t ch, double *sample_pk, double *tr
     if (!h) return SS_ERR_INVALID_ARG;
     if (!h->meter_ok) return SS_ERR_INVALID_MODE;
     if (ch >= h->channels) return SS_ERR_INVALID_CHANNEL;
-    if (h->peaks_stamp != h->change_count) {
-        // every channel's sample and true peak in one copy (they stand side by side in the state)
-        static_assert(offsetof(ssk::TdState, true_peak) == offsetof(ssk::TdState, sample_peak) + sizeof(float) * ssk::kMaxChannels,
-                      "sample_peak and true_peak are read as one block");
-        HIPCHK(hipMemcpyAsync(h->peaks_cache, &h->state.p->sample_peak[0], sizeof h->peaks_cache, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        pin_all_free(h);
-        h->peaks_stamp = h->change_count;
-    }
+    int rc = refresh_readings(h);
+    if (rc) return rc;
     const float sp = h->peaks_cache[ch], tp = h->peaks_cache[ssk::kMaxChannels + ch];
     if (sample_pk) *sample_pk = (double)sp;
     if (true_pk) *true_pk = (double)(tp > sp ? tp : sp);    // true_peak(): max(true, sample)

@@ -191,7 +191,7 @@ struct ss_analyzer {
     // :950, :969; a frame every 8 ms, a tick every 21): a reading is taken from the device once per state of the meter —
     // `change_count` moves with every feed, reset and re-configuration — and handed out from here until the state moves again.
     uint64_t change_count = 1;
-    uint64_t eval_stamp = 0, peaks_stamp = 0;
+    uint64_t eval_stamp = 0, peaks_stamp = 0;               // (both readings are taken together: one wait)
     double eval_cache[2] = {0.0, 0.0};                       // (integrated, range) at eval_stamp
     float peaks_cache[2 * ssk::kMaxChannels] = {};          // sample peaks | true peaks at peaks_stamp
     // Small calls — a tick through the Analyzer API: get_fft x 2, add_samples, get_shortterm_lufs on 16384 samples — move no
@@ -206,6 +206,7 @@ struct ss_analyzer {
     int pin_next = 0;
     float *pin_out = nullptr, *pin_out_dev = nullptr;       // kPinFloats / 2 + 1 dB values
     double *pin_d = nullptr, *pin_d_dev = nullptr;          // a getter's pair of doubles
+    float *pin_peaks = nullptr;                              // 2 * kMaxChannels floats: the state's peaks, copied there
 };
 
 namespace ssh {
