@@ -207,6 +207,11 @@ struct ss_analyzer {
     float *pin_out = nullptr, *pin_out_dev = nullptr;       // kPinFloats / 2 + 1 dB values
     double *pin_d = nullptr, *pin_d_dev = nullptr;          // a getter's pair of doubles
     float *pin_peaks = nullptr;                              // 2 * kMaxChannels floats: the state's peaks, copied there
+    double *pin_eval = nullptr, *pin_eval_dev = nullptr;    // (integrated, range) of the state the readings were last asked for
+    float *pin_peaks_dev = nullptr;
+    uint32_t *pin_flag = nullptr, *pin_flag_dev = nullptr;  // the readings launch stores its number there, last
+    uint32_t readings_seq = 0;                               // readings launches so far
+    uint64_t prefetch_stamp = 0;                             // change_count the launch in flight is of (0: none)
 };
 
 namespace ssh {
@@ -216,6 +221,9 @@ SS_HIDDEN int handle_reset(ss_analyzer *h);
 SS_HIDDEN int pin_ready(ss_analyzer *h);
 SS_HIDDEN int pin_acquire(ss_analyzer *h, int *idx);
 SS_HIDDEN void pin_all_free(ss_analyzer *h);           // behind a hipStreamSynchronize of h->stream
+// enqueue (no wait) the readings the reference's render loop asks for on every frame — integrated loudness and range, every
+// channel's peaks — behind whatever has just changed the meter's state: the getters then find them waiting
+SS_HIDDEN int prefetch_readings(ss_analyzer *h);
 // add_frames_f32 on the handle's meter; on_device: `samples` already lives in HBM (nothing is copied or waited for)
 // `deferred`: a single-piece device-resident call hands the gating launch (k_finalize_stream) of its new sub-blocks back to the
 // caller instead of enqueueing it (n_streams != 0: launch it with ssk::launch_finalize on h->stream before anything else reads the

@@ -182,8 +182,11 @@ struct FinalizeParams {
 };
 hipError_t launch_finalize(const FinalizeParams &p, hipStream_t s);
 // gate + LRA on explicit histograms (corpus gate after the all-reduce; handle getters)
+// `peaks` (optional): a handle's readings in one launch — 2 * kMaxChannels floats copied from peaks_src to peaks_dst beside the
+// evaluation, then `seq` stored into *flag (host-visible memory: whoever sees the flag sees out2 and the peaks)
+struct ReadingsExtra { const float *peaks_src; float *peaks_dst; uint32_t *flag; uint32_t seq; };
 hipError_t launch_hist_eval(const uint64_t *hist2000, const double *energies, const double *bounds,
-                            double *out2, hipStream_t s);
+                            double *out2, hipStream_t s, const ReadingsExtra *peaks = nullptr);
 // mean-square of the filtered ring over the last `frames` frames (handle getters)
 constexpr int kRingScratchDoubles = 320;     // k_ring_energy: 256 partial sums + the completion counter; k_tick: kRingTickBlocks + 1 from kRingTickScratch on
 constexpr int kRingTickScratch = 264;        // where a tick launch keeps ITS partial sums and count (the two kernels never share a slot)

@@ -259,20 +259,31 @@ hipError_t launch_finalize(const FinalizeParams &p, hipStream_t s)
 }
 
 __global__ __launch_bounds__(64) void k_hist_eval(const unsigned long long *hist2000, const double *en,
-                                                  const double *bd, double *out2)
+                                                  const double *bd, double *out2, ReadingsExtra x)
 {
     __shared__ unsigned long long hb[kHistBins];
     __shared__ unsigned long long hs[kHistBins];
     for (int i = threadIdx.x; i < kHistBins; i += 64) { hb[i] = hist2000[i]; hs[i] = hist2000[kHistBins + i]; }
+    if (x.peaks_dst) {
+        x.peaks_dst[threadIdx.x] = x.peaks_src[threadIdx.x];
+        x.peaks_dst[64 + threadIdx.x] = x.peaks_src[64 + threadIdx.x];
+    }
     __syncthreads();
     eval_hist(hb, hs, en, bd, &out2[0], &out2[1]);
+    if (x.flag) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(x.flag, x.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 hipError_t launch_hist_eval(const uint64_t *hist2000, const double *energies, const double *bounds,
-                            double *out2, hipStream_t s)
+                            double *out2, hipStream_t s, const ReadingsExtra *peaks)
 {
+    static_assert(2 * kMaxChannels == 128, "k_hist_eval copies two floats per lane");
     hipLaunchKernelGGL(k_hist_eval, dim3(1), dim3(64), 0, s,
-                       reinterpret_cast<const unsigned long long *>(hist2000), energies, bounds, out2);
+                       reinterpret_cast<const unsigned long long *>(hist2000), energies, bounds, out2,
+                       peaks ? *peaks : ReadingsExtra{nullptr, nullptr, nullptr, 0u});
     return hipGetLastError();
 }
 

@@ -445,6 +445,9 @@ int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side
         }
     }
     SS_TICK_T(5);
+    // ... and behind the gating, what the render loop asks the file analyzer for on its next frame (tui.rs:917, :950, :969):
+    // enqueued here, in the gap between the charts and the end of the loudness call
+    if (res->fed && res->add_status == SS_OK) { int rc = prefetch_readings(h); if (rc) return rc; }
     if (any_launch) HIPCHK(hipEventSynchronize(s->ev_tick));
     SS_TICK_T(6);
     if (res->fft_ran) {
@@ -518,6 +521,7 @@ int ss_session_tick_capture(ss_session *s, const float *latest, size_t n, double
     }
     HIPCHK(hipEventRecord(s->ev_tick, h->stream));
     if (gating.n_streams) HIPCHK(ssk::launch_finalize(gating, h->stream));
+    if (res->add_status == SS_OK) { int rc = prefetch_readings(h); if (rc) return rc; }
     // get_fft's value checks on the two 16384-sample slices (the device is working)
     std::vector<std::pair<size_t, uint8_t>> bad;
     for (size_t i = lb; i < pairs; i++) {

@@ -40,6 +40,7 @@ for tick, pos in enumerate(range(16384 * 2 + 2048, x.size, 2048)):
     t0 = time.perf_counter()
     sess.analyze_audio_file_samples(pos)
     t1 = time.perf_counter()
+    time.sleep(0.0003)        # (ticks are 21 ms apart; each leaves the gating and the render loop's readings running behind its results)
     if tick >= 20:
         t_sess.append(t1 - t0)
     if tick > 300:
@@ -76,3 +77,12 @@ for k in range(40):
     an.get_integrated_lufs(); an.get_true_peak(); an.get_loudness_range(); t2 = time.perf_counter()
     t_first.append(t1 - t0); t_rep.append(t2 - t1)
 print("render-loop getters (integrated + true peak + range): first reading of a state", f(t_first), "| again", f(t_rep))
+# the same getters on a file session's analyzer right behind a tick (the tick has enqueued them)
+t_g = []
+for k, pos in enumerate(range(16384 * 2 + 2048, x.size, 2048)):
+    sess.analyze_audio_file_samples(pos)
+    time.sleep(0.0002)                                   # (the render comes a few hundred microseconds later at the earliest)
+    t0 = time.perf_counter(); sess.analyzer.get_integrated_lufs(); sess.analyzer.get_true_peak(); sess.analyzer.get_loudness_range(); t1 = time.perf_counter()
+    t_g.append(t1 - t0)
+    if k > 200: break
+print("render-loop getters on the session's analyzer behind a tick:", f(t_g))
