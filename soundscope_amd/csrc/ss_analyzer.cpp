@@ -100,12 +100,29 @@ int pin_acquire(ss_analyzer *h, int *idx)
 
 void pin_all_free(ss_analyzer *h) { h->pin_busy[0] = h->pin_busy[1] = false; }
 
-int prefetch_readings(ss_analyzer *h)
+int attach_readings(ss_analyzer *h, ssk::FinalizeParams *gating)
+{
+    if (!h->meter_ok || !gating || gating->n_streams != 1) return SS_OK;
+#ifdef SS_TUNING
+    { static const bool off = std::getenv("SS_NO_PREFETCH") != nullptr; if (off) return SS_OK; }
+#endif
+    int rc = pin_ready(h);
+    if (rc) return rc;
+    h->readings_seq = h->readings_seq + 1u ? h->readings_seq + 1u : 1u;
+    gating->readings_out = h->pin_eval_dev;
+    gating->readings_peaks_src = &h->state.p->sample_peak[0]; gating->readings_peaks_dst = h->pin_peaks_dev;
+    gating->readings_flag = h->pin_flag_dev; gating->readings_seq = h->readings_seq;
+    h->prefetch_stamp = h->change_count;
+    return SS_OK;
+}
+
+int prefetch_readings(ss_analyzer *h, bool on_demand)
 {
     if (!h->meter_ok) return SS_OK;
 #ifdef SS_TUNING        // development builds only: SS_NO_PREFETCH=1 leaves the readings to the getters (A/B of the tick)
-    { static const bool off = std::getenv("SS_NO_PREFETCH") != nullptr; if (off) return SS_OK; }
+    { static const bool off = std::getenv("SS_NO_PREFETCH") != nullptr; if (off && !on_demand) return SS_OK; }
 #endif
+    (void)on_demand;
     const double *he, *hb;
     int rc = get_hist_tables(&he, &hb);
     if (rc) return rc;
@@ -438,7 +455,10 @@ int ssh::add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool o
             // a caller that has something shorter to put in front (a tick's short-term reading) launches the gating of a
             // single-piece call itself, on the same stream
             if (deferred && on_device && take == frames) *deferred = f;
-            else HIPCHK(ssk::launch_finalize(f, h->stream));
+            else {
+                if (pin >= 0) { rc = attach_readings(h, &f); if (rc) return rc; }     // (a tick-sized call: the render asks next)
+                HIPCHK(ssk::launch_finalize(f, h->stream));
+            }
         }
         // the staging buffer is reused by the next piece
         if (!on_device) HIPCHK(hipStreamSynchronize(h->stream));
@@ -448,9 +468,9 @@ int ssh::add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool o
     if (pin >= 0) {
         HIPCHK(hipEventRecord(h->pin_ev[pin], h->stream));
         h->pin_busy[pin] = true;
-        // a tick-sized call from the reference's loop: its render asks for these on the next frame
-        rc = prefetch_readings(h);
-        if (rc) return rc;
+        // a tick-sized call from the reference's loop: its render asks for these on the next frame (they rode the gating
+        // launch if there was one)
+        if (h->prefetch_stamp != h->change_count) { rc = prefetch_readings(h); if (rc) return rc; }
     }
     return SS_OK;
 }
@@ -515,7 +535,7 @@ static int refresh_readings(ss_analyzer *h)
 {
     if (h->eval_stamp == h->change_count && h->peaks_stamp == h->change_count) return SS_OK;
     if (h->prefetch_stamp != h->change_count) {         // nobody has asked for this state's readings yet
-        int rc = prefetch_readings(h);
+        int rc = prefetch_readings(h, true);
         if (rc) return rc;
     }
     // the flag (bounded polling: the launch may still be running, or the memory may deliver the flag with the kernel's end),

@@ -223,7 +223,10 @@ SS_HIDDEN int pin_acquire(ss_analyzer *h, int *idx);
 SS_HIDDEN void pin_all_free(ss_analyzer *h);           // behind a hipStreamSynchronize of h->stream
 // enqueue (no wait) the readings the reference's render loop asks for on every frame — integrated loudness and range, every
 // channel's peaks — behind whatever has just changed the meter's state: the getters then find them waiting
-SS_HIDDEN int prefetch_readings(ss_analyzer *h);
+SS_HIDDEN int prefetch_readings(ss_analyzer *h, bool on_demand = false);      // on_demand: a getter asking (never switched off)
+// the same riding a gating launch that is about to be enqueued on h->stream (k_finalize_stream takes the readings behind its
+// histogram updates): fills the launch's fields and marks the readings as on their way
+SS_HIDDEN int attach_readings(ss_analyzer *h, ssk::FinalizeParams *gating);
 // add_frames_f32 on the handle's meter; on_device: `samples` already lives in HBM (nothing is copied or waited for)
 // `deferred`: a single-piece device-resident call hands the gating launch (k_finalize_stream) of its new sub-blocks back to the
 // caller instead of enqueueing it (n_streams != 0: launch it with ssk::launch_finalize on h->stream before anything else reads the

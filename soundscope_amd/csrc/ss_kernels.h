@@ -179,6 +179,10 @@ struct FinalizeParams {
     double *out_lra;                 // [stream] (nullable)
     uint32_t *out_counts;            // [stream][2] gating / short-term blocks evaluated (nullable)
     const uint32_t *sub_end_of;   // ragged batches: sub-blocks of each stream (nullable = sub_end for all)
+    // streaming form only (one handle): behind the histogram updates the same wave takes the handle's readings — (integrated,
+    // range) into readings_out, the peaks and the flag as in ReadingsExtra below (readings_out == nullptr: off)
+    double *readings_out;
+    const float *readings_peaks_src; float *readings_peaks_dst; uint32_t *readings_flag; uint32_t readings_seq;
 };
 hipError_t launch_finalize(const FinalizeParams &p, hipStream_t s);
 // gate + LRA on explicit histograms (corpus gate after the all-reduce; handle getters)

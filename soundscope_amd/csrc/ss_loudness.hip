@@ -241,6 +241,28 @@ __global__ __launch_bounds__(64) void k_finalize_stream(FinalizeParams p)
         if (nb) atomicAdd(&p.out_counts[0], nb);
         if (ns) atomicAdd(&p.out_counts[1], ns);
     }
+    // the handle's readings behind the update (what the reference's render loop asks for on its next frame): the same wave
+    // evaluates the histograms it has just touched — no launch of its own inside a tick
+    if (p.readings_out) {
+        __shared__ unsigned long long hb[kHistBins];
+        __shared__ unsigned long long hs[kHistBins];
+        __threadfence();                                    // this wave's atomics have landed
+        for (int i = lane; i < kHistBins; i += 64) {
+            hb[i] = __hip_atomic_load(&gh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hs[i] = __hip_atomic_load(&gh[kHistBins + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (p.readings_peaks_dst) {
+            p.readings_peaks_dst[lane] = p.readings_peaks_src[lane];
+            p.readings_peaks_dst[64 + lane] = p.readings_peaks_src[64 + lane];
+        }
+        __syncthreads();
+        eval_hist(hb, hs, p.hist_energies, p.hist_bounds, &p.readings_out[0], &p.readings_out[1]);
+        if (p.readings_flag) {
+            __threadfence_system();
+            __syncthreads();
+            if (lane == 0) __hip_atomic_store(p.readings_flag, p.readings_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 hipError_t launch_finalize(const FinalizeParams &p, hipStream_t s)

@@ -421,7 +421,13 @@ int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side
         }
     }
     if (any_launch) HIPCHK(hipEventRecord(s->ev_tick, h->stream));
-    if (gating.n_streams) HIPCHK(ssk::launch_finalize(gating, h->stream));
+    // behind the event: the gating — and riding it, what the render loop asks the file analyzer for on its next frame
+    // (tui.rs:917, :950, :969: integrated loudness, range, peaks)
+    if (gating.n_streams) {
+        int rc = attach_readings(h, &gating);
+        if (rc) return rc;
+        HIPCHK(ssk::launch_finalize(gating, h->stream));
+    }
     SS_TICK_T(3);
     // while the device works: the x halves of the two charts (they do not depend on it)
     if (res->fft_ran) {
@@ -445,9 +451,8 @@ int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side
         }
     }
     SS_TICK_T(5);
-    // ... and behind the gating, what the render loop asks the file analyzer for on its next frame (tui.rs:917, :950, :969):
-    // enqueued here, in the gap between the charts and the end of the loudness call
-    if (res->fed && res->add_status == SS_OK) { int rc = prefetch_readings(h); if (rc) return rc; }
+    // (a tick that completed no sub-block has no gating launch to ride: the readings get their own)
+    if (res->fed && res->add_status == SS_OK && h->prefetch_stamp != h->change_count) { int rc = prefetch_readings(h); if (rc) return rc; }
     if (any_launch) HIPCHK(hipEventSynchronize(s->ev_tick));
     SS_TICK_T(6);
     if (res->fft_ran) {
@@ -520,8 +525,12 @@ int ss_session_tick_capture(ss_session *s, const float *latest, size_t n, double
         HIPCHK(ssk::launch_waveform(p, h->stream));
     }
     HIPCHK(hipEventRecord(s->ev_tick, h->stream));
-    if (gating.n_streams) HIPCHK(ssk::launch_finalize(gating, h->stream));
-    if (res->add_status == SS_OK) { int rc = prefetch_readings(h); if (rc) return rc; }
+    if (gating.n_streams) {
+        int rc = attach_readings(h, &gating);
+        if (rc) return rc;
+        HIPCHK(ssk::launch_finalize(gating, h->stream));
+    }
+    if (res->add_status == SS_OK && h->prefetch_stamp != h->change_count) { int rc = prefetch_readings(h); if (rc) return rc; }
     // get_fft's value checks on the two 16384-sample slices (the device is working)
     std::vector<std::pair<size_t, uint8_t>> bad;
     for (size_t i = lb; i < pairs; i++) {
