@@ -195,8 +195,11 @@ __device__ __forceinline__ void fft16k_window(const FftBatchParams &p, int midsi
             const float2 vb = reinterpret_cast<const float2 *>(base)[2 * (size_t)i + 1];
             x0 = ch == 0 ? (va.x + va.y) * 0.5f : (va.x - va.y) * 0.5f;
             x1 = ch == 0 ? (vb.x + vb.y) * 0.5f : (vb.x - vb.y) * 0.5f;
+        } else if (p.channels == 1) {
+            const float2 v = reinterpret_cast<const float2 *>(base)[i];                     // mono buffer: samples 2i, 2i+1 in one load
+            x0 = v.x; x1 = v.y;
         } else {
-            x0 = base[(size_t)(2 * i) * p.channels + ch];       // mono buffers have fft_ch == 1 => ch == 0
+            x0 = base[(size_t)(2 * i) * p.channels + ch];
             x1 = base[(size_t)(2 * i + 1) * p.channels + ch];
         }
         const float2 hw = *reinterpret_cast<const float2 *>(p.window + 2 * (size_t)i);
