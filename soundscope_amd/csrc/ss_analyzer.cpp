@@ -71,6 +71,7 @@ int pin_ready(ss_analyzer *h)
         HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->pin_in_dev[i]), h->pin_in[i], 0));
         HIPCHK(hipEventCreateWithFlags(&h->pin_ev[i], hipEventDisableTiming));
     }
+    HIPCHK(hipEventCreateWithFlags(&h->pin_ev[2], hipEventDisableTiming));       // behind a short-term / momentary reading
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->pin_out), (ss_analyzer::kPinFloats / 2 + 4) * sizeof(float), hipHostMallocDefault));
     HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->pin_out_dev), h->pin_out, 0));
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->pin_peaks), 2 * ssk::kMaxChannels * sizeof(float), hipHostMallocDefault));
@@ -168,10 +169,8 @@ void ss_analyzer_destroy(ss_analyzer *h)
     SS_ON_DEVICE(h);
     if (!h) return;
     if (h->stream) { (void)hipStreamSynchronize(h->stream); stream_release(h->stream); }
-    for (int i = 0; i < 2; i++) {
-        if (h->pin_in[i]) (void)hipHostFree(h->pin_in[i]);
-        if (h->pin_ev[i]) (void)hipEventDestroy(h->pin_ev[i]);
-    }
+    for (int i = 0; i < 2; i++) if (h->pin_in[i]) (void)hipHostFree(h->pin_in[i]);
+    for (int i = 0; i < 3; i++) if (h->pin_ev[i]) (void)hipEventDestroy(h->pin_ev[i]);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->pin_peaks) (void)hipHostFree(h->pin_peaks);
     if (h->pin_eval) (void)hipHostFree(h->pin_eval);
@@ -466,10 +465,7 @@ int ssh::add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool o
             // a caller that has something shorter to put in front (a tick's short-term reading) launches the gating of a
             // single-piece call itself, on the same stream
             if (deferred && on_device && take == frames) *deferred = f;
-            else {
-                if (pin >= 0) { rc = attach_readings(h, &f); if (rc) return rc; }     // (a tick-sized call: the render asks next)
-                HIPCHK(ssk::launch_finalize(f, h->stream));
-            }
+            else HIPCHK(ssk::launch_finalize(f, h->stream));
         }
         // the staging buffer is reused by the next piece
         if (!on_device) HIPCHK(hipStreamSynchronize(h->stream));
@@ -479,9 +475,6 @@ int ssh::add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool o
     if (pin >= 0) {
         HIPCHK(hipEventRecord(h->pin_ev[pin], h->stream));
         h->pin_busy[pin] = true;
-        // a tick-sized call from the reference's loop: its render asks for these on the next frame (they rode the gating
-        // launch if there was one)
-        if (h->prefetch_stamp != h->change_count) { rc = prefetch_readings(h); if (rc) return rc; }
     }
     return SS_OK;
 }
@@ -520,8 +513,11 @@ static int ring_loudness(ss_analyzer *h, uint64_t frames, double *out)
     if (rc) return rc;
     rc = ring_loudness_enqueue(h, frames, h->pin_d_dev);        // (energy, loudness) straight into page-locked memory
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
-    pin_all_free(h);
+    // the call waits for its own reading only; behind it the readings the reference's render loop asks for on its next frame
+    // (integrated loudness, range, peaks: tui.rs:917, :950, :969) are put on their way
+    HIPCHK(hipEventRecord(h->pin_ev[2], h->stream));
+    if (h->prefetch_stamp != h->change_count) { rc = prefetch_readings(h); if (rc) return rc; }
+    HIPCHK(hipEventSynchronize(h->pin_ev[2]));
     *out = h->pin_d[1];
     return SS_OK;
 }

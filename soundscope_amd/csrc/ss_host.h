@@ -201,7 +201,7 @@ struct ss_analyzer {
     // a buffer's kernel has read it); every call that waits for the stream frees both.
     static constexpr size_t kPinFloats = 32768;
     float *pin_in[2] = {nullptr, nullptr}, *pin_in_dev[2] = {nullptr, nullptr};
-    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    hipEvent_t pin_ev[3] = {nullptr, nullptr, nullptr};      // [0], [1]: an input buffer's kernel has read it; [2]: a ring reading is there
     bool pin_busy[2] = {false, false};
     int pin_next = 0;
     float *pin_out = nullptr, *pin_out_dev = nullptr;       // kPinFloats / 2 + 1 dB values
