@@ -425,7 +425,10 @@ int ssh::add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool o
         rc = pin_acquire(h, &pin);
         if (rc) return rc;
         std::memcpy(h->pin_in[pin], samples, n * sizeof(float));
-        samples = h->pin_in_dev[pin];
+        // ... and on to HBM by one DMA (reading the page-locked copy in place over PCIe cost the kernel 33 instead of 22 us)
+        HIPCHK(h->in.ensure(n));
+        HIPCHK(hipMemcpyAsync(h->in.p, h->pin_in[pin], n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        samples = h->in.p;
         on_device = true;
     }
     while (done < frames) {

@@ -1,3 +1,5 @@
+#!/bin/bash
+# kernel durations of the Analyzer path's add_samples + get_shortterm_lufs (tick-sized slices through page-locked buffers)
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/r6g; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
@@ -17,6 +19,10 @@ for rep in range(2):
 PY
 rocprofv3 --kernel-trace --stats -f csv -d $out/ht -o ht -- python /tmp/ad.py > $out/run.log 2>&1
 grep "wall" $out/run.log
-f=$(find $out/ht -name '*kernel_stats.csv' | head -1); head -6 "$f" | cut -d, -f1-7
+f=$(find $out/ht -name '*kernel_stats.csv' | head -1)
+python - "$f" <<PY
+import csv, sys
+for r in list(csv.reader(open(sys.argv[1])))[:6]: print(r[0][:60].ljust(60), *r[1:5])
+PY
 rm -rf $out/ht
 python /tmp/ad.py
