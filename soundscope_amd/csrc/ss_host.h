@@ -195,10 +195,11 @@ struct ss_analyzer {
     double eval_cache[2] = {0.0, 0.0};                       // (integrated, range) at eval_stamp
     float peaks_cache[2 * ssk::kMaxChannels] = {};          // sample peaks | true peaks at peaks_stamp
     // Small calls — a tick through the Analyzer API: get_fft x 2, add_samples, get_shortterm_lufs on 16384 samples — move no
-    // data with copy commands (a pageable 64 KB hipMemcpyAsync and a read-back cost more than the kernel between them): the
-    // samples are copied by the host into page-locked memory that the kernel reads in place, and results are written by the
-    // kernels into page-locked memory.  Two input buffers, so that add_samples returns behind its launch (an event says when
-    // a buffer's kernel has read it); every call that waits for the stream frees both.
+    // data with pageable copy commands and read-backs (a pageable 64 KB hipMemcpyAsync blocks the caller and costs more than the
+    // kernel behind it): the samples are copied by the host into page-locked memory, from where ONE DMA takes them to HBM (the
+    // kernels read their input in small pieces: in place over PCIe that cost them 10-14 us), and results are written by the
+    // kernels into page-locked memory.  Two input buffers, so that add_samples returns behind its launches (an event says when
+    // a buffer's copy has left it); every call that waits for the stream frees both.
     static constexpr size_t kPinFloats = 32768;
     float *pin_in[2] = {nullptr, nullptr}, *pin_in_dev[2] = {nullptr, nullptr};
     hipEvent_t pin_ev[3] = {nullptr, nullptr, nullptr};      // [0], [1]: an input buffer's kernel has read it; [2]: a ring reading is there
