@@ -209,3 +209,36 @@ def test_capture_session_non_finite_samples(oracle):
                 assert np.array_equal(got, want), case
         a, b = res.shortterm, ref["shortterm"]
         assert (np.isnan(a) and np.isnan(b)) or lufs_close(a, b), (case, a, b)
+
+
+def test_file_session_many_non_finite_pairs_and_empty_file(oracle):
+    """More non-finite pairs than the device-side index holds (the open falls back to the host's own scan), and a file without a
+    single sample: statuses and fallbacks like the restated App's."""
+    from oracle.app_driver import FileApp
+    rate = 48000
+    x = make_stereo(11, rate * 2, rate=rate, level=0.3)
+    x[2 * 20000:2 * 20000 + 2 * 6000:2] = np.nan              # 6000 pairs with a NaN left sample
+    x[2 * 50000 + 1:2 * 50000 + 2 * 3000:2] = np.inf          # 3000 pairs with an infinite right sample
+    sess = ssa.FileSession(x, 2, rate); app = FileApp(x, 2, rate)
+    assert np.array_equal(sess.audio_file_chart, app.audio_file_chart, equal_nan=True)
+    for pos in range(2048 * 14, x.size + 2 * 2048, 2048 * 5):
+        res = sess.analyze_audio_file_samples(pos); ref = app.analyze_audio_file_samples(pos)
+        for key in ("fft_ran", "mid_status", "side_status", "lufs_ran", "fed", "add_status"):
+            assert getattr(res, key) == ref[key], (pos, key, getattr(res, key), ref[key])
+        if ref["fft_ran"]:
+            for got, want in ((sess.mid_fft, app.mid_fft), (sess.side_fft, app.side_fft)):
+                assert got.shape == want.shape, pos
+                if want.shape[0] > 1:
+                    assert db_close(got[:, 1], want[:, 1], TOL_DB), pos
+                else:
+                    assert np.array_equal(got, want), pos
+    sess.close()
+    empty = np.zeros(0, np.float32)
+    sess = ssa.FileSession(empty, 2, rate); app = FileApp(empty, 2, rate)
+    assert sess.duration_ms == app.duration_ms
+    assert sess.audio_file_chart.shape == app.audio_file_chart.shape
+    for pos in (0, 2048, 40000):
+        res = sess.analyze_audio_file_samples(pos); ref = app.analyze_audio_file_samples(pos)
+        for key in ("fft_ran", "mid_status", "side_status", "lufs_ran", "fed", "add_status"):
+            assert getattr(res, key) == ref[key], (pos, key, getattr(res, key), ref[key])
+    sess.close()
