@@ -185,23 +185,38 @@ def reference_tick_workload(ssa, L, rate=48000, secs=12, cpu_ticks=60):
     open2_ms = float(np.median(warm))
     positions = list(range(16384 * 2 + 2048, x.size + 1, 2048))
     ticks = []
+    check_at = {19 + cpu_ticks // 2: None, 19 + cpu_ticks: None}       # ticks whose results are compared with the CPU driver's
     for k, pos in enumerate(positions):
         t0 = time.perf_counter()
         sess.analyze_audio_file_samples(pos)
         t1 = time.perf_counter()
         if k >= 20:
             ticks.append((t1 - t0) * 1e6)
+        if k in check_at:
+            check_at[k] = (sess.mid_fft.copy(), sess.side_fft.copy(), float(sess.lufs[299]))
         # (the reference's ticks are 21.3 ms apart; each leaves work behind its results — the gating of the new sub-blocks, the
         # readings the render loop will ask for — that a call issued the very next microsecond would queue behind)
         time.sleep(0.0003)
-    last_gpu = (sess.mid_fft.copy(), sess.side_fft.copy(), float(sess.lufs[299]))
     sess.close()
     t0 = time.perf_counter(); app = app_driver.FileApp(x, 2, rate); cpu_open_ms = (time.perf_counter() - t0) * 1e3
     cpu = []
-    for pos in positions[:20 + cpu_ticks]:
+    worst_db, worst_lu, compared = 0.0, 0.0, 0
+    for k, pos in enumerate(positions[:20 + cpu_ticks]):
         t0 = time.perf_counter()
         app.analyze_audio_file_samples(pos)
         cpu.append((time.perf_counter() - t0) * 1e6)
+        if check_at.get(k) is not None:
+            gm, gs, gst = check_at[k]
+            for got, want in ((gm, app.mid_fft), (gs, app.side_fft)):
+                if got.shape == want.shape and want.shape[0] > 1:
+                    near = want[:, 1] >= want[:, 1].max() - 70.0                 # (the bar's range: within 70 dB of the row's peak)
+                    worst_db = max(worst_db, float(np.max(np.abs(got[near, 1] - want[near, 1]))))
+                else:
+                    worst_db = float("inf")
+            worst_lu = max(worst_lu, abs(gst - float(app.lufs[299])))
+            compared += 1
+    out["tick_check_vs_cpu_driver"] = {"ticks_compared": compared, "spectrum_max_err_db": worst_db, "shortterm_err_lu": worst_lu,
+                                       "ok": bool(compared > 0 and worst_db <= 0.01 and worst_lu <= 0.01)}
     out["gpu_tick_us"] = {"median": float(np.median(ticks)), "p99": float(np.percentile(ticks, 99)), "ticks": len(ticks)}
     out["cpu_oracle_tick_us"] = {"median": float(np.median(cpu[20:])), "ticks": len(cpu) - 20, "cores": 1,
                                  "what": "oracle/app_driver.FileApp (the C restatement behind the same driver rules), 1 thread"}
