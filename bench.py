@@ -197,6 +197,13 @@ def reference_tick_workload(ssa, L, rate=48000, secs=12, cpu_ticks=60):
         # (the reference's ticks are 21.3 ms apart; each leaves work behind its results — the gating of the new sub-blocks, the
         # readings the render loop will ask for — that a call issued the very next microsecond would queue behind)
         time.sleep(0.0003)
+    # ... and 60 ticks at the reference's own cadence (1024 frames = 21.3 ms between ticks at 48 kHz: clocks and caches go idle)
+    slow = []
+    for pos in positions[len(positions) // 2:len(positions) // 2 + 60]:
+        t0 = time.perf_counter()
+        sess.analyze_audio_file_samples(pos)
+        slow.append((time.perf_counter() - t0) * 1e6)
+        time.sleep(1024.0 / rate)
     sess.close()
     t0 = time.perf_counter(); app = app_driver.FileApp(x, 2, rate); cpu_open_ms = (time.perf_counter() - t0) * 1e3
     cpu = []
@@ -217,7 +224,10 @@ def reference_tick_workload(ssa, L, rate=48000, secs=12, cpu_ticks=60):
             compared += 1
     out["tick_check_vs_cpu_driver"] = {"ticks_compared": compared, "spectrum_max_err_db": worst_db, "shortterm_err_lu": worst_lu,
                                        "ok": bool(compared > 0 and worst_db <= 0.01 and worst_lu <= 0.01)}
-    out["gpu_tick_us"] = {"median": float(np.median(ticks)), "p99": float(np.percentile(ticks, 99)), "ticks": len(ticks)}
+    out["gpu_tick_us"] = {"median": float(np.median(ticks)), "p99": float(np.percentile(ticks, 99)), "ticks": len(ticks),
+                          "pause_between_ticks_ms": 0.3,
+                          "at_reference_cadence": {"median": float(np.median(slow)), "p90": float(np.percentile(slow, 90)), "ticks": len(slow),
+                                                   "pause_between_ticks_ms": round(1024.0 / rate * 1e3, 1)}}
     out["cpu_oracle_tick_us"] = {"median": float(np.median(cpu[20:])), "ticks": len(cpu) - 20, "cores": 1,
                                  "what": "oracle/app_driver.FileApp (the C restatement behind the same driver rules), 1 thread"}
     out["file_open_ms"] = {"gpu_first": open_ms, "gpu_warm": open2_ms, "gpu_warm_each": [round(v, 2) for v in warm], "cpu_oracle": cpu_open_ms,
