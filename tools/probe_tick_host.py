@@ -20,10 +20,15 @@ pos = list(range(16384 * 2 + 2048, x.size, 2048))
 for p in pos[:20]:
     sess.analyze_audio_file_samples(p)
 f(out, 1)
-t0 = time.perf_counter()
+pause = float(sys.argv[1]) / 1e3 if len(sys.argv) > 1 else 0.0          # optional: milliseconds between ticks
+if pause: pos = pos[:20 + 100]
+wall = 0.0
 for p in pos[20:]:
+    t0 = time.perf_counter()
     sess.analyze_audio_file_samples(p)
-wall = (time.perf_counter() - t0) / len(pos[20:]) * 1e6
+    wall += time.perf_counter() - t0
+    if pause: time.sleep(pause)
+wall = wall / len(pos[20:]) * 1e6
 f(out, 1)
 n = len(pos[20:])
 names = ["host-side checks", "tick launch", "separate spectrum launch", "short-term enqueue + event + gating", "x halves (host)",
