@@ -437,10 +437,12 @@ const char *ss_batch_kernel_name(const ss_batch *b, int kernel);   /* the kernel
  *    ss_session_open_capture  device selection              tui.rs:1780-1808
  *    ss_session_tick_capture  analyze_microphone_input      tui.rs:1427-1480
  *    ss_session_restart       play / seek handlers          tui.rs:1586-1614
+ *    ss_session_capture_push  the capture callback's extend audio_capture.rs:41-52
  *  A tick is ONE call: nothing is uploaded for a file tick (the file was
- *  uploaded at open; its spectrum runs on a side stream beside the loudness
- *  chain), the capture tick uploads the 30*rate-sample capture ring.  The session owns its analyzer (file_analyzer /
- *  device_analyzer) and the 300-entry short-term history (tui.rs:420,463).
+ *  uploaded at open; its spectrum, its loudness call and its short-term
+ *  reading are one launch); the capture tick either uploads the 30*rate-sample snapshot it is given, or — the ring kept on the
+ *  device, ss_session_capture_push + ss_session_tick_capture_resident — only what was captured since the last tick.  The session
+ *  owns its analyzer (file_analyzer / device_analyzer) and the 300-entry short-term history (tui.rs:420,463).
  * ------------------------------------------------------------------------- */
 typedef struct ss_session ss_session;
 
@@ -485,6 +487,16 @@ int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side
 int ss_session_tick_capture(ss_session *s, const float *latest, size_t n, double *mid_xy,
                             double *side_xy, size_t cap_pairs, double *wave_xy,
                             size_t wave_cap_pairs, size_t *wave_n, ss_tick_result *res);
+/* The capture ring resident on the device (it starts full of zeros like the reference's, tui.rs:1783-1784):
+ *   ss_session_capture_push           the capture callback's `audio_buf.extend(data)` (audio_capture.rs:41-52; mono devices push
+ *                                     the zero-interleaved data the callback builds): host work only
+ *   ss_session_tick_capture_resident  analyze_microphone_input on the ring as it stands after every push so far: the same results
+ *                                     as ss_session_tick_capture on `latest_captured_samples.to_vec()`, without the snapshot
+ * The two forms can be mixed (a snapshot tick replaces the ring).  One caller at a time per session: where the reference
+ * locks its ring's mutex (audio_capture.rs:41, tui.rs:1428), lock around these calls. */
+int ss_session_capture_push(ss_session *s, const float *samples, size_t n);
+int ss_session_tick_capture_resident(ss_session *s, double *mid_xy, double *side_xy, size_t cap_pairs, double *wave_xy,
+                                     size_t wave_cap_pairs, size_t *wave_n, ss_tick_result *res);
 /* lufs = [-100.; 300]; analyzer.reset() */
 int ss_session_restart(ss_session *s);
 int ss_session_lufs_history(ss_session *s, double *out300);

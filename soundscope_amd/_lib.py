@@ -30,7 +30,8 @@ SYMBOLS = [
     "ss_wav_parse", "ss_pcm_sample_bytes", "ss_pcm_decode", "ss_batch_upload_pcm",
     "ss_session_open_file", "ss_session_open_capture", "ss_session_close", "ss_session_analyzer",
     "ss_session_waveform", "ss_session_gain_db", "ss_session_duration_ms", "ss_session_tick_file",
-    "ss_session_tick_capture", "ss_session_restart", "ss_session_lufs_history",
+    "ss_session_tick_capture", "ss_session_capture_push", "ss_session_tick_capture_resident", "ss_session_restart",
+    "ss_session_lufs_history",
     "ss_batch_render_spectrum", "ss_batch_download_spectrum_columns", "ss_batch_render_waveform",
     "ss_batch_download_waveform_columns", "ss_waveform_view", "ss_batch_kernel_name",
     "ss_host_register", "ss_host_unregister", "ss_batch_upload_pcm_async",
@@ -172,6 +173,8 @@ def _bind(lib):
         "ss_session_tick_file": (C.c_int, [vp, C.c_size_t, f64p, f64p, C.c_size_t, C.POINTER(TickResult)]),
         "ss_session_tick_capture": (C.c_int, [vp, f32p, C.c_size_t, f64p, f64p, C.c_size_t, f64p, C.c_size_t,
                                               szp, C.POINTER(TickResult)]),
+        "ss_session_capture_push": (C.c_int, [vp, f32p, C.c_size_t]),
+        "ss_session_tick_capture_resident": (C.c_int, [vp, f64p, f64p, C.c_size_t, f64p, C.c_size_t, szp, C.POINTER(TickResult)]),
         "ss_session_restart": (C.c_int, [vp]),
         "ss_session_lufs_history": (C.c_int, [vp, f64p]),
         "ss_batch_render_spectrum": (C.c_int, [vp, C.c_uint32, C.c_int, C.c_float]),

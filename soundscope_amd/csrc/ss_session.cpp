@@ -14,6 +14,13 @@ struct ss_session {
     uint32_t file_channels = 2, rate = 0;
     size_t n_samples = 0;               // file: interleaved samples; capture: 30 * rate
     DevBuf<float> pcm;                  // the file / the capture ring, resident
+    // capture, resident ring (ss_session_capture_push / ss_session_tick_capture_resident): what the capture callback has pushed
+    // since the last tick waits in page-locked memory; a tick shifts the ring by that much on the device (into pcm_alt, then the two
+    // swap) and uploads only the new samples
+    DevBuf<float> pcm_alt;
+    float *pending = nullptr;           // pinned, n_samples floats: the newest pushed samples, oldest first
+    size_t pending_n = 0;
+    std::vector<float> tail;            // host copy of the ring's newest 2 * SS_TICK_WINDOW samples (the crate's value checks)
     DevBuf<float> wave;                 // file open: [bins][2] of the whole-file chart (released behind it)
     hipEvent_t ev_tick = nullptr;       // behind a file tick's last result (the gating of the new sub-blocks runs after it)
     float *stage = nullptr;             // pinned: 2 * bin_stride floats (the two dB rows of a tick) | capture: [bins][2] chart floats
@@ -183,6 +190,7 @@ void ss_session_close(ss_session *s)
     if (s->stage) (void)hipHostFree(s->stage);
     if (s->stage_d) (void)hipHostFree(s->stage_d);
     if (s->row_flag) (void)hipHostFree(s->row_flag);
+    if (s->pending) (void)hipHostFree(s->pending);
     delete s;
 }
 
@@ -275,6 +283,8 @@ int ss_session_open_capture(uint32_t channels, uint32_t sample_rate, ss_session 
     int rc = session_common_init(s.get(), channels, sample_rate);
     if (rc) return rc;
     HIPCHK(s->pcm.alloc(s->n_samples));
+    HIPCHK(hipMemset(s->pcm.p, 0, s->n_samples * sizeof(float)));      // the reference's ring starts full of zeros (tui.rs:1783-1784)
+    s->tail.assign((size_t)2 * SS_TICK_WINDOW, 0.0f);
     size_t window, bins;
     waveform_shape(s->n_samples / 2, 15.0, &window, &bins);
     rc = session_stage(s.get(), (size_t)2 * s->bin_stride + 2 * bins);
@@ -467,26 +477,14 @@ int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side
     return SS_OK;
 }
 
-// analyze_microphone_input (tui.rs:1427-1480) on one snapshot of the capture ring
-int ss_session_tick_capture(ss_session *s, const float *latest, size_t n, double *mid_xy,
-                            double *side_xy, size_t cap_pairs, double *wave_xy,
-                            size_t wave_cap_pairs, size_t *wave_n, ss_tick_result *res)
+// analyze_microphone_input (tui.rs:1427-1480) on the ring resident in s->pcm; `newest`: the ring's newest 2 * SS_TICK_WINDOW
+// samples on the host (the crate's value checks run there while the device works)
+static int capture_tick_body(ss_session *s, const float *newest, double *mid_xy, double *side_xy, double *wave_xy,
+                             size_t *wave_n, size_t window, size_t bins, ss_tick_result *res)
 {
-    SS_ON_DEVICE(s);
-    if (wave_n) *wave_n = 0;
-    if (!s || s->is_file || !res || !mid_xy || !side_xy || !latest) return SS_ERR_INVALID_ARG;
-    if (n != s->n_samples) return SS_ERR_INVALID_ARG;
-    if (cap_pairs < s->bt->count || cap_pairs < 1) return SS_ERR_CAPACITY;
     ss_analyzer *h = s->an;
+    const size_t n = s->n_samples;
     const size_t pairs = n / 2;                                 // 15 * rate
-    size_t window, bins;
-    waveform_shape(pairs, 15.0, &window, &bins);
-    if (wave_xy && 2 * bins > wave_cap_pairs) return SS_ERR_CAPACITY;
-    std::memset(res, 0, sizeof *res);
-    res->fft_ran = 1; res->lufs_ran = 1; res->fed = 1;
-    // (one copy: the newest 16384 pairs first and the rest behind the tick launch — so that spectrum and loudness run while
-    // the host stages the chart's 5.6 MB — measured 219 against 199 us: a second pageable copy costs more than it hides)
-    HIPCHK(hipMemcpyAsync(s->pcm.p, latest, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
     const size_t lb = pairs - SS_TICK_WINDOW;
     const int lim = (20000.0f > (float)h->rate / 2.0f) ? SS_ERR_FREQ_LIMIT : SS_OK;
     // One launch for the spectrum of the newest 16384 pairs, the loudness call on the newest 16384 samples and the short-term
@@ -533,9 +531,9 @@ int ss_session_tick_capture(ss_session *s, const float *latest, size_t n, double
     if (res->add_status == SS_OK && h->prefetch_stamp != h->change_count) { int rc = prefetch_readings(h); if (rc) return rc; }
     // get_fft's value checks on the two 16384-sample slices (the device is working)
     std::vector<std::pair<size_t, uint8_t>> bad;
-    for (size_t i = lb; i < pairs; i++) {
-        const uint8_t c = pair_class(latest[2 * i], latest[2 * i + 1]);
-        if (c) bad.emplace_back(i, c);
+    for (size_t i = 0; i < (size_t)SS_TICK_WINDOW; i++) {
+        const uint8_t c = pair_class(newest[2 * i], newest[2 * i + 1]);
+        if (c) bad.emplace_back(lb + i, c);
     }
     int mid_st = window_value_status(s, lb, SS_TICK_WINDOW, 0, bad);
     int side_st = window_value_status(s, lb, SS_TICK_WINDOW, 2, bad);
@@ -556,6 +554,93 @@ int ss_session_tick_capture(ss_session *s, const float *latest, size_t n, double
     s->lufs[SS_LUFS_HISTORY - 1] = st_launched ? s->stage_d[1] : 0.0;
     res->shortterm = s->lufs[SS_LUFS_HISTORY - 1];
     return SS_OK;
+}
+
+
+static int capture_args(ss_session *s, double *mid_xy, double *side_xy, size_t cap_pairs, double *wave_xy, size_t wave_cap_pairs,
+                        size_t *wave_n, ss_tick_result *res, size_t *window, size_t *bins)
+{
+    if (wave_n) *wave_n = 0;
+    if (!s || s->is_file || !res || !mid_xy || !side_xy) return SS_ERR_INVALID_ARG;
+    if (cap_pairs < s->bt->count || cap_pairs < 1) return SS_ERR_CAPACITY;
+    waveform_shape(s->n_samples / 2, 15.0, window, bins);
+    if (wave_xy && 2 * *bins > wave_cap_pairs) return SS_ERR_CAPACITY;
+    std::memset(res, 0, sizeof *res);
+    res->fft_ran = 1; res->lufs_ran = 1; res->fed = 1;
+    return SS_OK;
+}
+
+// ... on one snapshot of the capture ring (latest_captured_samples.to_vec(), tui.rs:1428): the whole ring is uploaded
+int ss_session_tick_capture(ss_session *s, const float *latest, size_t n, double *mid_xy,
+                            double *side_xy, size_t cap_pairs, double *wave_xy,
+                            size_t wave_cap_pairs, size_t *wave_n, ss_tick_result *res)
+{
+    SS_ON_DEVICE(s);
+    size_t window, bins;
+    int rc = capture_args(s, mid_xy, side_xy, cap_pairs, wave_xy, wave_cap_pairs, wave_n, res, &window, &bins);
+    if (rc) return rc;
+    if (!latest || n != s->n_samples) return SS_ERR_INVALID_ARG;
+    // (one copy: the newest 16384 pairs first and the rest behind the tick launch — so that spectrum and loudness run while
+    // the host stages the chart's 5.6 MB — measured 219 against 199 us: a second pageable copy costs more than it hides)
+    HIPCHK(hipMemcpyAsync(s->pcm.p, latest, n * sizeof(float), hipMemcpyHostToDevice, s->an->stream));
+    s->pending_n = 0;                                            // (a snapshot supersedes whatever was pushed before it)
+    const float *newest = latest + (n - (size_t)2 * SS_TICK_WINDOW);
+    rc = capture_tick_body(s, newest, mid_xy, side_xy, wave_xy, wave_n, window, bins, res);
+    std::memcpy(s->tail.data(), newest, s->tail.size() * sizeof(float));
+    return rc;
+}
+
+// The capture callback's `audio_buf.extend(data)` (audio_capture.rs:41-52) for a ring that lives on the device: the samples are
+// kept (page-locked) until the next tick moves the ring.  Host work only; as with every call on a session, one caller at a time.
+int ss_session_capture_push(ss_session *s, const float *samples, size_t n)
+{
+    SS_ON_DEVICE(s);
+    if (!s || s->is_file || (!samples && n)) return SS_ERR_INVALID_ARG;
+    if (n == 0) return SS_OK;
+    const size_t N = s->n_samples;
+    if (!s->pending) HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->pending), N * sizeof(float), hipHostMallocDefault));
+    if (n >= N) {                                                // more than a whole ring at once: its newest N samples are the ring
+        std::memcpy(s->pending, samples + (n - N), N * sizeof(float));
+        s->pending_n = N;
+    } else {
+        if (s->pending_n + n > N) {                              // (no tick for 15 s: the oldest pushed samples have left the ring)
+            const size_t drop = s->pending_n + n - N;
+            std::memmove(s->pending, s->pending + drop, (s->pending_n - drop) * sizeof(float));
+            s->pending_n -= drop;
+        }
+        std::memcpy(s->pending + s->pending_n, samples, n * sizeof(float));
+        s->pending_n += n;
+    }
+    const size_t T = s->tail.size();
+    if (n >= T) std::memcpy(s->tail.data(), samples + (n - T), T * sizeof(float));
+    else {
+        std::memmove(s->tail.data(), s->tail.data() + n, (T - n) * sizeof(float));
+        std::memcpy(s->tail.data() + (T - n), samples, n * sizeof(float));
+    }
+    return SS_OK;
+}
+
+// analyze_microphone_input on the resident ring: what was pushed since the last tick moves the ring on the device (one device copy of
+// the part that stays, one DMA of the new samples) — no snapshot crosses PCIe
+int ss_session_tick_capture_resident(ss_session *s, double *mid_xy, double *side_xy, size_t cap_pairs, double *wave_xy,
+                                     size_t wave_cap_pairs, size_t *wave_n, ss_tick_result *res)
+{
+    SS_ON_DEVICE(s);
+    size_t window, bins;
+    int rc = capture_args(s, mid_xy, side_xy, cap_pairs, wave_xy, wave_cap_pairs, wave_n, res, &window, &bins);
+    if (rc) return rc;
+    const size_t N = s->n_samples, k = s->pending_n;
+    hipStream_t st = s->an->stream;
+    if (k >= N) {
+        HIPCHK(hipMemcpyAsync(s->pcm.p, s->pending, N * sizeof(float), hipMemcpyHostToDevice, st));
+    } else if (k) {
+        if (!s->pcm_alt.p) HIPCHK(s->pcm_alt.alloc(N));
+        HIPCHK(hipMemcpyAsync(s->pcm_alt.p, s->pcm.p + k, (N - k) * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(s->pcm_alt.p + (N - k), s->pending, k * sizeof(float), hipMemcpyHostToDevice, st));
+        s->pcm.swap(s->pcm_alt);
+    }
+    s->pending_n = 0;                                            // (the tick below waits for the stream: `pending` is free again)
+    return capture_tick_body(s, s->tail.data(), mid_xy, side_xy, wave_xy, wave_n, window, bins, res);
 }
 
 }  // extern "C"

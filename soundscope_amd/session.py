@@ -120,3 +120,19 @@ class CaptureSession(_Session):
         self._store(res)
         self.microphone_input_chart = self._wave[:n.value].copy()
         return res
+
+    def push(self, samples) -> None:
+        """The capture callback's `audio_buf.extend(data)` for a ring that lives on the device (host work only)."""
+        a, ap = _f32(samples)
+        _check(L.lib().ss_session_capture_push(self._s, ap, a.size))
+
+    def analyze_resident(self):
+        """One tick on the device-resident ring as it stands after every push so far (nothing but the new samples is uploaded)."""
+        res = L.TickResult()
+        n = C.c_size_t(0)
+        dp = C.POINTER(C.c_double)
+        _check(L.lib().ss_session_tick_capture_resident(self._s, self._mid.ctypes.data_as(dp), self._side.ctypes.data_as(dp), self._cap,
+                                                        self._wave.ctypes.data_as(dp), self._wave.shape[0], C.byref(n), C.byref(res)))
+        self._store(res)
+        self.microphone_input_chart = self._wave[:n.value].copy()
+        return res

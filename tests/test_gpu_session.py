@@ -242,3 +242,51 @@ def test_file_session_many_non_finite_pairs_and_empty_file(oracle):
         for key in ("fft_ran", "mid_status", "side_status", "lufs_ran", "fed", "add_status"):
             assert getattr(res, key) == ref[key], (pos, key, getattr(res, key), ref[key])
     sess.close()
+
+
+@pytest.mark.parametrize("rate,channels", [(48000, 2), (44100, 2), (48000, 1), (96000, 2)])
+def test_capture_ring_resident_on_the_device(oracle, rate, channels):
+    """The capture ring kept on the device: pushes of the sizes a capture callback delivers (and one longer than the whole ring, one
+    after a long pause without a tick), a tick after every few pushes — against the restated App on the ring the reference would
+    hold (zeros, then everything pushed, the oldest dropped), and against the snapshot form of the same tick."""
+    from oracle.app_driver import CaptureApp
+    rng = np.random.default_rng(5 + rate + channels)
+    n = 30 * rate
+    sess = ssa.CaptureSession(channels, rate)
+    snap = ssa.CaptureSession(channels, rate)
+    app = CaptureApp(channels, rate)
+    ring = np.zeros(n, np.float32)                          # the reference's ring: starts full of zeros (tui.rs:1783-1784)
+    src = make_stereo(9 + rate, 40 * rate, rate=rate, level=0.5)
+    at = 0
+
+    def push(k):
+        nonlocal ring, at
+        x = src[at:at + k]; at += k
+        sess.push(x)
+        ring = x[-n:].copy() if k >= n else np.concatenate([ring[k:], x])
+
+    plan = [[960, 960, 964], [4096], [2, 1022, 3000], [n + 1234], [512] * 5, [7 * rate, 9 * rate, 3 * rate], [480, 480]]
+    if rate == 96000: plan = plan[:5]
+    for pushes in plan:
+        for k in pushes: push(k)
+        res = sess.analyze_resident()
+        ref = app.analyze_microphone_input(ring)
+        res2 = snap.analyze_microphone_input(ring)
+        for key in ("mid_status", "side_status", "add_status", "shortterm_status"):
+            assert getattr(res, key) == ref[key] == getattr(res2, key), (key, getattr(res, key), ref[key])
+        assert np.array_equal(sess.microphone_input_chart, app.microphone_input_chart)       # bit-exact
+        assert np.array_equal(sess.microphone_input_chart, snap.microphone_input_chart)
+        assert np.array_equal(sess.mid_fft, snap.mid_fft) and np.array_equal(sess.side_fft, snap.side_fft)
+        assert db_close(sess.mid_fft[:, 1], app.mid_fft[:, 1], TOL_DB)
+        assert db_close(sess.side_fft[:, 1], app.side_fft[:, 1], TOL_DB)
+        assert lufs_close(res.shortterm, ref["shortterm"])
+        assert res.shortterm == res2.shortterm or abs(res.shortterm - res2.shortterm) <= 1e-9
+    assert np.allclose(sess.lufs, app.lufs, atol=TOL_DB)
+    # mixing the forms: a snapshot tick replaces the ring, pushes go on from there
+    other = make_stereo(77, 15 * rate, rate=rate, level=0.3)
+    sess.analyze_microphone_input(other); app.analyze_microphone_input(other); ring = other.copy()
+    push(2048)
+    res = sess.analyze_resident(); ref = app.analyze_microphone_input(ring)
+    assert np.array_equal(sess.microphone_input_chart, app.microphone_input_chart)
+    assert db_close(sess.mid_fft[:, 1], app.mid_fft[:, 1], TOL_DB)
+    assert lufs_close(res.shortterm, ref["shortterm"])

@@ -86,3 +86,15 @@ for k, pos in enumerate(range(16384 * 2 + 2048, x.size, 2048)):
     t_g.append(t1 - t0)
     if k > 200: break
 print("render-loop getters on the session's analyzer behind a tick:", f(t_g))
+# the capture tick on a ring that lives on the device: the callback pushes 1024 frames per tick, nothing else crosses PCIe
+cap2 = ssa.CaptureSession(2, rate)
+chunk = ring[:2048]
+t_cap = []
+for tick in range(120):
+    cap2.push(chunk)
+    t0 = time.perf_counter()
+    cap2.analyze_resident()
+    t1 = time.perf_counter()
+    if tick >= 20:
+        t_cap.append(t1 - t0)
+print("capture tick, ring resident on the device      :", f(t_cap))
