@@ -233,6 +233,30 @@ def reference_tick_workload(ssa, L, rate=48000, secs=12, cpu_ticks=60):
     out["file_open_ms"] = {"gpu_first": open_ms, "gpu_warm": open2_ms, "gpu_warm_each": [round(v, 2) for v in warm], "cpu_oracle": cpu_open_ms,
                            "seconds": secs}
     out["budget"] = "8 ms TUI loop + 21.3 ms between ticks at 48 kHz (SURVEY section 6)"
+    # the microphone mode: analyze_microphone_input (tui.rs:1427-1480) on the 30 * rate-sample capture ring — as a snapshot per tick
+    # (the reference's to_vec()), and with the ring kept on the device (the capture callback pushes 1024 frames per tick)
+    try:
+        ring = np.concatenate([x, x, x])[:30 * rate].copy()
+        cap = ssa.CaptureSession(2, rate)
+        t_snap, t_res = [], []
+        for k in range(50):
+            t0 = time.perf_counter(); cap.analyze_microphone_input(ring); t1 = time.perf_counter()
+            if k >= 10: t_snap.append((t1 - t0) * 1e6)
+            time.sleep(0.0003)
+        for k in range(110):
+            cap.push(x[2048 * k:2048 * (k + 1)])
+            t0 = time.perf_counter(); cap.analyze_resident(); t1 = time.perf_counter()
+            if k >= 10: t_res.append((t1 - t0) * 1e6)
+            time.sleep(0.0003)
+        capp = app_driver.CaptureApp(2, rate)
+        t_cpu = []
+        for k in range(6):
+            t0 = time.perf_counter(); capp.analyze_microphone_input(ring); t_cpu.append((time.perf_counter() - t0) * 1e6)
+        out["capture_tick_us"] = {"snapshot_per_tick": float(np.median(t_snap)), "ring_resident_on_device": float(np.median(t_res)),
+                                  "cpu_oracle": float(np.median(t_cpu[1:])), "snapshot_bytes": int(ring.nbytes)}
+        cap.close()
+    except Exception as ex:
+        out["capture_tick_us"] = {"error": repr(ex)}
     # the long file: receive_audio_file only (600 s = 57.6 M samples)
     try:
         long_s = 600
