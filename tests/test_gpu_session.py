@@ -290,3 +290,15 @@ def test_capture_ring_resident_on_the_device(oracle, rate, channels):
     assert np.array_equal(sess.microphone_input_chart, app.microphone_input_chart)
     assert db_close(sess.mid_fft[:, 1], app.mid_fft[:, 1], TOL_DB)
     assert lufs_close(res.shortterm, ref["shortterm"])
+
+
+@pytest.mark.parametrize("seed", [1, 5, 12, 33])
+def test_randomised_capture_programme_against_the_restated_app(oracle, seed):
+    """tools/fuzz_capture.py's programmes (a device-resident ring fed by pushes of random sizes, snapshot ticks, restarts, NaNs)."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_capture", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_capture.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    r = mod.programme(seed)
+    assert r is None, r
