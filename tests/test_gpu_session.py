@@ -302,3 +302,30 @@ def test_randomised_capture_programme_against_the_restated_app(oracle, seed):
     spec.loader.exec_module(mod)
     r = mod.programme(seed)
     assert r is None, r
+
+
+def test_two_sessions_ticking_from_two_threads():
+    """Two file sessions driven from two threads at once (ctypes releases the GIL during the calls): each reproduces, bit for bit,
+    the readings it gives when it runs alone — the table caches, the stream pool and the kernels' one-time set-up are shared."""
+    import threading
+    rate = 48000
+    files = [make_stereo(100 + i, rate * 6, rate=rate, level=0.3 + 0.2 * i) for i in range(2)]
+    positions = list(range(16384 * 2 + 2048, files[0].size, 2048))
+
+    def run(x, out):
+        sess = ssa.FileSession(x, 2, rate)
+        for pos in positions:
+            res = sess.analyze_audio_file_samples(pos)
+            out.append((res.shortterm, float(sess.mid_fft[:, 1].sum()), float(sess.side_fft[:, 1].sum())))
+        out.append((sess.analyzer.get_integrated_lufs(),) + tuple(sess.analyzer.get_true_peak()))
+        sess.close()
+
+    alone = [[], []]
+    for i in range(2): run(files[i], alone[i])
+    both = [[], []]
+    th = [threading.Thread(target=run, args=(files[i], both[i])) for i in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for i in range(2):
+        assert len(both[i]) == len(alone[i])
+        assert both[i] == alone[i], next((k, a, b) for k, (a, b) in enumerate(zip(alone[i], both[i])) if a != b)
