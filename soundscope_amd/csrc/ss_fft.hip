@@ -586,7 +586,11 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
     __shared__ __attribute__((aligned(16))) uint32_t xlev[4][2];
     // 8192 B: db_offset + pink per retained bin (n_bins <= 2047 at N = 4096).  Columns-only mode (COLS) uses the room for the
     // bins' chart columns (u16 each) and the two rows' column accumulators instead, and reads the table from global memory.
+#ifdef SS_MS1_NO_LDS_TABLE      // experiment (review item 6): no table in LDS, so that FOUR workgroups fit a CU (with -DSS_FFT1_WAVES=4)
+    __shared__ __attribute__((aligned(16))) float offp[COLS ? 2048 : 4];
+#else
     __shared__ __attribute__((aligned(16))) float offp[2048];
+#endif
     uint16_t *bincol = reinterpret_cast<uint16_t *>(offp);                //  4096 B
     uint32_t *colbuf = reinterpret_cast<uint32_t *>(offp) + 1024;         //  4096 B: [mid, side][cols <= 512]
 #define X1W(ka, tb_, ta_) ((ka) * kPlaneB + (tb_) * kRowB + (ta_))
@@ -621,8 +625,10 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
             reinterpret_cast<uint2 *>(bincol)[g] = reinterpret_cast<const uint2 *>(p.bin_col)[g];
         for (uint32_t c = (uint32_t)t; c < 2u * p.cols; c += 256u) colbuf[c] = 0xFFFFFFFFu;
     } else {
+#ifndef SS_MS1_NO_LDS_TABLE
         for (uint32_t g = (uint32_t)t; 4u * g < p.bin_stride; g += 256u)
             reinterpret_cast<float4 *>(offp)[g] = reinterpret_cast<const float4 *>(p.offpink)[g];
+#endif
     }
     // columns-only mode: gain of this stream, and where a finished window's columns go (flushed one window late, behind the
     // loop-end barrier that closes its epilogue's atomics, by the threads that idle least: all of them, one column pair each)
@@ -825,7 +831,11 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
         }
         float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
         if (COLS) fft4096_epilogue<false, true>(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, nullptr, nullptr, true, colbuf, bincol, p.cols, cgain, soff);
+#ifdef SS_MS1_NO_LDS_TABLE
+        else fft4096_epilogue<false>(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride, true, nullptr, nullptr, 0, 0.0f, soff);
+#else
         else fft4096_epilogue<true>(xbuf, t, p.first_bin, p.n_bins, p.db_offset, offp, o_mid, o_mid + p.bin_stride, true, nullptr, nullptr, 0, 0.0f, soff);
+#endif
         if (__builtin_expect(zrow_m || zrow_d, 0)) {
             if (!COLS) fft4096_floor_rows(t, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride, zrow_m, zrow_d);
             else fft4096_floor_columns(t, p.n_bins, p.db_offset, p.offpink, colbuf, bincol, p.cols, cgain, zrow_m, zrow_d);
