@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 1
+/* 2: ss_add_samples returns behind its launch (a device fault surfaces at the next getter), ss_get_fft_error_values,
+ *    ss_batch_get_true_peak_arith; the batch true peak defaults to SS_TP_ARITH_F32 */
+#define SS_ABI_VERSION 2
 
 typedef enum ss_status {
     SS_OK = 0,
@@ -146,6 +148,9 @@ int ss_get_sample_peak_channel(ss_analyzer *h, uint32_t channel, double *out);
  * off); 2 or 4 = forced (BASELINE config 5 asks for 4x at 96 kHz).  Takes
  * effect at the next ss_analyzer_configure or ss_reset (both start a fresh meter). */
 int ss_analyzer_set_true_peak_factor(ss_analyzer *h, int factor);
+/* arithmetic of the handle's 4x true-peak interpolator: SS_TP_ARITH_F32 (default, ebur128's width) or SS_TP_ARITH_F16X3
+ * (see ss_batch_set_true_peak_arith below); takes effect with the next ss_add_samples / session tick. */
+int ss_analyzer_set_true_peak_arith(ss_analyzer *h, int arith);
 /* inspection (tests): the K-weighting filter's carried DF-II state v1..v4 of one channel, as ebur128's Filter keeps it
  * between add_frames calls — sub-normal values flushed to zero at the end of every internal filter call like the crate
  * does.  Waits for the handle's stream. */
@@ -312,14 +317,17 @@ int ss_batch_geometry_get(const ss_batch *b, ss_batch_geometry *out);
  *      latency-bound tail (per-stream gating / histograms, a standalone decimation).
  * Per-kernel event timing (ss_batch_timing_enable) always runs sequentially. */
 int ss_batch_set_overlap(ss_batch *b, int mode);
-/* arithmetic of the 4x true-peak interpolator in batches (2 / 8 channels; other shapes always take SS_TP_ARITH_F32):
- *   SS_TP_ARITH_F16X3 (default)  three-term f16 split on the matrix cores with f32 accumulation, scaled per tile by a
+/* arithmetic of the 4x true-peak interpolator in batches (the Analyzer handle and the sessions: ss_analyzer_set_true_peak_arith, same default):
+ *   SS_TP_ARITH_F32 (default)    v_mfma_f32_16x16x4_f32: an f32 fmaf chain per output, the width of ebur128's interpolator
+ *                                (its 12 products per phase summed in f32; analyzer.rs:139-141,159-164);
+ *   SS_TP_ARITH_F16X3 (opt-in)   three-term f16 split on the matrix cores with f32 accumulation, scaled per tile by a
  *                                power of two from the tile's own peak: within 2^-21 of the tile peak of the f32 result
- *                                (measured 1.4e-7 relative on the bench corpus; north_star's bar is 1e-4);
- *   SS_TP_ARITH_F32              v_mfma_f32_16x16x4_f32: an f32 fmaf chain per output, the width of ebur128's interpolator
- *                                (its 12 products per phase summed in f32), ~25 % more time-domain kernel time. */
+ *                                (measured 2.0e-7 relative on the bench corpus against 1.1e-7 for the f32 product; north_star's
+ *                                bar is 1e-4), ~25 % less time-domain kernel time.  2 / 8 channels only: other shapes, and
+ *                                tiles with non-finite samples, take the f32 product whatever the mode. */
 enum { SS_TP_ARITH_F16X3 = 0, SS_TP_ARITH_F32 = 1 };
 int ss_batch_set_true_peak_arith(ss_batch *b, int arith);
+int ss_batch_get_true_peak_arith(const ss_batch *b);      /* SS_TP_ARITH_* */
 /* verification utility: order-independent 64-bit checksums, computed on the device, of everything a pass left in HBM for
  * each stream: out[3 * s + 0] the stream's whole spectrum block ([n_windows][fft_channels][fft_bin_stride] f32 bit patterns),
  * out[3 * s + 1] its decimation bins, out[3 * s + 2] its sub-block energies (f64 bit patterns).  Two passes agree on a

@@ -33,7 +33,11 @@ extern "C" {
     fn ss_get_sample_peak_channel(h: *mut SsAnalyzer, channel: u32, out: *mut c_double) -> c_int;
     fn ss_analyzer_set_true_peak_factor(h: *mut SsAnalyzer, factor: c_int) -> c_int;
     fn ss_status_string(status: c_int) -> *const c_char;
+    fn ss_abi_version() -> c_int;
 }
+
+/// `SS_ABI_VERSION` of include/soundscope_hip.h this shim was written against (checked once, in `Default`).
+const SS_ABI_VERSION: c_int = 2;
 
 fn ebu_err(rc: c_int) -> ebur128::Error {
     match rc { 2 => ebur128::Error::InvalidMode, 3 => ebur128::Error::InvalidChannelIndex, _ => ebur128::Error::NoMem }
@@ -62,6 +66,8 @@ unsafe impl Send for Analyzer {}
 
 impl Default for Analyzer {
     fn default() -> Self {
+        let abi = unsafe { ss_abi_version() };
+        if abi != SS_ABI_VERSION { panic!("libsoundscope_hip.so has ABI version {abi}, this shim needs {SS_ABI_VERSION}"); }
         let mut h = std::ptr::null_mut();
         let rc = unsafe { ss_analyzer_create(2, 44100, &mut h) };
         if rc != 0 { panic!("Failed to create loudness meter: status {rc}"); }

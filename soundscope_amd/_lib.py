@@ -21,7 +21,7 @@ SYMBOLS = [
     "ss_add_samples", "ss_reset", "ss_get_shortterm_lufs", "ss_get_integrated_lufs", "ss_get_loudness_range",
     "ss_get_true_peak", "ss_sample_rate", "ss_calculate_integrated_lufs", "ss_mid_side",
     "ss_get_momentary_lufs", "ss_get_true_peak_channel", "ss_get_sample_peak_channel",
-    "ss_analyzer_set_true_peak_factor",
+    "ss_analyzer_set_true_peak_factor", "ss_analyzer_set_true_peak_arith",
     "ss_batch_create", "ss_batch_destroy", "ss_batch_layout_get", "ss_batch_upload", "ss_batch_download_input",
     "ss_batch_input_device_ptr", "ss_batch_synthesize", "ss_batch_run", "ss_batch_sync", "ss_batch_results",
     "ss_batch_download_fft", "ss_batch_bin_tables", "ss_batch_download_waveform", "ss_batch_download_subblocks",
@@ -40,10 +40,11 @@ SYMBOLS = [
     "ss_comm_init", "ss_comm_init_from_env", "ss_comm_destroy", "ss_comm_rank", "ss_comm_size",
     "ss_comm_transport_name", "ss_comm_library_version", "ss_comm_barrier", "ss_comm_allreduce_u64_sum", "ss_comm_allreduce_f64_max",
     "ss_batch_allreduce_histograms", "ss_batch_traffic_floor",
-    "ss_batch_corpus_gate_enqueue", "ss_batch_corpus_gate_read", "ss_batch_checksums", "ss_inspect_filter_state", "ss_batch_set_true_peak_arith", "ss_batch_set_columns_gain",
+    "ss_batch_corpus_gate_enqueue", "ss_batch_corpus_gate_read", "ss_batch_checksums", "ss_inspect_filter_state", "ss_batch_set_true_peak_arith", "ss_batch_get_true_peak_arith", "ss_batch_set_columns_gain",
     "ss_inspect_kweight", "ss_inspect_true_peak", "ss_inspect_hann", "ss_inspect_bins", "ss_inspect_histogram",
 ]
 
+SS_ABI_VERSION = 2          # include/soundscope_hip.h; checked at load
 SS_OK = 0
 SS_ERR_NOMEM, SS_ERR_INVALID_MODE, SS_ERR_INVALID_CHANNEL = 1, 2, 3
 SS_ERR_TOO_FEW_SAMPLES, SS_ERR_NAN, SS_ERR_INFINITY, SS_ERR_NOT_POW2, SS_ERR_FREQ_LIMIT, SS_ERR_SCALING = 10, 11, 12, 13, 14, 15
@@ -210,6 +211,8 @@ def _bind(lib):
         "ss_batch_checksums": (C.c_int, [vp, u64p, C.c_uint32]),
         "ss_inspect_filter_state": (C.c_int, [vp, C.c_uint32, f64p]),
         "ss_batch_set_true_peak_arith": (C.c_int, [vp, C.c_int]),
+        "ss_analyzer_set_true_peak_arith": (C.c_int, [vp, C.c_int]),
+        "ss_batch_get_true_peak_arith": (C.c_int, [vp]),
         "ss_batch_set_columns_gain": (C.c_int, [vp, C.c_int, C.c_float]),
         "ss_inspect_kweight": (C.c_int, [C.c_uint32, f64p, f64p]),
         "ss_inspect_true_peak": (C.c_int, [C.c_int, f32p, C.c_uint32, C.POINTER(C.c_uint32)]),
@@ -241,5 +244,10 @@ def lib():
                 f"{LIB_PATH} is missing: the HIP extension has not been built "
                 "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C soundscope_amd/csrc`). "
                 "soundscope_amd has no CPU fallback.")
-        _LIB = _bind(C.CDLL(LIB_PATH))
+        cand = _bind(C.CDLL(LIB_PATH))
+        got = cand.ss_abi_version()
+        if got != SS_ABI_VERSION:
+            raise ImportError(f"{LIB_PATH} reports ABI version {got}, this binding was written for {SS_ABI_VERSION}: rebuild "
+                              "(make -C soundscope_amd/csrc)")
+        _LIB = cand
     return _LIB

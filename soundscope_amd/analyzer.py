@@ -159,6 +159,10 @@ class Analyzer:
     def set_true_peak_factor(self, factor: int) -> None:
         _check(L.lib().ss_analyzer_set_true_peak_factor(self._h, factor))
 
+    def set_true_peak_arith(self, arith: int) -> None:
+        """L.SS_TP_ARITH_F32 (default, the width of ebur128's interpolator) or L.SS_TP_ARITH_F16X3 (opt-in f16x3 split)."""
+        _check(L.lib().ss_analyzer_set_true_peak_arith(self._h, arith))
+
     # -- analyzer.rs:166-168
     def sample_rate(self) -> int:
         return L.lib().ss_sample_rate(self._h)

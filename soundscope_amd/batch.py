@@ -108,8 +108,13 @@ class Batch:
         _check(L.lib().ss_batch_set_overlap(self._h, int(mode)))
 
     def set_true_peak_arith(self, arith):
-        """L.SS_TP_ARITH_F16X3 (default: f16x3 split on the matrix cores) or L.SS_TP_ARITH_F32 (f32 MFMA, the crate's width)."""
+        """L.SS_TP_ARITH_F32 (default: f32 MFMA, the width of the crate's interpolator) or L.SS_TP_ARITH_F16X3 (opt-in: f16x3
+        split on the matrix cores, within 2^-21 of the tile peak of the f32 result, faster)."""
         _check(L.lib().ss_batch_set_true_peak_arith(self._h, int(arith)))
+
+    @property
+    def true_peak_arith(self):
+        return int(L.lib().ss_batch_get_true_peak_arith(self._h))
 
     def allreduce_histograms(self, comm):
         """The corpus gate's exchange: in-place SUM all-reduce of this batch's corpus histograms over `comm`

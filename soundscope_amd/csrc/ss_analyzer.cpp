@@ -198,6 +198,13 @@ int ss_analyzer_set_true_peak_factor(ss_analyzer *h, int factor)
     return SS_OK;
 }
 
+int ss_analyzer_set_true_peak_arith(ss_analyzer *h, int arith)
+{
+    if (!h || (arith != SS_TP_ARITH_F16X3 && arith != SS_TP_ARITH_F32)) return SS_ERR_INVALID_ARG;
+    h->tp_arith = arith;                          // read by the next ss_add_samples / tick (a launch parameter, no state behind it)
+    return SS_OK;
+}
+
 int ss_get_fft(const ss_analyzer *hc, const float *samples, size_t n,
                double *out_xy, size_t cap_pairs, size_t *out_n)
 {
@@ -443,6 +450,7 @@ int ssh::add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool o
         p.subblocks = h->sub.p; p.sub_stride = 0; p.sub_cap = ss_analyzer::kSubCap;
         p.ring = h->ring.p; p.ring_frames = h->ring_frames; p.tp_factor = h->tp_factor;
         p.s100 = (uint32_t)S; p.nseg = 1; p.seg_sub = 0; p.warm_sub = 0;
+        p.tp_f32 = h->tp_arith == SS_TP_ARITH_F32 ? 1u : 0u;           // default: ebur128's f32 interpolator width (the handle IS the reference's Analyzer)
         const bool with_tick = tick && tick->fft && on_device && take == frames;
         const uint64_t st_frames = S * 30;                              // the short-term window (3 s)
         if (with_tick && tick->shortterm_out && take <= st_frames && st_frames <= h->ring_frames &&

@@ -53,7 +53,7 @@ struct ss_batch {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool corpus_reduced = false;      // this pass's corpus histograms already hold the all-reduced sums
-    int tp_arith = 0;                 // SS_TP_ARITH_*
+    int tp_arith = SS_TP_ARITH_F32;   // SS_TP_ARITH_*: the reference's width unless the caller opts into the f16 split
     int overlap = 0;                  // 0 sequential, 1 the spectrum kernel beside the time-domain chain, 2 beside its tail only
     bool timing = false;
     hipEvent_t ev[2 * SS_KERNEL_COUNT] = {};
@@ -772,6 +772,8 @@ int ss_batch_set_true_peak_arith(ss_batch *b, int arith)
     b->tp_arith = arith;
     return SS_OK;
 }
+
+int ss_batch_get_true_peak_arith(const ss_batch *b) { return b ? b->tp_arith : SS_ERR_INVALID_ARG; }
 
 int ss_batch_download_fft(ss_batch *b, uint32_t stream, float *out, size_t cap)
 {

@@ -169,6 +169,7 @@ struct ss_analyzer {
     uint32_t meter_rate = 0;   // the rate the current meter was built for (rate sticks on a failed configure, the meter does not change)
     int tp_cfg = 0;            // 0 = crate rule
     int tp_factor = 0;         // effective
+    int tp_arith = SS_TP_ARITH_F32;   // ss_analyzer_set_true_peak_arith
     int tp_cfg_applied = 0;    // the tp_cfg the current meter was built with
     bool meter_ok = false;
     hipStream_t stream = nullptr;

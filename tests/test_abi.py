@@ -32,7 +32,7 @@ def test_python_binding_covers_header():
 
 def test_abi_version_and_status_strings():
     lib = L.lib()
-    assert lib.ss_abi_version() == 1
+    assert lib.ss_abi_version() == 2 == L.SS_ABI_VERSION
     assert lib.ss_status_string(0) == b"ok"
     assert b"NotAPowerOfTwo" in lib.ss_status_string(L.SS_ERR_NOT_POW2)
 
@@ -91,7 +91,7 @@ def test_c99_batch_client_links_and_fails_loudly_without_device(tmp_path):
     """The batch / corpus-gate client (tests/cabi/cabi_batch.c) compiles as strict C99 against the header, links against
     the in-tree library, and without a GPU `ss_batch_create` returns SS_ERR_DEVICE."""
     kv = build_c_client(tmp_path, "cabi_batch")
-    assert kv["abi"] == "1" and kv["sizeof_cfg"] == "48" and kv["sizeof_result"] == "56"
+    assert kv["abi"] == "2" and kv["sizeof_cfg"] == "48" and kv["sizeof_result"] == "56"
     if int(kv["devices"]) == 0:
         assert int(kv["create"]) == L.SS_ERR_DEVICE
 
@@ -100,6 +100,6 @@ def test_c99_client_links_and_fails_loudly_without_device(tmp_path):
     """The header is valid C99, every symbol the client uses resolves, and without a GPU the first compute
     entry point returns SS_ERR_DEVICE (no CPU fallback)."""
     kv = build_c_client(tmp_path)
-    assert kv["abi"] == "1" and kv["sizeof_tick"] == "56"
+    assert kv["abi"] == "2" and kv["sizeof_tick"] == "56"
     if int(kv["devices"]) == 0:
         assert int(kv["open"]) == L.SS_ERR_DEVICE

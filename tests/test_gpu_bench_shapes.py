@@ -33,8 +33,11 @@ def _threads():
     return max(1, min(64, len(os.sched_getaffinity(0))))
 
 
-@pytest.mark.parametrize("overlap", [0, 1, 2])
-def test_config3_bench_geometry_matches_oracle(oracle, overlap):
+F32, F16X3 = L.SS_TP_ARITH_F32, L.SS_TP_ARITH_F16X3
+
+
+@pytest.mark.parametrize("overlap,arith", [(0, None), (1, None), (2, None), (0, F32), (0, F16X3)])
+def test_config3_bench_geometry_matches_oracle(oracle, overlap, arith):
     """BASELINE config 3 exactly as bench.py runs it: 1024 synthetic streams x 10 s x 48 kHz stereo, N = 4096,
     hop 1024.  The geometry the shape selects (116 windows per spectrum workgroup, 4 time segments per stream with a
     run-in) is asserted, then eight streams — first, last and the ones either side of every quarter — are compared in
@@ -90,8 +93,8 @@ def test_config3_bench_geometry_matches_oracle(oracle, overlap):
         assert lufs_close(res[i].integrated_lufs, hs[i][2]), i
 
 
-@pytest.mark.parametrize("tp_factor,overlap", [(4, 0), (0, 0), (4, 1), (4, 2)])
-def test_config5_bench_shape_all_channels(oracle, tp_factor, overlap):
+@pytest.mark.parametrize("tp_factor,overlap,arith", [(4, 0, None), (0, 0, None), (4, 1, None), (4, 2, None), (4, 0, F32), (0, 0, F32), (4, 0, F16X3)])
+def test_config5_bench_shape_all_channels(oracle, tp_factor, overlap, arith):
     """BASELINE config 5 as bench.py times it: 64 streams x 10 s x 96 kHz x 8 channels, N = 16384 per channel at hop
     1024, true peak forced to 4x (the benchmark) and at the crate's rule (2x at 96 kHz).  Four streams are checked in
     full on the meter side (LUFS, LRA, all EIGHT channels' true and sample peaks through ss_batch_peaks) and on a
@@ -100,6 +103,9 @@ def test_config5_bench_shape_all_channels(oracle, tp_factor, overlap):
     b = ssa.Batch(rate, ch, ns, frames, 16384, 1024, flags=L.SS_BATCH_ALL, true_peak_factor=tp_factor)
     b.synthesize(0x5EED0000, 0)
     b.set_overlap(overlap)                                      # the 16384-point run kernel beside the 8-channel time-domain kernel
+    if arith is not None:                                       # None: the default = SS_TP_ARITH_F32 (the 8-channel f32 tile path)
+        b.set_true_peak_arith(arith)
+    assert b.true_peak_arith == (F32 if arith is None else arith)
     b.run(); b.sync()
     g, lay = b.geometry, b.layout
     assert (lay.n_windows, lay.fft_channels, lay.n_bins) == (921, 8, 3410)
@@ -153,9 +159,10 @@ def test_batch_peaks_api(oracle):
     assert L.lib().ss_batch_peaks(b2._h, 0, buf, None, 8) == L.SS_ERR_INVALID_MODE
 
 
+@pytest.mark.parametrize("arith", [F32, F16X3])
 @pytest.mark.parametrize("peak", [1e-5, 1e-6, 1e-7, 2.0 ** -23, 3e-9, 0.0])
-def test_true_peak_quiet_streams(oracle, peak):
-    """The f16-split true-peak product scales every tile by a power of two taken from its own sample peak, so its
+def test_true_peak_quiet_streams(oracle, peak, arith):
+    """Both true-peak arithmetics (the default f32 product and the opt-in f16 split) at very low levels.  The f16-split true-peak product scales every tile by a power of two taken from its own sample peak, so its
     relative accuracy does not depend on level: streams peaking at -100, -120, -140 dBFS, at one LSB of 24-bit PCM,
     far below that, and digital silence all stay within 1e-4 of the oracle (a fixed x256 scale lost this below
     about -120 dBFS, where the low f16 halves went sub-normal)."""
@@ -166,6 +173,7 @@ def test_true_peak_quiet_streams(oracle, peak):
     # second stream: the same quiet programme with one loud burst, so tiles of very different scale sit side by side
     y = x.copy()
     y[2 * 20000:2 * 20400] = base[2 * 20000:2 * 20400] * np.float32(0.9)
+    b.set_true_peak_arith(arith)
     b.upload(0, np.concatenate([x, y])); b.run(); b.sync()
     res = b.results()
     for i, s in enumerate((x, y)):
@@ -176,6 +184,7 @@ def test_true_peak_quiet_streams(oracle, peak):
             assert res[i].sample_peak[c] == m.sample_peak(c)
     # streaming handle, 16384-sample slices (the tick driver's feed)
     an = ssa.Analyzer(); an.create_loudness_meter(2, rate)
+    an.set_true_peak_arith(arith)
     m = oracle.Meter(2, rate)
     for off in range(0, y.size - 16384, 16384):
         an.add_samples(y[off:off + 16384]); m.add_frames(y[off:off + 16384])

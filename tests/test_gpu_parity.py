@@ -746,8 +746,9 @@ def test_batch_flag_subsets_agree_with_full_run(flags):
             assert list(rp[s].true_peak) == list(rf[s].true_peak) and list(rp[s].sample_peak) == list(rf[s].sample_peak)
 
 
-def test_true_peak_f16_path_guards(oracle):
-    """The 4x true peak runs as an f16-split matrix product (256 x = hi + lo) where that is safe and falls back to the
+@pytest.mark.parametrize("arith", [L.SS_TP_ARITH_F16X3, L.SS_TP_ARITH_F32])
+def test_true_peak_f16_path_guards(oracle, arith):
+    """(Both arithmetics; the guards matter in the opt-in f16 mode.)  There the 4x true peak runs as an f16-split matrix product (256 x = hi + lo) where that is safe and falls back to the
     f32 product around anything beyond +-128 full scale.  Quiet streams, huge isolated samples next to tile
     boundaries (tiles are 960 frames at 48 kHz) and uniformly huge streams all stay within 1e-4 of the oracle."""
     rate, frames = 48000, 48000 * 3
@@ -759,6 +760,7 @@ def test_true_peak_f16_path_guards(oracle):
     huge = (base * np.float32(400.0)).astype(np.float32)
     xs = [quiet, spikes, huge, base]
     b = ssa.Batch(rate, 2, len(xs), frames, 4096, 1024, flags=L.SS_BATCH_LUFS | L.SS_BATCH_TRUE_PEAK)
+    b.set_true_peak_arith(arith)
     b.upload(0, np.concatenate(xs)); b.run(); b.sync()
     res = b.results()
     for i, x in enumerate(xs):
@@ -768,6 +770,7 @@ def test_true_peak_f16_path_guards(oracle):
             assert res[i].sample_peak[c] == m.sample_peak(c)
     # the streaming handle: slices of every size, the spike stream
     an = ssa.Analyzer(); an.create_loudness_meter(2, rate)
+    an.set_true_peak_arith(arith)
     m = oracle.Meter(2, rate)
     off = 0
     for n in (2 * 959, 2, 2 * 7, 16384, 2 * 4800, 2 * 33, 16384, 16384, 2 * 20000):

@@ -96,6 +96,14 @@ def test_shim_keeps_the_reference_api():
     assert "ss_analyzer_create(2, 44100" in src                    # Analyzer::default(): 2 channels, 44.1 kHz (analyzer.rs:34-45)
 
 
+def test_shim_checks_the_abi_version_of_the_header():
+    src = open(SHIM).read()
+    m = re.search(r"const SS_ABI_VERSION: c_int = (\d+);", src)
+    hv = re.search(r"#define SS_ABI_VERSION (\d+)", open(HEADER).read())
+    assert m and hv and m.group(1) == hv.group(1) == str(L.SS_ABI_VERSION)
+    assert "ss_abi_version()" in src and "abi != SS_ABI_VERSION" in src
+
+
 def test_get_fft_errors_map_to_the_crate_variants():
     """status 10..15 of ss_get_fft become the SpectrumAnalyzerError variants the reference's `?`
     would have produced (analyzer.rs:60-65), so the text the TUI prints (tui.rs:1439-1442) is the crate's own.  The header's
