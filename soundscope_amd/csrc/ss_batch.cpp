@@ -49,6 +49,9 @@ struct ss_batch {
     int columns_gain_mode = SS_GAIN_FIXED;
     float columns_gain_db = 0.0f;
     DevBuf<uint16_t> bin_col;       // chart column of every retained bin (0xFFFF for the row padding)
+    DevBuf<uint2> col_groups;       // the same per group of four bins (FftBatchParams::col_groups)
+    DevBuf<float> col_init;         // FftBatchParams::col_init
+    DevBuf<uint2> col_bins;         // FftBatchParams::col_bins
     // opt-in (SS_BATCH_OVERLAP=1): the spectrum kernel on a second stream beside the time-domain chain
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -176,6 +179,26 @@ int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
             std::vector<uint16_t> bc(L.fft_bin_stride, (uint16_t)0xFFFF);
             for (uint32_t i = 0; i < L.n_bins; i++) bc[i] = (uint16_t)spectrum_column_of(b->bt->chart_x[i], cols);
             HIPCHK(b->bin_col.upload(bc));
+            std::vector<uint2> cg(L.fft_bin_stride / 4), cbins(L.fft_bin_stride / 4);
+            std::vector<float> cinit(cols, std::numeric_limits<float>::quiet_NaN());
+            for (uint32_t i = 0; i < L.n_bins; i++) cinit[bc[i]] = -std::numeric_limits<float>::infinity();
+            for (uint32_t g = 0; g < cg.size(); g++) {
+                uint32_t o[4];
+                bool general = false;
+                for (uint32_t e = 0; e < 4; e++) {
+                    const bool pad = bc[4 * g + e] == 0xFFFF;
+                    o[e] = pad ? 2048u : 4u * bc[4 * g + e];
+                    general = general || pad;
+                }
+                uint32_t n = 1;
+                while (n < 4 && o[n] == o[0]) n++;
+                for (uint32_t e = n; e < 4; e++) general = general || o[e] != o[3];
+                cg[g] = make_uint2(o[0] | (o[3] << 16), n | (general ? 0x100u : 0u));
+                cbins[g] = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+            }
+            HIPCHK(b->col_bins.upload(cbins));
+            HIPCHK(b->col_init.upload(cinit));
+            HIPCHK(b->col_groups.upload(cg));
             const uint64_t rows = (uint64_t)cfg->n_streams * L.n_windows * L.fft_channels;
             HIPCHK(b->render_spec.alloc(rows * cols));
             b->render_cols = cols;
@@ -507,7 +530,7 @@ int ss_batch_run(ss_batch *b)
         p.windows_per_block = b->windows_per_block;
         p.windows_of = b->ragged ? b->windows_d.p : nullptr;
         if (b->columns_only) {
-            p.out_cols = b->render_spec.p; p.bin_col = b->bin_col.p; p.cols = b->render_cols;
+            p.out_cols = b->render_spec.p; p.bin_col = b->bin_col.p; p.col_groups = b->col_groups.p; p.col_init = b->col_init.p; p.col_bins = b->col_bins.p; p.cols = b->render_cols;
             p.integrated = b->columns_gain_mode == SS_GAIN_REFERENCE ? b->integrated.p : nullptr;
             p.gain_db = b->columns_gain_db;
         }

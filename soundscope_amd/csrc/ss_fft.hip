@@ -71,18 +71,34 @@ constexpr int kPlaneB = 16 * kRowB;
 // LDS_TABLE: `offpink` is the workgroup's LDS copy of the table (k_fft4096_ms1 / k_fft4096_pairw stage it once per run of
 // windows): the rows are read right where they are used instead of being requested from global memory a whole epilogue
 // ahead (eight registers held across it, and as many vector-memory requests per window as the samples themselves).
-// COLS: nothing is stored — every dB value is gained, clamped to the chart's [-100, 0] dB and folded into its chart column
-// in LDS (tui.rs:49-51, :801-821; the column rule is the library's, include/soundscope_hip.h).  A value v <= 0 travels as
-// the bit pattern of 0 - v, which orders like an unsigned integer, so "max v" is one ds_min_u32 per run of bins that share
-// a column (a lane's four consecutive bins usually do); colbuf[row * cols + c] starts at 0xFFFFFFFF = "no bin" = NaN.
+// COLS: nothing is stored — every dB value is folded into its chart column in LDS (tui.rs:49-51, :801-821; the column rule is
+// the library's, include/soundscope_hip.h).  The accumulators hold plain dB values: the gain and the chart's [-100, 0] clamp
+// are monotone, so they commute with the maximum and are applied ONCE per column when a window's columns are flushed —
+// max(clamp(v + gain)) == clamp(max(v) + gain) to the bit.  Folding is an LDS float atomic (ds_max_f32, which ignores a NaN
+// operand like IEEE maxNum) at a byte offset from a host-built table — no per-bin branch, key conversion or clamp in the vector
+// ALU, which is what bounds this kernel (the divergent per-bin ds_min_u32 form of rounds 3-4: 3.30 ms; this one 3.00).
+//   * Chart columns are monotone in the bin index and, above the lowest few dozen bins, at least four bins wide: a lane's four
+//     consecutive bins lie in ONE column or straddle one boundary.  coltab[g] = (o0 | o3 << 16, n | general << 8): the offsets
+//     of the first and the last bin's column and the number n of bins in the first.  The two run maxima are taken in registers
+//     (five selects, three maxima per row) and one atomic per row goes out — two where the group straddles.  One atomic per BIN
+//     and no arithmetic at all (SS_COLS_FOLD 0) was measured: 3.86 ms — the sixteen-odd lanes that share a wide column queue on
+//     one LDS address (SQ_LDS_BANK_CONFLICT 40 % of the LDS cycles), profiles/r05_ab_columns.txt.
+//   * Groups the two-run form cannot express (three or four columns inside the group: the lowest bins; the row padding in the
+//     last group, whose offsets point at a spare slot) carry general = 1 and fold bin by bin from colbins — a wave-uniform branch.
+//   * An accumulator starts at -inf where the column owns a bin and at NaN where it owns none (p.col_init); the flush turns NaN
+//     into "no bin" and -inf (every bin of the column was NaN) into the -100 the two-pass kernel gives.
 // `side_off` (wave-uniform): the second row rode the transform multiplied by 2^E (its block exponent, see "Two rows, one
 // transform" below); side_off = -E * 20 log10(2) takes the factor out again in dB.
+constexpr uint32_t kColStride = 516;            // floats between the two rows' accumulators (512 columns + the spare slot)
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) char lds_char;
+__device__ __forceinline__ void lds_fmax(lds_f32 *p, float v) { (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // ds_max_f32
 template <bool LDS_TABLE = false, bool COLS = false>
 __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t first_bin, uint32_t n_bins,
                                                  float db_offset, const float *__restrict__ offpink,
                                                  float *o_mid, float *o_side, bool store_side = true,
-                                                 uint32_t *colbuf = nullptr, const uint16_t *bincol = nullptr,
-                                                 uint32_t cols = 0, float gain = 0.0f, float side_off = 0.0f)
+                                                 float side_off = 0.0f, float *colbuf = nullptr, const uint2 *coltab = nullptr,
+                                                 const uint2 *colbins = nullptr)
 {
     const uint32_t ngroups = (n_bins + 3) >> 2;
     // dB = 10 log10(2) * log2(q) + (db_offset + pink[bin]); an exact zero reads -150 (+ pink): the log operand is
@@ -109,6 +125,7 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
         if (!LDS_TABLE && g < ngroups) op[i] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(offpink) + boff);   // table padded to the row stride
     }
     float rm[2][4], rs[2][4];
+    uint2 ctab[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};      // COLS: the groups' column offsets, requested with the spectrum reads
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         const uint32_t g = (uint32_t)t + 256u * i;
@@ -130,6 +147,7 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
                 zm[e] = xb[SPEC_POS(4096 - k)];                  // Z[N - k]
             }
             if (LDS_TABLE) op[i] = reinterpret_cast<const float4 *>(offpink)[g];
+            if (COLS) ctab[i] = coltab[g];
 #if defined(__HIP_DEVICE_COMPILE__)
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -171,33 +189,51 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
         }
     }
     if (COLS) {
+        lds_char *const cb = (lds_char *)colbuf;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const uint32_t g = (uint32_t)t + 256u * i;
             if (g < ngroups) {
-                const uint2 cw = reinterpret_cast<const uint2 *>(bincol)[g];          // four u16 column indices (0xFFFF: padding)
-                const uint32_t c[4] = {cw.x & 0xFFFFu, cw.x >> 16, cw.y & 0xFFFFu, cw.y >> 16};
+                const uint2 ct = ctab[i];
+#if SS_COLS_FOLD
+                const uint32_t o0 = ct.x & 0xFFFFu, o3 = ct.x >> 16, nf = ct.y & 0xFFu;
+                const bool general = (ct.y >> 8) != 0u;
+                if (__builtin_expect(__ballot(general) != 0ull, 0)) {          // (wave-uniform: the wave that owns the lowest bins / the padding)
+                    if (general) {
+                        const uint2 cw = colbins[g];
+                        const uint32_t o[4] = {cw.x & 0xFFFFu, cw.x >> 16, cw.y & 0xFFFFu, cw.y >> 16};
 #pragma unroll
-                for (int row = 0; row < 2; row++) {
-                    uint32_t key[4];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const float v = fminf(fmaxf((row ? rs[i][e] : rm[i][e]) + gain, -100.0f), 0.0f);
-                        key[e] = __float_as_uint(0.0f - v);
-                    }
-                    uint32_t *cb = colbuf + row * cols;
-                    uint32_t m = key[0], cc = c[0];
-#pragma unroll
-                    for (int e = 1; e < 4; e++) {
-                        if (c[e] != cc) {
-                            if (cc != 0xFFFFu) atomicMin(cb + cc, m);
-                            m = key[e]; cc = c[e];
-                        } else {
-                            m = key[e] < m ? key[e] : m;
+                        for (int e = 0; e < 4; e++) {
+                            lds_f32 *a = (lds_f32 *)(cb + o[e]);
+                            lds_fmax(a, rm[i][e]);
+                            lds_fmax(a + kColStride, rs[i][e]);
                         }
                     }
-                    if (cc != 0xFFFFu) atomicMin(cb + cc, m);
                 }
+                if (!general) {
+                    const bool p1 = nf > 1u, p2 = nf > 2u, p3 = nf > 3u;
+                    auto max3 = [](float a, float b, float c) -> float { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; };
+                    auto max2 = [](float a, float b) -> float { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+#pragma unroll
+                    for (int row = 0; row < 2; row++) {
+                        const float *r = row ? rs[i] : rm[i];
+                        // (a bin outside a run is replaced by a bin inside it: a duplicate cannot change a maximum)
+                        float f = max3(r[0], p1 ? r[1] : r[0], p2 ? r[2] : r[0]);
+                        f = max2(f, p3 ? r[3] : r[0]);
+                        const float l = max3(r[3], p2 ? r[3] : r[2], p1 ? r[3] : r[1]);
+                        lds_fmax((lds_f32 *)(cb + o0) + row * kColStride, f);
+                        if (!p3) lds_fmax((lds_f32 *)(cb + o3) + row * kColStride, l);
+                    }
+                }
+#else
+                const uint32_t o[4] = {ct.x & 0xFFFFu, ct.x >> 16, ct.y & 0xFFFFu, ct.y >> 16};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    lds_f32 *a = (lds_f32 *)(cb + o[e]);
+                    lds_fmax(a, rm[i][e]);
+                    lds_fmax(a + kColStride, rs[i][e]);
+                }
+#endif
             }
         }
         return;
@@ -245,23 +281,22 @@ __device__ __forceinline__ void fft4096_floor_rows(int t, uint32_t n_bins, float
 // the epilogue's atomics; every column of the row is rewritten from scratch by a plain store, then the floor values — a
 // monotone function of the bin's pink compensation — are folded in like any other row)
 __device__ __forceinline__ void fft4096_floor_columns(int t, uint32_t n_bins, float db_offset, const float *__restrict__ offpink,
-                                                      uint32_t *colbuf, const uint16_t *bincol, uint32_t cols, float gain,
+                                                      float *colbuf, const uint16_t *bincol, const float *col_init, uint32_t cols,
                                                       bool first_zero, bool second_zero)
 {
     constexpr float kDb = 3.01029995663981195f;
     const float lg0 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint((-150.0f - db_offset) / kDb)));
     __syncthreads();
     for (uint32_t c = (uint32_t)t; c < cols; c += 256u) {
-        if (first_zero) colbuf[c] = 0xFFFFFFFFu;
-        if (second_zero) colbuf[cols + c] = 0xFFFFFFFFu;
+        if (first_zero) colbuf[c] = col_init[c];
+        if (second_zero) colbuf[kColStride + c] = col_init[c];
     }
     __syncthreads();
     for (uint32_t k = (uint32_t)t; k < n_bins; k += 256u) {
-        const uint32_t c = bincol[k];
-        const float v = fminf(fmaxf(fmaf(lg0, kDb, offpink[k]) + gain, -100.0f), 0.0f);
-        const uint32_t key = __float_as_uint(0.0f - v);
-        if (first_zero) atomicMin(colbuf + c, key);
-        if (second_zero) atomicMin(colbuf + cols + c, key);
+        const uint32_t c = bincol[k];                                   // (global memory: this path is rare)
+        const float v = fmaf(lg0, kDb, offpink[k]);
+        if (first_zero) lds_fmax((lds_f32 *)colbuf + c, v);
+        if (second_zero) lds_fmax((lds_f32 *)colbuf + kColStride + c, v);
     }
 }
 
@@ -521,9 +556,9 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
         __syncthreads();
         // ---- epilogue: groups of four consecutive bins per thread, 16-byte stores
         float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
-        fft4096_epilogue(xbuf[0], t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride, true, nullptr, nullptr, 0, 0.0f, block_off(E0));
+        fft4096_epilogue(xbuf[0], t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride, true, block_off(E0));
         if (two) fft4096_epilogue(xbuf[1], t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid + out_win_stride,
-                                  o_mid + out_win_stride + p.bin_stride, true, nullptr, nullptr, 0, 0.0f, block_off(E1));
+                                  o_mid + out_win_stride + p.bin_stride, true, block_off(E1));
         // a row whose WINDOWED samples are all zero reads the reference's floor (the transform of zeros, analyzer.rs:20-22)
         if (__builtin_expect(X[0] == 0u || X[1] == 0u, 0))
             fft4096_floor_rows(t, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride, X[0] == 0u, X[1] == 0u);
@@ -550,6 +585,12 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
 #ifndef SS_FFT1_WAVES
 #define SS_FFT1_WAVES 3
 #endif
+#ifndef SS_COLS_FOLD
+#define SS_COLS_FOLD 1    // columns-only epilogue: 1 folds a lane's four bins in registers first (one or two atomics per row and group); 0 one atomic per bin
+#endif
+#ifndef SS_MS1_TW
+#define SS_MS1_TW 12     // resident pass-1 twiddles of k_fft4096_ms1 (6, 9, 12; 0 = all fifteen): 168 VGPRs at 12, the three-waves limit
+#endif
 // Wave priority by phase: a wave that is exchanging through LDS (writes, barrier, reads) runs at raised priority so
 // its few LDS instructions issue ahead of the other workgroups' butterflies; measured 3.15 -> 3.05 ms (A/B in one process)
 #ifndef SS_FFT_PRIO
@@ -573,7 +614,7 @@ __device__ unsigned long long g_fft_prof[16];
 #define SS_FPROF_MARK(i)
 #define SS_FPROF_END
 #endif
-template <int HS, bool TW6, bool COLS>
+template <int HS, int TWN, bool COLS>
 __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchParams p)
 {
     constexpr int NH = 16 / HS;                                           // hops per window
@@ -587,12 +628,14 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
     // 8192 B: db_offset + pink per retained bin (n_bins <= 2047 at N = 4096).  Columns-only mode (COLS) uses the room for the
     // bins' chart columns (u16 each) and the two rows' column accumulators instead, and reads the table from global memory.
 #ifdef SS_MS1_NO_LDS_TABLE      // experiment (review item 6): no table in LDS, so that FOUR workgroups fit a CU (with -DSS_FFT1_WAVES=4)
-    __shared__ __attribute__((aligned(16))) float offp[COLS ? 2048 : 4];
+    __shared__ __attribute__((aligned(16))) float offp[4];
 #else
     __shared__ __attribute__((aligned(16))) float offp[2048];
 #endif
-    uint16_t *bincol = reinterpret_cast<uint16_t *>(offp);                //  4096 B
-    uint32_t *colbuf = reinterpret_cast<uint32_t *>(offp) + 1024;         //  4096 B: [mid, side][cols <= 512]
+    // COLS: + 4096 B offset table (one uint2 per group of four bins) + 4128 B column accumulators [mid, side][kColStride]
+    // (three workgroups per CU leave 53 KB each: 53.4 KB with these)
+    __shared__ __attribute__((aligned(16))) uint2 coltab[COLS ? 512 : 1];
+    __shared__ __attribute__((aligned(16))) float colbuf[COLS ? 2 * kColStride : 1];
 #define X1W(ka, tb_, ta_) ((ka) * kPlaneB + (tb_) * kRowB + (ta_))
 #define X2W(kb, ka_, tb_) ((kb) * kPlaneB + (ka_) * kRowB + (tb_))
     const int t = threadIdx.x;
@@ -612,33 +655,37 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
 #pragma unroll
     for (int j = 0; j < 8; j++) hwp[j] = v2f{p.half_window[t + 256 * (2 * j)], p.half_window[t + 256 * (2 * j + 1)]};
     v2f tw1[16];
+    constexpr bool TW6 = TWN != 0;                                        // some of the fifteen are rebuilt
+    // TWN resident pass-1 twiddles: 6 = {1, 2, 3, 4, 8, 12}; 9 adds {5, 6, 7}; 12 adds {9, 10, 11} (one multiply instead of two each)
+    auto tw_resident = [](int ka) -> bool { return (ka & 3) == 0 || (ka & 12) == 0 || (TWN >= 9 && (ka >> 2) == 1) || (TWN >= 12 && (ka >> 2) == 2); };
     if (TW6) {
-        tw1[1] = twn[t]; tw1[2] = twn[2 * t]; tw1[3] = twn[3 * t];
-        tw1[4] = twn[4 * t]; tw1[8] = twn[8 * t]; tw1[12] = twn[12 * t];
+#pragma unroll
+        for (int ka = 1; ka < 16; ka++) if (tw_resident(ka)) tw1[ka] = twn[ka * t];
     } else {
 #pragma unroll
         for (int ka = 1; ka < 16; ka++) tw1[ka] = twn[t * ka];
     }
     tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[(t & 15) * (t >> 4)];      // [kb][tb]: W_256^(tb kb) at kb * 16 + tb
     if (COLS) {
-        for (uint32_t g = (uint32_t)t; 4u * g < p.bin_stride; g += 256u)
-            reinterpret_cast<uint2 *>(bincol)[g] = reinterpret_cast<const uint2 *>(p.bin_col)[g];
-        for (uint32_t c = (uint32_t)t; c < 2u * p.cols; c += 256u) colbuf[c] = 0xFFFFFFFFu;
-    } else {
-#ifndef SS_MS1_NO_LDS_TABLE
-        for (uint32_t g = (uint32_t)t; 4u * g < p.bin_stride; g += 256u)
-            reinterpret_cast<float4 *>(offp)[g] = reinterpret_cast<const float4 *>(p.offpink)[g];
-#endif
+        for (uint32_t g = (uint32_t)t; 4u * g < p.bin_stride; g += 256u) coltab[g] = p.col_groups[g];
+        for (uint32_t c = (uint32_t)t; c < p.cols; c += 256u) { const float v = p.col_init[c]; colbuf[c] = v; colbuf[kColStride + c] = v; }
+        if (t < 4) { colbuf[512 + t] = 0.0f; colbuf[kColStride + 512 + t] = 0.0f; }      // the spare slots the row padding folds into
     }
+#ifndef SS_MS1_NO_LDS_TABLE
+    for (uint32_t g = (uint32_t)t; 4u * g < p.bin_stride; g += 256u)
+        reinterpret_cast<float4 *>(offp)[g] = reinterpret_cast<const float4 *>(p.offpink)[g];
+#endif
     // columns-only mode: gain of this stream, and where a finished window's columns go (flushed one window late, behind the
     // loop-end barrier that closes its epilogue's atomics, by the threads that idle least: all of them, one column pair each)
     const float cgain = COLS ? (p.integrated ? -13.0f - (float)p.integrated[stream] : p.gain_db) : 0.0f;
     auto flush_columns = [&](uint32_t wdone) {
         float *oc = p.out_cols + ((size_t)stream * p.n_windows + wdone) * 2u * p.cols;
         for (uint32_t c = (uint32_t)t; c < 2u * p.cols; c += 256u) {
-            const uint32_t k = colbuf[c];
-            colbuf[c] = 0xFFFFFFFFu;
-            oc[c] = k == 0xFFFFFFFFu ? __builtin_nanf("") : 0.0f - __uint_as_float(k);
+            const uint32_t i = c < p.cols ? c : c - p.cols + kColStride;
+            const float k = colbuf[i];
+            const bool none = k != k;                                 // NaN: the column owns no bin (never written, never reset)
+            if (!none) colbuf[i] = -INFINITY;
+            oc[c] = none ? k : fminf(fmaxf(k + cgain, -100.0f), 0.0f);
         }
     };
     const int tb = t & 15, hi = t >> 4;
@@ -749,9 +796,9 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
 #pragma unroll
         for (int ka = 1; ka < 16; ka++) {
             v2f v = z[R16(ka)];
-            if (TW6) {
-                if (ka & 3) v = pk_cmul(v, tw1[ka & 3]);
-                if (ka & 12) v = pk_cmul(v, tw1[ka & 12]);
+            if (TW6 && !tw_resident(ka)) {
+                v = pk_cmul(v, tw1[ka & 3]);
+                v = pk_cmul(v, tw1[ka & 12]);
             } else {
                 v = pk_cmul(v, tw1[ka]);
             }
@@ -830,15 +877,14 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
             presettle();
         }
         float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
-        if (COLS) fft4096_epilogue<false, true>(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, nullptr, nullptr, true, colbuf, bincol, p.cols, cgain, soff);
 #ifdef SS_MS1_NO_LDS_TABLE
-        else fft4096_epilogue<false>(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride, true, nullptr, nullptr, 0, 0.0f, soff);
+        fft4096_epilogue<false, COLS>(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride, true, soff, colbuf, coltab, p.col_bins);
 #else
-        else fft4096_epilogue<true>(xbuf, t, p.first_bin, p.n_bins, p.db_offset, offp, o_mid, o_mid + p.bin_stride, true, nullptr, nullptr, 0, 0.0f, soff);
+        fft4096_epilogue<true, COLS>(xbuf, t, p.first_bin, p.n_bins, p.db_offset, offp, o_mid, o_mid + p.bin_stride, true, soff, colbuf, coltab, p.col_bins);
 #endif
         if (__builtin_expect(zrow_m || zrow_d, 0)) {
             if (!COLS) fft4096_floor_rows(t, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride, zrow_m, zrow_d);
-            else fft4096_floor_columns(t, p.n_bins, p.db_offset, p.offpink, colbuf, bincol, p.cols, cgain, zrow_m, zrow_d);
+            else fft4096_floor_columns(t, p.n_bins, p.db_offset, p.offpink, colbuf, p.bin_col, p.col_init, p.cols, zrow_m, zrow_d);
         }
         SS_FPROF_MARK(10);
         __syncthreads();
@@ -1023,7 +1069,7 @@ __global__ __launch_bounds__(256, SS_FFT_PAIRW_WAVES) void k_fft4096_pairw(FftBa
         __syncthreads();
         SS_PRIO_LO();
         float *o_first = outp + (size_t)(pp - pp_begin) * 2u * row_stride;
-        fft4096_epilogue(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_first, o_first + row_stride, two, nullptr, nullptr, 0, 0.0f, block_off(E));
+        fft4096_epilogue(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_first, o_first + row_stride, two, block_off(E));
         if (__builtin_expect(zrow_a || (two && zrow_b), 0))
             fft4096_floor_rows(t, p.n_bins, p.db_offset, p.offpink, o_first, o_first + row_stride, zrow_a, two && zrow_b);
         if (more) {
@@ -1131,7 +1177,7 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms_anyhop(FftBatc
         for (int kc = 0; kc < 16; kc++) xbuf[kc * 256 + SPEC_POS(t)] = z[R16(kc)];
         __syncthreads();
         float *o_mid = outp + (size_t)(w - w_begin) * out_win_stride;
-        fft4096_epilogue(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride, true, nullptr, nullptr, 0, 0.0f, block_off(E));
+        fft4096_epilogue(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride, true, block_off(E));
         if (__builtin_expect(Xm == 0u || Xd == 0u, 0))
             fft4096_floor_rows(t, p.n_bins, p.db_offset, p.offpink, o_mid, o_mid + p.bin_stride, Xm == 0u, Xd == 0u);
     }
@@ -1456,8 +1502,8 @@ hipError_t launch_fft4096_ms(const FftBatchParams &p, hipStream_t s)
     dim3 grid(groups * p.n_streams), block(256);
     // hop 1024 (the reference's cadence): the single-window kernel at 3 workgroups per CU measured 2.5 %
     // faster than the window-pair kernel k_fft4096_ms<4> at 2 (A/B in one process, 3.48 vs 3.57 ms)
-    if (p.hop == 1024 && p.out_cols) hipLaunchKernelGGL((k_fft4096_ms1<4, true, true>), grid, block, 0, s, p);
-    else if (p.hop == 1024) hipLaunchKernelGGL((k_fft4096_ms1<4, true, false>), grid, block, 0, s, p);
+    if (p.hop == 1024 && p.out_cols) hipLaunchKernelGGL((k_fft4096_ms1<4, SS_MS1_TW, true>), grid, block, 0, s, p);
+    else if (p.hop == 1024) hipLaunchKernelGGL((k_fft4096_ms1<4, SS_MS1_TW, false>), grid, block, 0, s, p);
     else if (p.hop == 512) hipLaunchKernelGGL(k_fft4096_ms<2>, grid, block, 0, s, p);
     else if (p.hop == 2048) hipLaunchKernelGGL(k_fft4096_ms<8>, grid, block, 0, s, p);
     else hipLaunchKernelGGL(k_fft4096_ms_anyhop, grid, block, 0, s, p);

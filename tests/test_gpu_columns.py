@@ -22,6 +22,8 @@ def test_fused_columns_equal_the_two_pass_result(cols, gain):
     rate, frames, ns = 48000, 48000 * 3 + 333, 5
     xs = [make_stereo(300 + s, frames, rate=rate, level=0.05 + 0.2 * s, gap=(s == 2)) for s in range(ns)]
     xs[4][1::2] = xs[4][0::2]                                    # a dual-mono stream: its side row is the -150 dB floor
+    xs[3][2 * 70000] = np.nan                                    # four windows whose every bin is NaN: -100 in every column that owns a bin
+    xs[1][2 * 30000 + 1] = np.inf
     two = ssa.Batch(rate, 2, ns, frames, 4096, 1024, flags=L.SS_BATCH_ALL)
     two.upload(0, np.concatenate(xs)); two.run(); two.render_spectrum(cols, gain)
     one = ssa.Batch(rate, 2, ns, frames, 4096, 1024, flags=L.SS_BATCH_ALL, spectrum_columns=cols)
