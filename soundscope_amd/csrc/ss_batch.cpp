@@ -193,7 +193,7 @@ int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
                 uint32_t n = 1;
                 while (n < 4 && o[n] == o[0]) n++;
                 for (uint32_t e = n; e < 4; e++) general = general || o[e] != o[3];
-                cg[g] = make_uint2(o[0] | (o[3] << 16), n | (general ? 0x100u : 0u));
+                cg[g] = make_uint2(o[0] | (o[3] << 16), general ? 0u : n);
                 cbins[g] = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
             }
             HIPCHK(b->col_bins.upload(cbins));

@@ -6,7 +6,11 @@
 #include "ss_kernels.h"
 #include "ss_fft_dev.h"
 #include <cstdlib>
+#include <type_traits>
 
+#ifndef SS_COLS_FOLD
+#define SS_COLS_FOLD 1    // columns-only epilogue: 1 folds a lane's four bins in registers first (one or two atomics per row and group); 0 one atomic per bin
+#endif
 #ifndef SS_FFT_PAIRW_WAVES
 #define SS_FFT_PAIRW_WAVES 3   // min waves per SIMD k_fft4096_pairw is register-allocated for (4: 128 VGPRs with 13 spilled, measured 10 % slower)
 #endif
@@ -78,13 +82,13 @@ constexpr int kPlaneB = 16 * kRowB;
 // operand like IEEE maxNum) at a byte offset from a host-built table — no per-bin branch, key conversion or clamp in the vector
 // ALU, which is what bounds this kernel (the divergent per-bin ds_min_u32 form of rounds 3-4: 3.30 ms; this one 3.00).
 //   * Chart columns are monotone in the bin index and, above the lowest few dozen bins, at least four bins wide: a lane's four
-//     consecutive bins lie in ONE column or straddle one boundary.  coltab[g] = (o0 | o3 << 16, n | general << 8): the offsets
-//     of the first and the last bin's column and the number n of bins in the first.  The two run maxima are taken in registers
+//     consecutive bins lie in ONE column or straddle one boundary.  coltab[g] = (o0 | o3 << 16, n): the offsets
+//     of the first and the last bin's column and the number n of bins in the first (0: a general group, below).  The two run maxima are taken in registers
 //     (five selects, three maxima per row) and one atomic per row goes out — two where the group straddles.  One atomic per BIN
 //     and no arithmetic at all (SS_COLS_FOLD 0) was measured: 3.86 ms — the sixteen-odd lanes that share a wide column queue on
 //     one LDS address (SQ_LDS_BANK_CONFLICT 40 % of the LDS cycles), profiles/r05_ab_columns.txt.
 //   * Groups the two-run form cannot express (three or four columns inside the group: the lowest bins; the row padding in the
-//     last group, whose offsets point at a spare slot) carry general = 1 and fold bin by bin from colbins — a wave-uniform branch.
+//     last group, whose offsets point at a spare slot) carry n = 0 and fold bin by bin from colbins — a wave-uniform branch.
 //   * An accumulator starts at -inf where the column owns a bin and at NaN where it owns none (p.col_init); the flush turns NaN
 //     into "no bin" and -inf (every bin of the column was NaN) into the -100 the two-pass kernel gives.
 // `side_off` (wave-uniform): the second row rode the transform multiplied by 2^E (its block exponent, see "Two rows, one
@@ -125,7 +129,53 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
         if (!LDS_TABLE && g < ngroups) op[i] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(offpink) + boff);   // table padded to the row stride
     }
     float rm[2][4], rs[2][4];
-    uint2 ctab[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};      // COLS: the groups' column offsets, requested with the spectrum reads
+    // COLS: a group's eight values are folded as soon as they exist (nothing is stored, so nothing has to wait for the loads of
+    // the other group; sixteen values would otherwise live across both groups' arithmetic)
+    lds_char *const cb = (lds_char *)colbuf;
+    auto fold_group = [&](const int i, const uint32_t g) {
+                const uint2 ct = coltab[g];
+#if SS_COLS_FOLD
+                const uint32_t o0 = ct.x & 0xFFFFu, o3 = ct.x >> 16, nf = ct.y;     // (a whole dword: compares against inline constants)
+                const bool general = nf == 0u;
+                if (__builtin_expect(__ballot(general) != 0ull, 0)) {          // (wave-uniform: the wave that owns the lowest bins / the padding)
+                    if (general) {
+                        uint32_t gg = g;                       // (opaque: hoisted out of the window loop this address was spilled)
+                        asm volatile("" : "+v"(gg));
+                        const uint2 cw = colbins[gg];
+                        const uint32_t o[4] = {cw.x & 0xFFFFu, cw.x >> 16, cw.y & 0xFFFFu, cw.y >> 16};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            lds_f32 *a = (lds_f32 *)(cb + o[e]);
+                            lds_fmax(a, rm[i][e]);
+                            lds_fmax(a + kColStride, rs[i][e]);
+                        }
+                    }
+                }
+                if (!general) {
+                    const bool p1 = nf > 1u, p2 = nf > 2u, p3 = nf > 3u;
+                    auto max3 = [](float a, float b, float c) -> float { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; };
+                    auto max2 = [](float a, float b) -> float { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+#pragma unroll
+                    for (int row = 0; row < 2; row++) {
+                        const float *r = row ? rs[i] : rm[i];
+                        // (a bin outside a run is replaced by a bin inside it: a duplicate cannot change a maximum)
+                        float f = max3(r[0], p1 ? r[1] : r[0], p2 ? r[2] : r[0]);
+                        f = max2(f, p3 ? r[3] : r[0]);
+                        const float l = max3(r[3], p2 ? r[3] : r[2], p1 ? r[3] : r[1]);
+                        lds_fmax((lds_f32 *)(cb + o0) + row * kColStride, f);
+                        if (!p3) lds_fmax((lds_f32 *)(cb + o3) + row * kColStride, l);
+                    }
+                }
+#else
+                const uint32_t o[4] = {ct.x & 0xFFFFu, ct.x >> 16, ct.y & 0xFFFFu, ct.y >> 16};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    lds_f32 *a = (lds_f32 *)(cb + o[e]);
+                    lds_fmax(a, rm[i][e]);
+                    lds_fmax(a + kColStride, rs[i][e]);
+                }
+#endif
+    };
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         const uint32_t g = (uint32_t)t + 256u * i;
@@ -147,7 +197,6 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
                 zm[e] = xb[SPEC_POS(4096 - k)];                  // Z[N - k]
             }
             if (LDS_TABLE) op[i] = reinterpret_cast<const float4 *>(offpink)[g];
-            if (COLS) ctab[i] = coltab[g];
 #if defined(__HIP_DEVICE_COMPILE__)
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -183,61 +232,13 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
                     rs[i][e] = qs[e] == 0.0f ? fmaf(lg0, kDb, opv[e]) : fmaf(__log2f(qs[e]), kDb, ops[e]);      // a zero is -150 whatever the exponent
                 }
             }
+            if (COLS) fold_group(i, g);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; e++) { rm[i][e] = 0.0f; rs[i][e] = 0.0f; }
         }
     }
-    if (COLS) {
-        lds_char *const cb = (lds_char *)colbuf;
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const uint32_t g = (uint32_t)t + 256u * i;
-            if (g < ngroups) {
-                const uint2 ct = ctab[i];
-#if SS_COLS_FOLD
-                const uint32_t o0 = ct.x & 0xFFFFu, o3 = ct.x >> 16, nf = ct.y & 0xFFu;
-                const bool general = (ct.y >> 8) != 0u;
-                if (__builtin_expect(__ballot(general) != 0ull, 0)) {          // (wave-uniform: the wave that owns the lowest bins / the padding)
-                    if (general) {
-                        const uint2 cw = colbins[g];
-                        const uint32_t o[4] = {cw.x & 0xFFFFu, cw.x >> 16, cw.y & 0xFFFFu, cw.y >> 16};
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            lds_f32 *a = (lds_f32 *)(cb + o[e]);
-                            lds_fmax(a, rm[i][e]);
-                            lds_fmax(a + kColStride, rs[i][e]);
-                        }
-                    }
-                }
-                if (!general) {
-                    const bool p1 = nf > 1u, p2 = nf > 2u, p3 = nf > 3u;
-                    auto max3 = [](float a, float b, float c) -> float { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; };
-                    auto max2 = [](float a, float b) -> float { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
-#pragma unroll
-                    for (int row = 0; row < 2; row++) {
-                        const float *r = row ? rs[i] : rm[i];
-                        // (a bin outside a run is replaced by a bin inside it: a duplicate cannot change a maximum)
-                        float f = max3(r[0], p1 ? r[1] : r[0], p2 ? r[2] : r[0]);
-                        f = max2(f, p3 ? r[3] : r[0]);
-                        const float l = max3(r[3], p2 ? r[3] : r[2], p1 ? r[3] : r[1]);
-                        lds_fmax((lds_f32 *)(cb + o0) + row * kColStride, f);
-                        if (!p3) lds_fmax((lds_f32 *)(cb + o3) + row * kColStride, l);
-                    }
-                }
-#else
-                const uint32_t o[4] = {ct.x & 0xFFFFu, ct.x >> 16, ct.y & 0xFFFFu, ct.y >> 16};
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    lds_f32 *a = (lds_f32 *)(cb + o[e]);
-                    lds_fmax(a, rm[i][e]);
-                    lds_fmax(a + kColStride, rs[i][e]);
-                }
-#endif
-            }
-        }
-        return;
-    }
+    if (COLS) return;
 #if defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_sched_barrier(0);          // the stores stay behind everything above
 #endif
@@ -585,11 +586,11 @@ __global__ __launch_bounds__(256, SS_FFT_WAVES) void k_fft4096_ms(FftBatchParams
 #ifndef SS_FFT1_WAVES
 #define SS_FFT1_WAVES 3
 #endif
-#ifndef SS_COLS_FOLD
-#define SS_COLS_FOLD 1    // columns-only epilogue: 1 folds a lane's four bins in registers first (one or two atomics per row and group); 0 one atomic per bin
-#endif
 #ifndef SS_MS1_TW
 #define SS_MS1_TW 12     // resident pass-1 twiddles of k_fft4096_ms1 (6, 9, 12; 0 = all fifteen): 168 VGPRs at 12, the three-waves limit
+#endif
+#ifndef SS_COLS_TW
+#define SS_COLS_TW SS_MS1_TW      // the columns-only instantiation: the SAME count, or its rows would round differently from the stored ones
 #endif
 // Wave priority by phase: a wave that is exchanging through LDS (writes, barrier, reads) runs at raised priority so
 // its few LDS instructions issue ahead of the other workgroups' butterflies; measured 3.15 -> 3.05 ms (A/B in one process)
@@ -667,7 +668,7 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
     }
     tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[(t & 15) * (t >> 4)];      // [kb][tb]: W_256^(tb kb) at kb * 16 + tb
     if (COLS) {
-        for (uint32_t g = (uint32_t)t; 4u * g < p.bin_stride; g += 256u) coltab[g] = p.col_groups[g];
+        for (uint32_t g = (uint32_t)t; 4u * g < p.bin_stride; g += 256u) coltab[g] = SS_COLS_FOLD ? p.col_groups[g] : p.col_bins[g];
         for (uint32_t c = (uint32_t)t; c < p.cols; c += 256u) { const float v = p.col_init[c]; colbuf[c] = v; colbuf[kColStride + c] = v; }
         if (t < 4) { colbuf[512 + t] = 0.0f; colbuf[kColStride + 512 + t] = 0.0f; }      // the spare slots the row padding folds into
     }
@@ -1221,7 +1222,7 @@ __global__ __launch_bounds__(512, 2) void k_fft16k(FftBatchParams p, int midside
 #ifndef SS_RUN8_WAVES
 #define SS_RUN8_WAVES 4
 #endif
-template <bool MIDSIDE>
+template <bool MIDSIDE, int NE_LAST>
 __global__ __launch_bounds__(512, SS_RUN8_WAVES) void k_fft16k_run(FftBatchParams p, uint32_t fft_ch)
 {
     __shared__ __attribute__((aligned(16))) v2f xbuf2[2][16 * kPlaneB];      // 2 x 34816 B
@@ -1284,6 +1285,19 @@ __global__ __launch_bounds__(512, SS_RUN8_WAVES) void k_fft16k_run(FftBatchParam
     const uint32_t ngroups = (p.n_bins + 3) >> 2;
     constexpr float kDb = 3.01029995663981195f;
     const float off2 = p.db_offset - 6.02059991327962390f;      // the epilogue carries 2 X
+    // Epilogue geometry.  An iteration covers 2048 retained bins: wave wv the 256 starting at 256 wv, as four slices of 64 (one bin
+    // per lane and slice).  The LAST iteration covers what is left, R = 4 ngroups - 2048 (n_iter - 1) bins, with ne_last =
+    // ceil(R / 512) slices per wave instead of four — 3410 bins at 96 kHz: 2048 + 3 x 512, 6820 at 48 kHz: 3 x 2048 + 2 x 512 — so
+    // an eighth of the four-term recombinations is no longer computed for bins nobody keeps, and every wave (hence every SIMD)
+    // saves the same share.  Its bins sit 2048 - 64 (4 - ne_last) wv behind the previous iteration's, not 2048: the twiddles of
+    // that iteration take one more turn by the wave-uniform constant wlast = W_16384^(-64 (4 - ne_last) wv).
+    const uint32_t n_iter = (4u * ngroups + 2047u) >> 11;                  // (the launcher instantiates NE_LAST = ne_last)
+    v2f wlast;
+    {
+        const uint32_t wv0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const v2f wl = tw16k[(64u * (4u - (uint32_t)NE_LAST) * wv0) & 8191u];
+        wlast = v2f{uniform_f(wl.x), uniform_f(-wl.y)};                // conjugate: a turn backwards
+    }
     // Everything loaded above is "used" once here, in front of the window loop.  A register whose load is still pending at
     // the loop's entry gets its s_waitcnt at its first use INSIDE the loop, and vmcnt counts stores too: in every later
     // iteration that wait — vmcnt(0) in the middle of the first radix pass — stood there for the PREVIOUS window's output
@@ -1387,63 +1401,66 @@ __global__ __launch_bounds__(512, SS_RUN8_WAVES) void k_fft16k_run(FftBatchParam
         float *o = p.out + (((size_t)stream * p.n_windows + w) * fft_ch + ch) * p.bin_stride;
         {
             float *stg = stage[wv];
-            uint32_t pb[4], pm[4];
             uint32_t fb = p.first_bin;
             asm volatile("" : "+s"(fb));
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const uint32_t b = fb + 256u * wv + 64u * e + lane;
-                pb[e] = b & 4095u; pm[e] = (4096u - (b & 4095u)) & 4095u;
-            }
             const v2f rho = {0.70710678118654752f, -0.70710678118654752f};
-            const uint32_t n_iter = (4u * ngroups + 2047u) >> 11;
             asm volatile("" : "+v"(wt[0]), "+v"(wt[1]), "+v"(wt[2]), "+v"(wt[3]));
-            for (uint32_t it = 0; it < n_iter; it++) {
-                const uint32_t g = 512u * it + 64u * wv + lane;        // group of four bins this lane stores
+            // one iteration over NE slices of 64 bins per wave (NE = 4 but for the last one, where it is the kernel's NE_LAST)
+            auto iteration = [&](auto ne_c, const uint32_t it, const bool last_it) {
+                constexpr int NE = decltype(ne_c)::value;
+                const uint32_t g = 512u * it + 16u * NE * wv + lane;   // group of four bins this lane stores
+                const bool g_ok = (NE == 4 || lane < 16u * NE) && g < ngroups;
                 float4 pk = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (p.pink) pk = *reinterpret_cast<const float4 *>(p.pink + 4u * (g < ngroups ? g : ngroups - 1u));
-                v2f e0v[4], emv[4], o0v[4], omv[4];
+                const uint32_t b0 = fb + 2048u * it + 64u * NE * wv + lane;
+                v2f e0v[NE], emv[NE], o0v[NE], omv[NE];
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    e0v[e] = xbuf2[0][pb[e]]; emv[e] = xbuf2[0][pm[e]];
-                    o0v[e] = xbuf2[1][pb[e]]; omv[e] = xbuf2[1][pm[e]];
+                for (int e = 0; e < NE; e++) {
+                    const uint32_t pb = (b0 + 64u * e) & 4095u, pm = (4096u - pb) & 4095u;
+                    e0v[e] = xbuf2[0][pb]; emv[e] = xbuf2[0][pm];
+                    o0v[e] = xbuf2[1][pb]; omv[e] = xbuf2[1][pm];
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                float r[4], qv[4];
+                float r[4] = {0.f, 0.f, 0.f, 0.f}, qv[NE];
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
+                for (int e = 0; e < NE; e++) {
                     const v2f e0 = e0v[e], em = emv[e], o0 = o0v[e], om = omv[e];
                     v2f a0, a1, a2, a3;        // 2 A_r[b]
                     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,0] neg_hi:[0,1]" : "=v"(a0) : "v"(e0), "v"(em));
                     asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[1,0]" : "=v"(a1) : "v"(e0), "v"(em));
                     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,0] neg_hi:[0,1]" : "=v"(a2) : "v"(o0), "v"(om));
                     asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[1,0]" : "=v"(a3) : "v"(o0), "v"(om));
-                    v2f x = pk_cmul(a3, wt[e]) + a2;
-                    x = pk_cmul(x, wt[e]) + a1;
-                    x = pk_cmul(x, wt[e]) + a0;
+                    // narrower slices: the bins moved by 2048 - 64 (4 - NE) wv since the previous iteration, not by 2048
+                    const v2f wte = NE != 4 ? pk_cmul(wt[e], wlast) : wt[e];
+                    v2f x = pk_cmul(a3, wte) + a2;
+                    x = pk_cmul(x, wte) + a1;
+                    x = pk_cmul(x, wte) + a0;
                     qv[e] = fmaf(x.x, x.x, x.y * x.y);
-                    pb[e] ^= 2048u;                                    // +-2048 mod 4096
-                    pm[e] ^= 2048u;
                 }
                 // an exact zero reads -150 (analyzer.rs:20-22): rare, so the wave first asks whether any of its magnitudes is zero
-                if (__builtin_expect(__ballot(fminf(fminf(qv[0], qv[1]), fminf(qv[2], qv[3])) == 0.0f) == 0ull, 1)) {
+                float qmin = qv[0];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) r[e] = fmaf(__log2f(qv[e]), kDb, off2);
+                for (int e = 1; e < NE; e++) qmin = fminf(qmin, qv[e]);
+                if (__builtin_expect(__ballot(qmin == 0.0f) == 0ull, 1)) {
+#pragma unroll
+                    for (int e = 0; e < NE; e++) r[e] = fmaf(__log2f(qv[e]), kDb, off2);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) r[e] = qv[e] == 0.0f ? -150.0f : fmaf(__log2f(qv[e]), kDb, off2);
+                    for (int e = 0; e < NE; e++) r[e] = qv[e] == 0.0f ? -150.0f : fmaf(__log2f(qv[e]), kDb, off2);
                 }
-                if (it + 1 < n_iter) {                                 // (the last iteration's turn would not be used)
+                if (!last_it) {                                        // (the last iteration's turn would not be used)
 #pragma unroll
                     for (int e = 0; e < 4; e++) wt[e] = pk_cmul(wt[e], rho);
                 }
 #pragma unroll
-                for (int e = 0; e < 4; e++) stg[64 * e + lane] = r[e];
+                for (int e = 0; e < NE; e++) stg[64 * e + lane] = r[e];
                 __builtin_amdgcn_wave_barrier();                      // LDS is in order per wave: ordering is all that is needed
                 const float4 v = reinterpret_cast<const float4 *>(stg)[lane];
                 __builtin_amdgcn_wave_barrier();
-                if (g < ngroups) reinterpret_cast<float4 *>(o)[g] = make_float4(v.x + pk.x, v.y + pk.y, v.z + pk.z, v.w + pk.w);
-            }
+                if (g_ok) reinterpret_cast<float4 *>(o)[g] = make_float4(v.x + pk.x, v.y + pk.y, v.z + pk.z, v.w + pk.w);
+            };
+            for (uint32_t it = 0; it + 1 < n_iter; it++) iteration(std::integral_constant<int, 4>{}, it, false);
+            iteration(std::integral_constant<int, NE_LAST>{}, n_iter - 1u, true);
         }
         if (more) {
 #pragma unroll
@@ -1482,8 +1499,12 @@ hipError_t launch_fft16k_run(FftBatchParams p, int mode, hipStream_t s)
     uint32_t groups = 1;
     fft16k_run_geometry(p.n_streams, fft_ch, p.n_windows, &p.windows_per_block, &groups);
     const dim3 grid((uint32_t)((pairs * groups + 7) & ~(uint64_t)7)), block(512);      // multiple of 8: see the XCD mapping in the kernel
-    if (mode == 1) hipLaunchKernelGGL(k_fft16k_run<true>, grid, block, 0, s, p, fft_ch);
-    else hipLaunchKernelGGL(k_fft16k_run<false>, grid, block, 0, s, p, fft_ch);
+    const uint32_t ngroups = (p.n_bins + 3) >> 2, n_iter = (4u * ngroups + 2047u) >> 11;
+    const uint32_t ne_last = (4u * ngroups - 2048u * (n_iter - 1u) + 511u) >> 9;       // slices of the epilogue's last iteration, 1 .. 4
+#define SS_RUN16K(MS, NE) hipLaunchKernelGGL((k_fft16k_run<MS, NE>), grid, block, 0, s, p, fft_ch)
+    if (mode == 1) { if (ne_last == 1) SS_RUN16K(true, 1); else if (ne_last == 2) SS_RUN16K(true, 2); else if (ne_last == 3) SS_RUN16K(true, 3); else SS_RUN16K(true, 4); }
+    else { if (ne_last == 1) SS_RUN16K(false, 1); else if (ne_last == 2) SS_RUN16K(false, 2); else if (ne_last == 3) SS_RUN16K(false, 3); else SS_RUN16K(false, 4); }
+#undef SS_RUN16K
     return hipGetLastError();
 }
 
@@ -1502,7 +1523,7 @@ hipError_t launch_fft4096_ms(const FftBatchParams &p, hipStream_t s)
     dim3 grid(groups * p.n_streams), block(256);
     // hop 1024 (the reference's cadence): the single-window kernel at 3 workgroups per CU measured 2.5 %
     // faster than the window-pair kernel k_fft4096_ms<4> at 2 (A/B in one process, 3.48 vs 3.57 ms)
-    if (p.hop == 1024 && p.out_cols) hipLaunchKernelGGL((k_fft4096_ms1<4, SS_MS1_TW, true>), grid, block, 0, s, p);
+    if (p.hop == 1024 && p.out_cols) hipLaunchKernelGGL((k_fft4096_ms1<4, SS_COLS_TW, true>), grid, block, 0, s, p);
     else if (p.hop == 1024) hipLaunchKernelGGL((k_fft4096_ms1<4, SS_MS1_TW, false>), grid, block, 0, s, p);
     else if (p.hop == 512) hipLaunchKernelGGL(k_fft4096_ms<2>, grid, block, 0, s, p);
     else if (p.hop == 2048) hipLaunchKernelGGL(k_fft4096_ms<8>, grid, block, 0, s, p);

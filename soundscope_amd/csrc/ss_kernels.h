@@ -63,8 +63,8 @@ struct FftBatchParams {
     float *out_cols;             // nullptr: ordinary rows into `out`
     const uint16_t *bin_col;     // bin_stride entries: chart column of every retained bin, 0xFFFF for the row padding
     const uint2 *col_groups;     // bin_stride / 4 entries, one per group of four bins: x = o0 | o3 << 16 (byte offsets, 4 x column, of the
-                                 // first / last bin's column in a row's accumulators), y = n | general << 8 (n bins lie in the first
-                                 // column, the rest in the last; general: the group holds more columns, or row padding)
+                                 // first / last bin's column in a row's accumulators), y = n: n bins lie in the first column, the rest in the
+                                 // last; n = 0: a general group (more columns inside it, or row padding)
     const uint2 *col_bins;       // the same per bin: four u16 byte offsets per group, 2048 (a spare slot) for the row padding
     const float *col_init;       // cols entries: -inf where the column owns a bin, NaN where it owns none
     const double *integrated;    // per stream: gain = -13 - (float)integrated (tui.rs:1234); nullptr: gain_db for all
