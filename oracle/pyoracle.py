@@ -39,6 +39,7 @@ def _load(native: bool = False):
     lib.so_meter_new_ex.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]
     lib.so_meter_free.argtypes = [vp]
     lib.so_meter_reset.argtypes = [vp]
+    lib.so_meter_set_ftz.argtypes = [vp, C.c_int]
     lib.so_meter_add_frames_f32.argtypes = [vp, f32p, C.c_size_t]
     for n in ("momentary", "shortterm", "global", "range"):
         getattr(lib, "so_meter_loudness_" + n).argtypes = [vp, f64p]
@@ -170,6 +171,13 @@ class Meter:
 
     def reset(self):
         lib().so_meter_reset(self._h)
+
+    def set_ftz(self, per_op):
+        """False: sub-normal filter state flushed at the end of every internal filter call (default; the crate without SSE2);
+        True: MXCSR flush-to-zero during the call (the crate's x86 build)."""
+        rc = lib().so_meter_set_ftz(self._h, 1 if per_op else 0)
+        if rc:
+            raise OracleError(rc)
 
     def add_frames(self, x):
         x, xp = _f32(x)

@@ -373,6 +373,7 @@ struct so_meter {
     double v[64][5];
     double sample_peak[64], true_peak[64];
     uint64_t block_hist[HIST_BINS], st_hist[HIST_BINS];
+    int ftz_mode;                /* SO_FTZ_*: how sub-normal filter state is flushed (so_meter_set_ftz) */
     /* true-peak interpolator */
     int tp_factor, tp_delay, tp_zi;
     interp_phase tp_phase[4];
@@ -513,6 +514,13 @@ void so_meter_reset(so_meter *m)
     m->tp_zi = 0;
 }
 
+int so_meter_set_ftz(so_meter *m, int mode)
+{
+    if (!m || (mode != SO_FTZ_END_OF_CALL && mode != SO_FTZ_PER_OP)) return SO_ERR_INVALID_MODE;
+    m->ftz_mode = mode;
+    return SO_OK;
+}
+
 void so_meter_filter_coeffs(so_meter *m, double b[5], double a[5])
 {
     memcpy(b, m->b, sizeof m->b); memcpy(a, m->a, sizeof m->a);
@@ -530,6 +538,11 @@ int so_meter_filter_state(so_meter *m, uint32_t ch, double v4[4])
  * (DF-II, f64) into the ring buffer at audio_data_index. */
 static void filter_process(so_meter *m, const float *src, size_t frames)
 {
+#if defined(__x86_64__) && defined(__SSE2_MATH__)
+    /* SO_FTZ_PER_OP: flush-to-zero for the whole of Filter::process (peaks, interpolator, filter), like the crate's x86 build */
+    unsigned int mxcsr_saved = 0;
+    if (m->ftz_mode == SO_FTZ_PER_OP) { mxcsr_saved = __builtin_ia32_stmxcsr(); __builtin_ia32_ldmxcsr(mxcsr_saved | 0x8000u); }
+#endif
     const uint32_t C = m->channels;
     /* sample peak */
     for (uint32_t c = 0; c < C; c++) {
@@ -566,20 +579,46 @@ static void filter_process(so_meter *m, const float *src, size_t frames)
         }
         m->tp_zi = zi;
     }
-    /* K-weighting */
+    /* K-weighting.  Sub-normals, [RECALLED] from ebur128 0.1.10's filter.rs (after libebur128's TURN_ON_FTZ / FLUSH_MANUALLY):
+     *   SO_FTZ_END_OF_CALL  builds without SSE2 (and the crate's own fallback): gradual underflow inside the call, the four
+     *                       state variables flushed to zero at its end;
+     *   SO_FTZ_PER_OP       x86 / x86-64 builds (what a user of the reference runs): MXCSR.FTZ is set for the duration of
+     *                       Filter::process, every sub-normal RESULT of an SSE operation becomes a signed zero, and there is
+     *                       no flush at the end.  Restated with the hardware bit itself where this file is built for x86-64
+     *                       (the loop below is SSE2 scalar arithmetic, -ffp-contract=off), by a per-operation software flush
+     *                       elsewhere.
+     * The two differ only while the state decays through 2.2e-308 .. 4.9e-324 (about 2.9 s of digital silence behind a
+     * programme at 48 kHz): the filtered samples there square to zero in either, so no reading of the meter can tell them
+     * apart — tests/test_oracle_known_answers.py::test_filter_ftz_models_agree_on_every_reading pins that. */
     const double *a = m->a, *b = m->b;
     double *dst = m->audio_data + m->audio_data_index;
+#if defined(__x86_64__) && defined(__SSE2_MATH__)
+#define SO_FZ(x) (x)
+#else
+#define SO_FZ(x) ((m->ftz_mode == SO_FTZ_PER_OP && fabs(x) < DBL_MIN) ? copysign(0.0, (x)) : (x))
+#endif
     for (uint32_t c = 0; c < C; c++) {
         if (m->channel_map[c] == CH_UNUSED) continue;
         double *v = m->v[c];
         for (size_t i = 0; i < frames; i++) {
-            v[0] = (double)src[i * C + c] - a[1] * v[1] - a[2] * v[2] - a[3] * v[3] - a[4] * v[4];
-            dst[i * C + c] = b[0] * v[0] + b[1] * v[1] + b[2] * v[2] + b[3] * v[3] + b[4] * v[4];
+            double t = (double)src[i * C + c];
+            t = SO_FZ(t - SO_FZ(a[1] * v[1])); t = SO_FZ(t - SO_FZ(a[2] * v[2]));
+            t = SO_FZ(t - SO_FZ(a[3] * v[3])); t = SO_FZ(t - SO_FZ(a[4] * v[4]));
+            v[0] = t;
+            double y = SO_FZ(b[0] * v[0]);
+            y = SO_FZ(y + SO_FZ(b[1] * v[1])); y = SO_FZ(y + SO_FZ(b[2] * v[2]));
+            y = SO_FZ(y + SO_FZ(b[3] * v[3])); y = SO_FZ(y + SO_FZ(b[4] * v[4]));
+            dst[i * C + c] = y;
             v[4] = v[3]; v[3] = v[2]; v[2] = v[1]; v[1] = v[0];
         }
-        /* denormal flush after every call */
-        for (int k = 1; k <= 4; k++) if (fabs(v[k]) < DBL_MIN) v[k] = 0.0;
+        /* denormal flush after every call (the build without hardware flush-to-zero) */
+        if (m->ftz_mode == SO_FTZ_END_OF_CALL)
+            for (int k = 1; k <= 4; k++) if (fabs(v[k]) < DBL_MIN) v[k] = 0.0;
     }
+#undef SO_FZ
+#if defined(__x86_64__) && defined(__SSE2_MATH__)
+    if (m->ftz_mode == SO_FTZ_PER_OP) __builtin_ia32_ldmxcsr(mxcsr_saved);
+#endif
 }
 
 /* calc_gating_block: mean square over the last frames_per_block frames of the

@@ -84,6 +84,11 @@ int so_meter_sample_peak(so_meter *m, uint32_t ch, double *out);
 int so_meter_true_peak(so_meter *m, uint32_t ch, double *out);
 const uint64_t *so_meter_block_hist(so_meter *m);   /* 1000 bins */
 const uint64_t *so_meter_st_hist(so_meter *m);      /* 1000 bins */
+/* sub-normal handling of the K-weighting filter: SO_FTZ_END_OF_CALL (default: the state flushed at the end of every internal
+ * filter call, the crate's build without SSE2 — and what the device path restates) or SO_FTZ_PER_OP (MXCSR flush-to-zero for the
+ * duration of the call, the crate's x86 build; see filter_process) */
+enum { SO_FTZ_END_OF_CALL = 0, SO_FTZ_PER_OP = 1 };
+int so_meter_set_ftz(so_meter *m, int mode);
 void so_meter_filter_coeffs(so_meter *m, double b[5], double a[5]);
 /* carried DF-II state v1..v4 of one channel after the last add_frames (sub-normals flushed like ebur128's Filter::process) */
 int so_meter_filter_state(so_meter *m, uint32_t ch, double v4[4]);

@@ -416,3 +416,39 @@ def test_integrated_and_lra_match_exact_numpy_bs1770(oracle, seed, rate):
     integ, lra = _bs1770_exact(x, rate, b, a)
     assert m.integrated() == pytest.approx(integ, abs=0.1)
     assert m.loudness_range() == pytest.approx(lra, abs=0.2)
+
+
+@pytest.mark.parametrize("rate,slice_len", [(48000, 16384), (44100, 8820), (96000, 16384)])
+def test_filter_ftz_models_agree_on_every_reading(oracle, rate, slice_len):
+    """The two sub-normal models of the K-weighting filter (oracle/ss_oracle.c filter_process): the state flushed at the end of
+    every internal filter call (the crate built without SSE2 — the oracle's default, and what the device path restates) and
+    MXCSR flush-to-zero for the duration of the call (the crate's x86 build, [RECALLED]).  A programme that decays into digital
+    silence walks the carried state through the whole sub-normal range: every reading of the meter (momentary, short-term,
+    integrated, range, peaks) must be IDENTICAL in both models after every call — the filtered samples down there square to
+    zero either way — and the carried states may differ only below 1e-300: the end-of-call model reaches exactly zero and stays
+    there, the per-operation model does NOT (flushed differences break the cancellation of the near-double pole; the state
+    wanders between 1e-304 and 1e-308 for as long as the silence lasts — a limit cycle no reading can see)."""
+    rng = np.random.default_rng(5)
+    n = rate * 6
+    x = np.zeros(2 * n, np.float32)
+    burst = rate // 2
+    x[:2 * burst] = (0.4 * rng.uniform(-1, 1, 2 * burst)).astype(np.float32)          # half a second of programme, then exact zeros
+    a, b = oracle.Meter(2, rate), oracle.Meter(2, rate)
+    b.set_ftz(True)
+    tiny = 2.2250738585072014e-308
+    seen_subnormal_gap = False
+    for off in range(0, x.size, slice_len):
+        a.add_frames(x[off:off + slice_len]); b.add_frames(x[off:off + slice_len])
+        for name in ("momentary", "shortterm", "integrated", "loudness_range"):
+            va, vb = getattr(a, name)(), getattr(b, name)()
+            assert va == vb or (np.isnan(va) and np.isnan(vb)), (name, off, va, vb)
+        for c in range(2):
+            assert a.true_peak(c) == b.true_peak(c) and a.sample_peak(c) == b.sample_peak(c)
+            sa, sb = a.filter_state(c), b.filter_state(c)
+            differ = sa != sb
+            if differ.any():
+                seen_subnormal_gap = True
+                assert np.all((np.abs(sa[differ]) < 1e-300) & (np.abs(sb[differ]) < 1e-300)), (off, c, sa, sb)
+            assert not np.any((np.abs(sa) < tiny) & (sa != 0.0)), (off, c, sa)          # end-of-call model: no sub-normal is carried
+    assert not a.filter_state(0).any()                                                  # the end-of-call model ends at exactly zero
+    assert seen_subnormal_gap and np.abs(b.filter_state(0)).max() < 1e-300              # the per-operation model near DBL_MIN

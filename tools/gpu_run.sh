@@ -19,6 +19,8 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p "$out"
 cd "$root"
+# the toolchain that would pin the oracle (tools/pin_from_crates/run.sh): reported on every call, so that the day a box has it is noticed
+echo "rust toolchain on this box: cargo=$(command -v cargo || echo none) rustc=$(command -v rustc || echo none)" | tee "$out/00_toolchain.log"
 i=0
 for step in "$@"; do
   i=$((i + 1))
