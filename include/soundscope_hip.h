@@ -367,13 +367,18 @@ double ss_corpus_loudness_range(const uint64_t *st_hist1000);
  *  ranks poll for it.  ss_comm_init_from_env derives rank / world from RANK / WORLD_SIZE and the file name from
  *  the launcher's process id and MASTER_PORT (torchrun as a launcher only), or takes SS_COMM_FILE.
  *  Environment: RCCL across processes needs HSA_ENABLE_IPC_MODE_LEGACY=0 on hosts whose driver has only dmabuf IPC, and
- *  the HSA runtime reads it at the process' first HIP call.  Loading the library changes nothing in the environment;
- *  ss_comm_init (RCCL, world > 1) sets the variable if it is unset — call it before any other entry point that touches
- *  the GPU, or export the variable in the launcher.
+ *  the HSA runtime reads it at the process' first HIP call.  Loading the library changes nothing in the environment; the
+ *  ss_comm_init* calls (RCCL, world > 1) set the variable if it is unset, which is in time only when they make the process'
+ *  FIRST HIP call.  A rank therefore does NOT call ss_set_device first: ss_comm_init_on_device(…, device, …) and
+ *  ss_comm_init_from_env (device = SS_COMM_DEVICE, else LOCAL_RANK) make the rank's GPU current themselves, behind the
+ *  setenv; plain ss_comm_init keeps whatever device is current (for callers that export the variable in the launcher, as
+ *  bench.py does).  When the variable is wrong the failure surfaces as "hipIpcGetMemHandle: invalid argument" inside
+ *  ncclCommInitRank; the error text of a failed init names the variable.
  * ------------------------------------------------------------------------- */
 typedef struct ss_comm ss_comm;
 enum { SS_COMM_RCCL = 0, SS_COMM_HOST_TCP = 1 };
 int ss_comm_init(int transport, int rank, int world, const char *rendezvous_file, ss_comm **out);
+int ss_comm_init_on_device(int transport, int rank, int world, int device, const char *rendezvous_file, ss_comm **out);
 int ss_comm_init_from_env(int transport, ss_comm **out);
 void ss_comm_destroy(ss_comm *c);
 int ss_comm_rank(const ss_comm *c);

@@ -37,7 +37,7 @@ SYMBOLS = [
     "ss_host_register", "ss_host_unregister", "ss_batch_upload_pcm_async",
     "ss_batch_set_lengths", "ss_batch_stream_shape", "ss_batch_upload_samples",
     "ss_device_synchronize", "ss_batch_peaks", "ss_batch_geometry_get", "ss_batch_set_overlap",
-    "ss_comm_init", "ss_comm_init_from_env", "ss_comm_destroy", "ss_comm_rank", "ss_comm_size",
+    "ss_comm_init", "ss_comm_init_on_device", "ss_comm_init_from_env", "ss_comm_destroy", "ss_comm_rank", "ss_comm_size",
     "ss_comm_transport_name", "ss_comm_library_version", "ss_comm_barrier", "ss_comm_allreduce_u64_sum", "ss_comm_allreduce_f64_max",
     "ss_batch_allreduce_histograms", "ss_batch_traffic_floor",
     "ss_batch_corpus_gate_enqueue", "ss_batch_corpus_gate_read", "ss_batch_checksums", "ss_inspect_filter_state", "ss_batch_set_true_peak_arith", "ss_batch_get_true_peak_arith", "ss_batch_set_columns_gain",
@@ -195,6 +195,7 @@ def _bind(lib):
         "ss_batch_geometry_get": (C.c_int, [vp, C.POINTER(BatchGeometry)]),
         "ss_batch_set_overlap": (C.c_int, [vp, C.c_int]),
         "ss_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)]),
+        "ss_comm_init_on_device": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)]),
         "ss_comm_init_from_env": (C.c_int, [C.c_int, C.POINTER(vp)]),
         "ss_comm_destroy": (None, [vp]),
         "ss_comm_rank": (C.c_int, [vp]),

@@ -66,25 +66,33 @@ int handle_reset(ss_analyzer *h)
 int pin_ready(ss_analyzer *h)
 {
     if (h->pin_d) return SS_OK;
+    // Idempotent per resource: a call that failed part-way leaves what it got in the handle, and the next one allocates only what
+    // is still missing (nothing is leaked; ss_analyzer_destroy frees whatever is there).
+    auto host_alloc = [](auto **slot, size_t bytes) -> hipError_t {
+        return *slot ? hipSuccess : hipHostMalloc(reinterpret_cast<void **>(slot), bytes, hipHostMallocDefault);
+    };
+    auto event = [](hipEvent_t *e) -> hipError_t { return *e ? hipSuccess : hipEventCreateWithFlags(e, hipEventDisableTiming); };
     for (int i = 0; i < 2; i++) {
-        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->pin_in[i]), ss_analyzer::kPinFloats * sizeof(float), hipHostMallocDefault));
+        HIPCHK(host_alloc(&h->pin_in[i], ss_analyzer::kPinFloats * sizeof(float)));
         HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->pin_in_dev[i]), h->pin_in[i], 0));
-        HIPCHK(hipEventCreateWithFlags(&h->pin_ev[i], hipEventDisableTiming));
+        HIPCHK(event(&h->pin_ev[i]));
     }
-    HIPCHK(hipEventCreateWithFlags(&h->pin_ev[2], hipEventDisableTiming));       // behind a short-term / momentary reading
-    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->pin_out), (ss_analyzer::kPinFloats / 2 + 4) * sizeof(float), hipHostMallocDefault));
+    HIPCHK(event(&h->pin_ev[2]));                                                // behind a short-term / momentary reading
+    HIPCHK(host_alloc(&h->pin_out, (ss_analyzer::kPinFloats / 2 + 4) * sizeof(float)));
     HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->pin_out_dev), h->pin_out, 0));
-    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->pin_peaks), 2 * ssk::kMaxChannels * sizeof(float), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->pin_eval), 2 * sizeof(double), hipHostMallocDefault));
+    HIPCHK(host_alloc(&h->pin_peaks, 2 * ssk::kMaxChannels * sizeof(float)));
+    HIPCHK(host_alloc(&h->pin_eval, 2 * sizeof(double)));
     HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->pin_eval_dev), h->pin_eval, 0));
     HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->pin_peaks_dev), h->pin_peaks, 0));
-    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->pin_flag), sizeof(uint32_t), hipHostMallocDefault));
-    *h->pin_flag = 0u;
+    if (!h->pin_flag) {
+        HIPCHK(host_alloc(&h->pin_flag, sizeof(uint32_t)));
+        *h->pin_flag = 0u;
+    }
     HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->pin_flag_dev), h->pin_flag, 0));
-    double *d = nullptr;
-    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&d), 2 * sizeof(double), hipHostMallocDefault));
-    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->pin_d_dev), d, 0));
-    h->pin_d = d;                               // (last: "ready" means all of them)
+    HIPCHK(host_alloc(&h->pin_d_pending, 2 * sizeof(double)));
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->pin_d_dev), h->pin_d_pending, 0));
+    h->pin_d = h->pin_d_pending;                // (last: "ready" means all of them)
+    h->pin_d_pending = nullptr;
     return SS_OK;
 }
 
@@ -176,6 +184,7 @@ void ss_analyzer_destroy(ss_analyzer *h)
     if (h->pin_eval) (void)hipHostFree(h->pin_eval);
     if (h->pin_flag) (void)hipHostFree(h->pin_flag);
     if (h->pin_d) (void)hipHostFree(h->pin_d);
+    if (h->pin_d_pending) (void)hipHostFree(h->pin_d_pending);
     delete h;
 }
 
@@ -408,7 +417,7 @@ int ssh::add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool o
                           TickExtras *tick)
 {
     if (deferred) deferred->n_streams = 0;
-    if (tick) tick->fused = false;
+    if (tick) { tick->fused = false; tick->st_fused = false; }
     SS_ON_DEVICE(h);
     if (!h) return SS_ERR_INVALID_ARG;
     if (!h->meter_ok) return SS_ERR_INVALID_MODE;
@@ -465,6 +474,7 @@ int ssh::add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool o
             p.st_blocks = ssk::kRingTickBlocks;
         }
         HIPCHK(ssk::launch_time_domain(p, h->stream, with_tick ? tick->fft : nullptr, with_tick ? &tick->fused : nullptr));
+        if (with_tick) tick->st_fused = tick->fused && p.st_out != nullptr;
         const uint64_t sb0 = h->frames_fed / S, sb1 = (h->frames_fed + take) / S;
         if (sb1 > sb0) {
             ssk::FinalizeParams f{};

@@ -352,7 +352,7 @@ void ss_comm_destroy(ss_comm *c)
     delete c;
 }
 
-int ss_comm_init(int transport, int rank, int world, const char *rendezvous_file, ss_comm **out)
+static int comm_init_impl(int transport, int rank, int world, int device, const char *rendezvous_file, ss_comm **out)
 {
     if (!out) return SS_ERR_INVALID_ARG;
     *out = nullptr;
@@ -368,6 +368,9 @@ int ss_comm_init(int transport, int rank, int world, const char *rendezvous_file
     if (transport == SS_COMM_RCCL) {
         if (world > 1) default_hsa_ipc_mode();            // before this call's (possibly the process' first) HIP call
         if (ss_device_count() <= 0) return SS_ERR_DEVICE;
+        // device >= 0 (ss_comm_init_on_device, ss_comm_init_from_env): this call makes the rank's GPU current ITSELF, behind the
+        // setenv above — the order a rank off device 0 cannot get by calling ss_set_device first (that call starts the HSA runtime)
+        if (device >= 0) COMM_HIP(hipSetDevice(device));
         COMM_HIP(hipGetDevice(&c->device));
         if (!rccl_open(c->rccl, err)) return fail(err);
         if (rank == 0) COMM_NCCL(c, c->rccl.GetUniqueId(&id));
@@ -419,7 +422,14 @@ int ss_comm_init(int transport, int rank, int world, const char *rendezvous_file
         if (fut.wait_for(std::chrono::seconds(join_timeout_s())) != std::future_status::ready) { verdict = SS_ERR_DEVICE; why = "ncclCommInitRank: timed out"; }
         else {
             const ncclResult_t r = fut.get();
-            if (r != ncclSuccess) { verdict = SS_ERR_DEVICE; why = std::string("ncclCommInitRank: ") + c->rccl.GetErrorString(r); }
+            if (r != ncclSuccess) {
+                verdict = SS_ERR_DEVICE;
+                why = std::string("ncclCommInitRank: ") + c->rccl.GetErrorString(r);
+                const char *ipc = std::getenv("HSA_ENABLE_IPC_MODE_LEGACY");
+                why += std::string(" (HSA_ENABLE_IPC_MODE_LEGACY=") + (ipc ? ipc : "unset") +
+                       " in this process; dmabuf-only hosts need 0, in place before the process' first HIP call: export it in the launcher, "
+                       "or create the communicator with ss_comm_init_on_device / ss_comm_init_from_env BEFORE any other GPU call)";
+            }
             else c->comm = job->comm;
         }
         // all ranks succeed or all fail: the verdicts are summed over the join sockets
@@ -441,6 +451,17 @@ int ss_comm_init(int transport, int rank, int world, const char *rendezvous_file
 // Launchers that export RANK / WORLD_SIZE (torchrun, used purely as a process launcher): the rendezvous file is
 // SS_COMM_FILE if set, otherwise /tmp/ss_comm_<launcher pid>_<launcher start time>_<MASTER_PORT> — all ranks are
 // children of one launcher process, and the start time keeps a recycled pid from matching a stale file.
+int ss_comm_init(int transport, int rank, int world, const char *rendezvous_file, ss_comm **out)
+{
+    return comm_init_impl(transport, rank, world, -1, rendezvous_file, out);
+}
+
+int ss_comm_init_on_device(int transport, int rank, int world, int device, const char *rendezvous_file, ss_comm **out)
+{
+    if (device < 0) return SS_ERR_INVALID_ARG;
+    return comm_init_impl(transport, rank, world, device, rendezvous_file, out);
+}
+
 int ss_comm_init_from_env(int transport, ss_comm **out)
 {
     const char *r = std::getenv("RANK"), *w = std::getenv("WORLD_SIZE");
@@ -467,7 +488,11 @@ int ss_comm_init_from_env(int transport, ss_comm **out)
         const char *mp = std::getenv("MASTER_PORT");
         file = "/tmp/ss_comm_" + std::to_string(ppid) + "_" + std::to_string(start) + "_" + (mp ? mp : "0") + ".rdzv";
     }
-    return ss_comm_init(transport, rank, world, file.c_str(), out);
+    // the rank's GPU: SS_COMM_DEVICE, else LOCAL_RANK (one process per GPU), else whatever device is current
+    int device = -1;
+    if (const char *d = std::getenv("SS_COMM_DEVICE")) device = std::atoi(d);
+    else if (const char *l = std::getenv("LOCAL_RANK")) device = std::atoi(l);
+    return comm_init_impl(transport, rank, world, transport == SS_COMM_RCCL ? device : -1, file.c_str(), out);
 }
 
 int ss_comm_rank(const ss_comm *c) { return c ? c->rank : -1; }

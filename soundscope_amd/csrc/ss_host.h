@@ -208,6 +208,7 @@ struct ss_analyzer {
     int pin_next = 0;
     float *pin_out = nullptr, *pin_out_dev = nullptr;       // kPinFloats / 2 + 1 dB values
     double *pin_d = nullptr, *pin_d_dev = nullptr;          // a getter's pair of doubles
+    double *pin_d_pending = nullptr;                        // the same while pin_ready has not finished (pin_d set = all of them ready)
     float *pin_peaks = nullptr;                              // 2 * kMaxChannels floats: the state's peaks, copied there
     double *pin_eval = nullptr, *pin_eval_dev = nullptr;    // (integrated, range) of the state the readings were last asked for
     float *pin_peaks_dev = nullptr;
@@ -239,7 +240,8 @@ SS_HIDDEN int attach_readings(ss_analyzer *h, ssk::FinalizeParams *gating);
 struct TickExtras {
     const ssk::FftBatchParams *fft = nullptr;   // nullptr: no spectrum this tick (then nothing is fused)
     double *shortterm_out = nullptr;            // (energy, loudness), device-visible; nullptr: no reading wanted
-    bool fused = false;
+    bool fused = false;                         // out: the spectrum rode the loudness call's launch (k_tick)
+    bool st_fused = false;                      // out: ... and so did the short-term reading (its window parameters were set)
 };
 SS_HIDDEN int add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool on_device, ssk::FinalizeParams *deferred = nullptr,
                                TickExtras *tick = nullptr);

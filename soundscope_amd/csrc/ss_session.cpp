@@ -222,6 +222,8 @@ int ss_session_open_file(const float *interleaved, size_t n_samples, uint32_t ch
     HIPCHK(bad_list.alloc(kBadCap));
     HIPCHK(ssk::launch_nonfinite_pairs(s->pcm.p, pairs, bad_count.p, bad_list.p, kBadCap, h->stream));
     uint32_t n_bad = 0;
+    // (the copy below targets this stack variable: whatever way this function is left, the stream is drained first)
+    struct DrainOnExit { hipStream_t st; ~DrainOnExit() { (void)hipStreamSynchronize(st); } } drain_guard{h->stream};
     HIPCHK(hipMemcpyAsync(&n_bad, bad_count.p, sizeof n_bad, hipMemcpyDeviceToHost, h->stream));
     // AudioFile::from_file: duration = mid.len() / rate * 1000. ms, truncated (audio_player.rs:153-161)
     const double dur_ms = (double)pairs / (double)sample_rate * 1000.0;
@@ -285,6 +287,9 @@ int ss_session_open_capture(uint32_t channels, uint32_t sample_rate, ss_session 
     HIPCHK(s->pcm.alloc(s->n_samples));
     HIPCHK(hipMemset(s->pcm.p, 0, s->n_samples * sizeof(float)));      // the reference's ring starts full of zeros (tui.rs:1783-1784)
     s->tail.assign((size_t)2 * SS_TICK_WINDOW, 0.0f);
+    // what the capture callback pushes between two ticks: page-locked, allocated HERE — ss_session_capture_push stands in for the
+    // audio callback's audio_buf.extend (a real-time thread) and must not call into the driver
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->pending), s->n_samples * sizeof(float), hipHostMallocDefault));
     size_t window, bins;
     waveform_shape(s->n_samples / 2, 15.0, &window, &bins);
     rc = session_stage(s.get(), (size_t)2 * s->bin_stride + 2 * bins);
@@ -400,6 +405,13 @@ int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side
     const size_t pos_i = pos_f * s->file_channels;
     const size_t lufs_lb = pos_i > SS_TICK_WINDOW ? pos_i - SS_TICK_WINDOW : 0;
     ssk::FinalizeParams gating{};
+    // The gating of this tick's new sub-blocks is handed back by add_samples_impl AFTER frames_fed has advanced: if the tick is
+    // left early (a failed launch, an event error) it is still launched — otherwise those sub-blocks would be missing from the
+    // histograms for the rest of the session.
+    struct DeferredGating {
+        ss_analyzer *h; ssk::FinalizeParams *g; bool launched = false;
+        ~DeferredGating() { if (!launched && g->n_streams) (void)ssk::launch_finalize(*g, h->stream); }
+    } gating_guard{h, &gating};
     if (lufs_lb != 0) {
         res->lufs_ran = 1;
         std::memmove(&s->lufs[0], &s->lufs[1], (SS_LUFS_HISTORY - 1) * sizeof(double));
@@ -411,7 +423,8 @@ int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side
             res->add_status = add_samples_impl(h, s->pcm.p + lufs_lb, SS_TICK_WINDOW, true, &gating, &extras);
             if (res->add_status == SS_ERR_DEVICE) return SS_ERR_DEVICE;
             if (res->add_status == SS_OK) any_launch = true;
-            if (extras.fused) { fft_launched = true; st_launched = true; }
+            if (extras.fused) fft_launched = true;
+            if (extras.st_fused) st_launched = true;
         }
     }
     SS_TICK_T(1);
@@ -436,6 +449,7 @@ int ss_session_tick_file(ss_session *s, size_t pos, double *mid_xy, double *side
     if (gating.n_streams) {
         int rc = attach_readings(h, &gating);
         if (rc) return rc;
+        gating_guard.launched = true;
         HIPCHK(ssk::launch_finalize(gating, h->stream));
     }
     SS_TICK_T(3);
@@ -496,12 +510,20 @@ static int capture_tick_body(ss_session *s, const float *newest, double *mid_xy,
     bool fft_launched = false, st_launched = false;
     std::memmove(&s->lufs[0], &s->lufs[1], (SS_LUFS_HISTORY - 1) * sizeof(double));
     ssk::FinalizeParams gating{};
+    // The gating of this tick's new sub-blocks is handed back by add_samples_impl AFTER frames_fed has advanced: if the tick is
+    // left early (a failed launch, an event error) it is still launched — otherwise those sub-blocks would be missing from the
+    // histograms for the rest of the session.
+    struct DeferredGating {
+        ss_analyzer *h; ssk::FinalizeParams *g; bool launched = false;
+        ~DeferredGating() { if (!launched && g->n_streams) (void)ssk::launch_finalize(*g, h->stream); }
+    } gating_guard{h, &gating};
     TickExtras extras;
     extras.fft = fft_wanted ? &fft_p : nullptr;
     extras.shortterm_out = s->stage_d_dev;
     res->add_status = add_samples_impl(h, s->pcm.p + (n - SS_TICK_WINDOW), SS_TICK_WINDOW, true, &gating, &extras);
     if (res->add_status == SS_ERR_DEVICE) return SS_ERR_DEVICE;
-    if (extras.fused) { fft_launched = true; st_launched = true; }
+    if (extras.fused) fft_launched = true;
+    if (extras.st_fused) st_launched = true;
     if (fft_wanted && !fft_launched) {
         HIPCHK(ssk::launch_fft16k(fft_p, 1, h->stream));
         fft_launched = true;
@@ -526,6 +548,7 @@ static int capture_tick_body(ss_session *s, const float *newest, double *mid_xy,
     if (gating.n_streams) {
         int rc = attach_readings(h, &gating);
         if (rc) return rc;
+        gating_guard.launched = true;
         HIPCHK(ssk::launch_finalize(gating, h->stream));
     }
     if (res->add_status == SS_OK && h->prefetch_stamp != h->change_count) { int rc = prefetch_readings(h); if (rc) return rc; }
@@ -594,11 +617,10 @@ int ss_session_tick_capture(ss_session *s, const float *latest, size_t n, double
 // kept (page-locked) until the next tick moves the ring.  Host work only; as with every call on a session, one caller at a time.
 int ss_session_capture_push(ss_session *s, const float *samples, size_t n)
 {
-    SS_ON_DEVICE(s);
-    if (!s || s->is_file || (!samples && n)) return SS_ERR_INVALID_ARG;
+    // host work only (two memcpy): no HIP call, nothing that can block or fail on the capture callback's thread
+    if (!s || s->is_file || !s->pending || (!samples && n)) return SS_ERR_INVALID_ARG;
     if (n == 0) return SS_OK;
     const size_t N = s->n_samples;
-    if (!s->pending) HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->pending), N * sizeof(float), hipHostMallocDefault));
     if (n >= N) {                                                // more than a whole ring at once: its newest N samples are the ring
         std::memcpy(s->pending, samples + (n - N), N * sizeof(float));
         s->pending_n = N;

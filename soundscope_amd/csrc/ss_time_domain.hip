@@ -229,7 +229,32 @@ struct TdShare {
     uint32_t waves_done;                 // waves whose share stands in call_e
 };
 
-// A tick's short-term reading, first part (k_tick's workgroups behind the loudness call's): the weighted energy of the ring over
+// A tick's short-term reading is summed by whichever of its st_blocks + 1 contributors (the ring workgroups below, the loudness
+// call's workgroup) ARRIVES LAST — nobody waits for anybody, so the launch cannot hang where the workgroups are not all resident
+// at once (CU masking, a tiny partition, a debugger).  A contributor leaves its share in st_scratch (ring workgroup r: slot r,
+// the loudness call: slot kRingTickBlocks + 1), makes it visible to the device and counts itself in; the one that reads
+// st_blocks from the counter adds everything in a fixed order (the same tree whoever runs it) and writes (energy, loudness).
+__device__ __forceinline__ bool tick_reading_arrive(const TdParams &p)
+{
+    __threadfence();                                                       // the share is visible before the count
+    uint32_t *const count = reinterpret_cast<uint32_t *>(p.st_scratch + kRingTickBlocks);
+    return __hip_atomic_fetch_add(count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == p.st_blocks;
+}
+// one whole wave of the last contributor
+__device__ __forceinline__ void tick_reading_finish(const TdParams &p, uint32_t lane)
+{
+    double pr = lane < p.st_blocks ? __builtin_nontemporal_load(p.st_scratch + lane) : 0.0;
+    for (int d = 32; d >= 1; d >>= 1) pr += __shfl_down(pr, d, 64);
+    if (lane == 0) {
+        const double tot = __builtin_nontemporal_load(p.st_scratch + kRingTickBlocks + 1);
+        const double en = (pr + tot) / p.st_frames;
+        p.st_out[0] = en;
+        p.st_out[1] = en <= 0.0 ? -INFINITY : 10.0 * log10(en) - 0.691;      // energy_to_loudness
+        __hip_atomic_store(reinterpret_cast<uint32_t *>(p.st_scratch + kRingTickBlocks), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// first part (k_tick's workgroups behind the loudness call's): the weighted energy of the ring over
 // the frames of the window that lie IN FRONT of this call — which the call does not touch, so these workgroups run beside it.
 // One run of ring elements with at most one wrap, like k_ring_energy (ss_loudness.hip); block r of `blocks` leaves its partial
 // sum in scratch[r] and counts itself in behind it.
@@ -267,13 +292,15 @@ __device__ __forceinline__ void ring_window_partial(const TdParams &p, uint32_t 
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_down(acc, d, 64);
     if ((threadIdx.x & 63u) == 0u) red[threadIdx.x >> 6] = acc;
     __syncthreads();
+    __shared__ uint32_t last_here;
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int w = 0; w < kTdSplitWaves; w++) t += red[w];
         p.st_scratch[r] = t;
-        __threadfence();                                                   // the partial sum is visible before the count
-        atomicAdd(reinterpret_cast<unsigned int *>(p.st_scratch + kRingTickBlocks), 1u);
+        last_here = tick_reading_arrive(p) ? 1u : 0u;
     }
+    __syncthreads();
+    if (last_here && threadIdx.x < 64u) tick_reading_finish(p, threadIdx.x);
 }
 
 template <int FACTOR, bool RING, int CT, int WAVE, int WPS, bool SPLIT = false>
