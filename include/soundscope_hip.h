@@ -303,12 +303,32 @@ typedef struct ss_batch_geometry {
     uint32_t fft_blocks;             /* spectrum workgroups per pass                                  */
     uint32_t td_segments;            /* time segments per stream in the time-domain kernel            */
     uint32_t td_segment_subblocks;   /* 100 ms sub-blocks per segment (0: one segment)                */
-    uint32_t td_warm_subblocks;      /* filter run-in of segments > 0                                 */
+    uint32_t td_warm_subblocks;      /* filter run-in of segments > 0 (SS_TD_RUN_IN only)             */
     uint32_t td_true_peak_factor;    /* 0, 2, 4                                                       */
     uint32_t waveform_fused;         /* 1: decimation runs inside the time-domain kernel              */
     uint32_t overlap;                /* ss_batch_set_overlap mode: 0, 1 or 2                          */
-} ss_batch_geometry;                 /* 32 bytes */
+    uint32_t td_split;               /* 1: a stream is one segment walked by the four waves of a workgroup, the filter state handed
+                                      *    from tile to tile (the whole recurrence: no run-in); td_segments is 1 then              */
+    uint32_t td_fixup_subblocks;     /* sub-blocks at the head of every segment > 0 re-run from the exact state by the second launch */
+} ss_batch_geometry;                 /* 40 bytes (32 up to ABI version 1) */
 int ss_batch_geometry_get(const ss_batch *b, ss_batch_geometry *out);
+/* how the time-domain kernel walks a stream.  The K-weighting recurrence has a long memory (poles at |z| = 0.995): a stream cut
+ * into time segments for parallelism must hand the filter state from one segment to the next.
+ *   SS_TD_AUTO (default)   time segments, one wave each, EXACT hand-over: every segment starts at its boundary from a zero state,
+ *                          leaves its end state behind, and a second light launch re-runs the first 0.2 s of every segment > 0 from
+ *                          the state the segment in front of it left, overwriting those sub-blocks' energies (after 0.2 s the
+ *                          zero start differs from the true trajectory by e^-48 of the state: 1e-13 of the filtered signal on
+ *                          DC-offset material, under the 2e-11 at which any two evaluation orders of this recurrence differ).
+ *                          Segment 0 and the re-run head of segment 1 equal the one-segment path bit for bit; elsewhere the
+ *                          difference is the rounding noise of the recurrence (3e-10 at worst on the bench corpus, the same as
+ *                          for the exact-by-construction SS_TD_WHOLE_STREAMS), not a dropped term (tests pin both).
+ *   SS_TD_RUN_IN           the form of rounds 1-4, kept for comparison: a segment > 0 starts its filter 0.1 s early from a zero
+ *                          state and drops that run-in (3e-10 on sub-block energies of DC-offset material: a truncation).
+ *   SS_TD_WHOLE_STREAMS    stereo / eight channels, equal lengths: a stream is ONE segment walked by the four waves of a
+ *                          workgroup, the state handed from tile to tile through LDS — exact by construction, but the waves of a
+ *                          workgroup wait for each other: 16 % slower at the bench shape than independent segment waves. */
+enum { SS_TD_AUTO = 0, SS_TD_RUN_IN = 1, SS_TD_WHOLE_STREAMS = 2 };
+int ss_batch_set_time_domain_mode(ss_batch *b, int mode);
 /* how a pass is laid over the batch's two HIP streams; results are identical in every mode.
  *   0  sequential: spectrum kernel, then the time-domain chain (default);
  *   1  the spectrum kernel on a second stream beside the whole time-domain chain (they use different pipes: packed f32

@@ -40,7 +40,7 @@ SYMBOLS = [
     "ss_comm_init", "ss_comm_init_on_device", "ss_comm_init_from_env", "ss_comm_destroy", "ss_comm_rank", "ss_comm_size",
     "ss_comm_transport_name", "ss_comm_library_version", "ss_comm_barrier", "ss_comm_allreduce_u64_sum", "ss_comm_allreduce_f64_max",
     "ss_batch_allreduce_histograms", "ss_batch_traffic_floor",
-    "ss_batch_corpus_gate_enqueue", "ss_batch_corpus_gate_read", "ss_batch_checksums", "ss_inspect_filter_state", "ss_batch_set_true_peak_arith", "ss_batch_get_true_peak_arith", "ss_batch_set_columns_gain",
+    "ss_batch_corpus_gate_enqueue", "ss_batch_corpus_gate_read", "ss_batch_checksums", "ss_inspect_filter_state", "ss_batch_set_true_peak_arith", "ss_batch_get_true_peak_arith", "ss_batch_set_time_domain_mode", "ss_batch_set_columns_gain",
     "ss_inspect_kweight", "ss_inspect_true_peak", "ss_inspect_hann", "ss_inspect_bins", "ss_inspect_histogram",
 ]
 
@@ -56,6 +56,7 @@ SS_PCM_U8, SS_PCM_S16, SS_PCM_S24, SS_PCM_S32, SS_PCM_F32, SS_PCM_F64 = 1, 2, 3,
 SS_GAIN_FIXED, SS_GAIN_REFERENCE = 0, 1
 SS_COMM_RCCL, SS_COMM_HOST_TCP = 0, 1
 SS_TP_ARITH_F16X3, SS_TP_ARITH_F32 = 0, 1
+SS_TD_AUTO, SS_TD_RUN_IN, SS_TD_WHOLE_STREAMS = 0, 1, 2
 SS_KERNEL_FFT, SS_KERNEL_TIME_DOMAIN, SS_KERNEL_FINALIZE, SS_KERNEL_WAVEFORM, SS_KERNEL_COUNT = 0, 1, 2, 3, 4
 
 
@@ -93,7 +94,8 @@ class StreamShape(C.Structure):
 class BatchGeometry(C.Structure):
     _fields_ = [("fft_windows_per_block", C.c_uint32), ("fft_blocks", C.c_uint32), ("td_segments", C.c_uint32),
                 ("td_segment_subblocks", C.c_uint32), ("td_warm_subblocks", C.c_uint32),
-                ("td_true_peak_factor", C.c_uint32), ("waveform_fused", C.c_uint32), ("overlap", C.c_uint32)]
+                ("td_true_peak_factor", C.c_uint32), ("waveform_fused", C.c_uint32), ("overlap", C.c_uint32),
+                ("td_split", C.c_uint32), ("td_fixup_subblocks", C.c_uint32)]
 
 
 class BatchLayout(C.Structure):
@@ -214,6 +216,7 @@ def _bind(lib):
         "ss_batch_set_true_peak_arith": (C.c_int, [vp, C.c_int]),
         "ss_analyzer_set_true_peak_arith": (C.c_int, [vp, C.c_int]),
         "ss_batch_get_true_peak_arith": (C.c_int, [vp]),
+        "ss_batch_set_time_domain_mode": (C.c_int, [vp, C.c_int]),
         "ss_batch_set_columns_gain": (C.c_int, [vp, C.c_int, C.c_float]),
         "ss_inspect_kweight": (C.c_int, [C.c_uint32, f64p, f64p]),
         "ss_inspect_true_peak": (C.c_int, [C.c_int, f32p, C.c_uint32, C.POINTER(C.c_uint32)]),

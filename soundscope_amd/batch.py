@@ -107,6 +107,11 @@ class Batch:
         2: beside the chain's tail only (time-domain kernel first and alone).  Same results in every mode."""
         _check(L.lib().ss_batch_set_overlap(self._h, int(mode)))
 
+    def set_time_domain_mode(self, mode):
+        """L.SS_TD_AUTO (time segments with the exact state hand-over), L.SS_TD_RUN_IN (segments with the 0.1 s run-in of earlier
+        rounds, for comparison), L.SS_TD_WHOLE_STREAMS (a workgroup per stream, where the shape allows)."""
+        _check(L.lib().ss_batch_set_time_domain_mode(self._h, int(mode)))
+
     def set_true_peak_arith(self, arith):
         """L.SS_TP_ARITH_F32 (default: f32 MFMA, the width of the crate's interpolator) or L.SS_TP_ARITH_F16X3 (opt-in: f16x3
         split on the matrix cores, within 2^-21 of the tile peak of the f32 result, faster)."""

@@ -22,6 +22,8 @@ struct ss_batch {
     uint32_t wave_window = 0;
     uint32_t windows_per_block = 16;
     uint32_t td_nseg = 1, td_seg_sub = 0;
+    bool td_split = false;          // whole-stream workgroups (choose_td_geometry)
+    int td_mode = 0;                // ss_batch_set_time_domain_mode
     bool wave_fused = false;     // decimation runs inside the time-domain kernel
     uint32_t wave_halo = 0;
     FftTables *ft = nullptr;
@@ -30,6 +32,7 @@ struct ss_batch {
     DevBuf<float> pcm, fft, wave;
     DevBuf<ssk::TdState> state;
     DevBuf<double> sub, weights, integrated, lra, out2;
+    DevBuf<double> seg_state;       // [stream][segment][channel][4]: the filter state behind every time segment (exact hand-over)
     DevBuf<uint64_t> hist, corpus;
     DevBuf<uint32_t> counts;
     DevBuf<unsigned char> raw;      // device staging of raw PCM for the asynchronous ingest
@@ -99,6 +102,57 @@ int batch_collect_timing(ss_batch *b)
 }  // namespace
 
 extern "C" {
+
+// How the time-domain kernel walks a stream.
+//  * whole-stream workgroups (td_split): a stream is ONE segment, its tiles dealt to the four waves of a workgroup, the filter state
+//    and the lanes' energy shares handed from tile to tile through LDS — the whole recurrence, nothing truncated.  Needs enough
+//    streams to fill the chip with one workgroup each (n_streams x 4 waves against the W0 the chip holds); stereo and eight
+//    channels, equal lengths.
+//  * segments (the rest): a stream is cut into nseg runs of whole sub-blocks, one wave each; a segment > 0 starts its filter
+//    kTdWarmSub sub-blocks (0.1 s) early from a zero state and drops that run-in (what the missing history would add to the
+//    output has decayed to 1e-9 of a DC step by then, ss_time_domain.hip).  A segment costs its run-in; pick the segment
+//    length that maximises   useful fraction  seg / (seg + warm)  x  fill of the last round  waves / (ceil(waves / W0) W0)
+//    (ranks the measured config-5 sweep seg = 2..13 in the right order; measured within noise for config 3).
+// mode (ss_batch_set_time_domain_mode): 0 the better score of the two, 1 segments, 2 whole-stream workgroups where the shape allows.
+static void choose_td_geometry(ss_batch *b)
+{
+    if (!b->td) return;
+    const ss_batch_config *cfg = &b->cfg;
+    const ss_batch_layout &L = b->lay;
+    const uint32_t C = cfg->channels;
+    const uint32_t nsub = L.n_subblocks;
+    const double W0 = 256.0 * ssk::td_resident_waves_per_cu(C, b->td->host.s100, b->wave_fused ? b->wave_halo : 0);
+    auto score_of = [&](uint32_t seg, uint32_t nseg) {
+        const double waves = (double)cfg->n_streams * nseg;
+        const double useful = nseg > 1 ? (double)seg / (double)(seg + kTdWarmSub) : 1.0;
+        return useful * waves / (std::ceil(waves / W0) * W0);
+    };
+    uint32_t best_seg = 0;
+    double best = nsub ? score_of(nsub, 1) : 0.0;                         // one segment: no run-in
+    for (uint32_t want = 2; want <= nsub; want++) {                     // balanced segments: seg = ceil(nsub / want)
+        const uint32_t seg = (nsub + want - 1) / want;
+        if (seg < kTdWarmSub) break;
+        const double sc = score_of(seg, (nsub + seg - 1) / seg);
+        if (sc > best * 1.0000001) { best = sc; best_seg = seg; }
+    }
+#ifdef SS_TUNING
+    if (const char *e = std::getenv("SS_TD_SEG_SUB")) best_seg = (uint32_t)std::atoi(e);
+#endif
+    const bool split_ok = (C == 2 || C == 8) && nsub > 0;
+    const double wsplit = 4.0 * cfg->n_streams;
+    const double split_score = split_ok ? wsplit / (std::ceil(wsplit / W0) * W0) : 0.0;
+    // (measured at the bench shape: the coupled waves of a workgroup run 16 % behind independent segment waves — the chain makes a
+    // workgroup as slow as its slowest wave, tile by tile — so the automatic choice wants a clear win in fill)
+    b->td_split = split_ok && (b->td_mode == 2 || (b->td_mode == 0 && 0.8 * split_score > best));
+    if (b->td_split) {
+        b->td_nseg = 1; b->td_seg_sub = 0;
+    } else if (best_seg >= kTdWarmSub && best_seg < nsub) {
+        b->td_seg_sub = best_seg;
+        b->td_nseg = (nsub + best_seg - 1) / best_seg;
+    } else {
+        b->td_nseg = 1; b->td_seg_sub = 0;
+    }
+}
 
 int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
 {
@@ -256,36 +310,7 @@ int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
             if (halo <= 512) { b->wave_fused = true; b->wave_halo = halo; }
         }
     }
-    // time segments per stream.  A segment costs a kTdWarmSub-sub-block filter run-in and the chip holds W0
-    // waves at once (LDS per wave grows with channels and halo).  Pick the segment length that maximises
-    //   useful fraction  seg / (seg + warm)  x  fill of the last round  waves / (ceil(waves / W0) W0)
-    // (ranks the measured config-5 sweep seg = 2..13 in the right order; measured within noise for config 3)
-    if (b->td) {
-        const uint32_t nsub = L.n_subblocks;
-        const double W0 = 256.0 * ssk::td_resident_waves_per_cu(C, b->td->host.s100, b->wave_fused ? b->wave_halo : 0);
-        auto score_of = [&](uint32_t seg, uint32_t nseg) {
-            const double waves = (double)cfg->n_streams * nseg;
-            const double useful = nseg > 1 ? (double)seg / (double)(seg + kTdWarmSub) : 1.0;
-            return useful * waves / (std::ceil(waves / W0) * W0);
-        };
-        uint32_t best_seg = 0;
-        double best = nsub ? score_of(nsub, 1) : 0.0;                         // one segment: no run-in
-        for (uint32_t want = 2; want <= nsub; want++) {                     // balanced segments: seg = ceil(nsub / want)
-            const uint32_t seg = (nsub + want - 1) / want;
-            if (seg < kTdWarmSub) break;
-            const double sc = score_of(seg, (nsub + seg - 1) / seg);
-            if (sc > best * 1.0000001) { best = sc; best_seg = seg; }
-        }
-#ifdef SS_TUNING
-        if (const char *e = std::getenv("SS_TD_SEG_SUB")) best_seg = (uint32_t)std::atoi(e);
-#endif
-        if (best_seg >= kTdWarmSub && best_seg < nsub) {
-            b->td_seg_sub = best_seg;
-            b->td_nseg = (nsub + best_seg - 1) / best_seg;
-        } else {
-            b->td_nseg = 1; b->td_seg_sub = 0;
-        }
-    }
+    choose_td_geometry(b.get());
     for (auto &e : b->ev) HIPCHK(hipEventCreate(&e));
     b->ev_ready = true;
     *out = b.release();
@@ -577,11 +602,23 @@ int ss_batch_run(ss_batch *b)
         p.n_streams = c.n_streams; p.channels = C; p.k = b->td->dev.p; p.state = b->state.p;
         p.subblocks = b->sub.p; p.sub_cap = L.n_subblocks ? L.n_subblocks : 1;
         p.sub_stride = (uint64_t)p.sub_cap * C; p.ring = nullptr; p.ring_frames = 0; p.tp_factor = b->tp_factor;
-        p.s100 = b->td->host.s100; p.nseg = b->td_nseg; p.seg_sub = b->td_seg_sub; p.warm_sub = kTdWarmSub;
+        p.s100 = b->td->host.s100; p.nseg = b->td_nseg; p.seg_sub = b->td_seg_sub;
+        // segments > 0: exact hand-over (no run-in; their first kTdFixSub sub-blocks re-run from the true state by the second launch
+        // below), or — mode 1 — the 0.1 s run-in from a zero state of rounds 1-4
+        const bool exact_segments = b->td_nseg > 1 && b->td_mode != 1;
+        p.warm_sub = exact_segments ? 0u : kTdWarmSub;
+        if (exact_segments) {
+            const size_t need = (size_t)c.n_streams * b->td_nseg * C * 4;
+            if (b->seg_state.n < need) HIPCHK(b->seg_state.alloc(need));
+            p.seg_state = b->seg_state.p;
+            p.fix_sub = b->td_seg_sub < kTdFixSub ? b->td_seg_sub : kTdFixSub;
+        }
         p.frames_of = b->ragged ? b->frames_d.p : nullptr;
         p.tp_f32 = b->tp_arith == SS_TP_ARITH_F32 ? 1u : 0u;
+        p.split_batch = (b->td_split && !b->ragged) ? 1u : 0u;      // (ragged lengths: one wave per stream walks its single segment)
         if (b->wave_fused && !b->ragged) { p.wave_out = b->wave.p; p.wave_stride = (uint64_t)2 * b->wave_window; p.wave_window = b->wave_window; p.halo_frames = b->wave_halo; }
         HIPCHK(ssk::launch_time_domain(p, b->stream));
+        if (exact_segments) HIPCHK(ssk::launch_time_domain_fixup(p, b->stream));
     }
     HIPCHK(rec(2 * SS_KERNEL_TIME_DOMAIN + 1));
     if (mode == 2) {
@@ -741,7 +778,9 @@ int ss_batch_geometry_get(const ss_batch *b, ss_batch_geometry *out)
     if (b->td) {
         out->td_segments = b->td_nseg;
         out->td_segment_subblocks = b->td_seg_sub;
-        out->td_warm_subblocks = b->td_nseg > 1 ? kTdWarmSub : 0;
+        out->td_warm_subblocks = (b->td_nseg > 1 && b->td_mode == 1) ? kTdWarmSub : 0;
+        out->td_split = b->td_split ? 1u : 0u;
+        out->td_fixup_subblocks = (b->td_nseg > 1 && b->td_mode != 1) ? (b->td_seg_sub < kTdFixSub ? b->td_seg_sub : kTdFixSub) : 0;
         out->td_true_peak_factor = (uint32_t)b->tp_factor;
     }
     out->waveform_fused = (b->wave_fused && !b->ragged) ? 1u : 0u;
@@ -797,6 +836,16 @@ int ss_batch_set_true_peak_arith(ss_batch *b, int arith)
 }
 
 int ss_batch_get_true_peak_arith(const ss_batch *b) { return b ? b->tp_arith : SS_ERR_INVALID_ARG; }
+
+int ss_batch_set_time_domain_mode(ss_batch *b, int mode)
+{
+    SS_ON_DEVICE(b);
+    if (!b || mode < 0 || mode > 2) return SS_ERR_INVALID_ARG;      // SS_TD_AUTO / SS_TD_RUN_IN / SS_TD_WHOLE_STREAMS
+    HIPCHK(hipStreamSynchronize(b->stream));
+    b->td_mode = mode;
+    choose_td_geometry(b);
+    return SS_OK;
+}
 
 int ss_batch_download_fft(ss_batch *b, uint32_t stream, float *out, size_t cap)
 {

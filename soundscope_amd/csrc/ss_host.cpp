@@ -196,6 +196,8 @@ int get_td_tables(uint32_t rate, int factor, uint32_t channels, TdTables **out)
     for (int nstep = 0; nstep < 68; nstep++) sst::kweight_transition_pow(k.a, (uint64_t)nstep, k.m_step_split[nstep]);
     for (int cidx = 0; cidx < 64; cidx++)
         sst::kweight_transition_pow(k.a, (uint64_t)ssk::td_split_chunk_frames(channels, (rate + 5) / 10) * (uint64_t)(cidx + 1), k.m_chunk_split[cidx]);
+    for (int cidx = 0; cidx < 64; cidx++)
+        sst::kweight_transition_pow(k.a, (uint64_t)ssk::td_chunk_frames(channels, (rate + 5) / 10) * (uint64_t)(cidx + 1), k.m_chunk[cidx]);
     k.tp_factor = factor;
     k.tp_len = 0;
     if (factor) {

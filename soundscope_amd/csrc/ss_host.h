@@ -155,6 +155,11 @@ inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 #define SS_TD_WARM_SUB 1
 #endif
 constexpr uint32_t kTdWarmSub = SS_TD_WARM_SUB;
+// sub-blocks at the head of a time segment > 0 that the fix-up launch re-runs from the exact incoming state.  Behind them the main
+// launch's trajectory (zero state at the segment's start) differs from the true one by A^n s: e^-48 (1 + 48) ~ 7e-20 of the state
+// after 0.2 s — on the DC-offset torture material (state 4e4 x the offset) 1e-13 of the filtered signal, under the 2e-11 at which any
+// two orders of evaluating this recurrence differ (measured: exact whole-stream path vs one-segment path, profiles/r05_ab_td_handover.txt)
+constexpr uint32_t kTdFixSub = 2;
 
 SS_HIDDEN int meter_args_ok(uint32_t channels, uint32_t rate);
 

@@ -110,6 +110,7 @@ struct TdConst {                 // one per (rate, true-peak factor), device res
     double m_step_split[68][16]; // A^n, n = 0 .. 67 (same coordinates): the partial last chunk of a SPLIT tile (n < L <= 65)
     double m_chunk_split[64][16];// (A^L)^(c + 1) for chunk c of a SPLIT tile: what the state in front of the tile adds to the state
                                  // behind chunk c — applied when that state arrives, behind a scan that ran without it
+    double m_chunk[64][16];      // the same for L = td_chunk_frames(C): batches whose streams are walked by a whole workgroup (split_batch)
     float tp[3][kTpHistMax];     // polyphase branches 1..factor-1, coefficient of x[n - t]
     int32_t tp_factor;           // 0, 2, 4
     int32_t tp_len;              // taps per branch (12 or 24)
@@ -151,6 +152,14 @@ struct TdParams {
     uint32_t halo_frames;        // frames kept in front of each tile: >= longest bin, multiple of 4
     const uint64_t *frames_of;    // ragged batches: frames of each stream (nullable = n_frames for all)
     uint32_t tp_f32;              // 1: the factor-4 true peak as the f32 MFMA product everywhere (no f16 split)
+    // Exact segment hand-over (batches, nseg > 1, warm_sub == 0): every segment's wave leaves the filter state behind its last frame in
+    // seg_state[stream][segment][channel][4]; a second, light launch (fixup = 1: no true peak, no decimation) then re-runs the first
+    // fix_sub sub-blocks of every segment > 0 from the state the segment in front of it left, and overwrites their energies.
+    double *seg_state;
+    uint32_t fixup, fix_sub;
+    uint32_t split_batch;         // 1 (batches, nseg == 1): a stream is ONE segment walked by the four waves of a workgroup, the filter
+                                  // state handed from tile to tile through LDS (SPLIT with the batch's chunk length) — no run-in, nothing
+                                  // of the recurrence truncated
     // a tick's short-term reading inside the same launch (k_tick only; st_out == nullptr: off).  The window of st_frames frames
     // ends with this call; the st_old_total ring elements from st_begin_elem on are the part in front of the call.
     double *st_out;               // (energy, loudness): device or mapped host memory
@@ -164,6 +173,8 @@ struct TdParams {
 // *tick_fused tells whether that happened — if not, only the time-domain kernel was launched (p.st_out ignored) and the spectrum
 // and the reading are the caller's to launch
 hipError_t launch_time_domain(const TdParams &p, hipStream_t s, const FftBatchParams *tick_fft = nullptr, bool *tick_fused = nullptr);
+// the second launch of the exact segment hand-over (see TdParams::seg_state): p as given to launch_time_domain
+hipError_t launch_time_domain_fixup(const TdParams &p, hipStream_t s);
 // frames per sequential chunk for a channel count (the constant block's m_pow must match)
 uint32_t td_chunk_frames(uint32_t channels, uint32_t s100);
 // the same for a streaming call whose tiles are shared by the waves of one workgroup (SPLIT): see ss_time_domain.hip

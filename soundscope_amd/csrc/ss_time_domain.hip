@@ -466,7 +466,7 @@ static hipError_t td_launch_w(const TdParams &p, hipStream_t s)
 {
     const uint32_t C = p.channels;
     const uint32_t S = p.s100;
-    const uint32_t L = SPLIT ? td_split_chunk_frames(C, S) : td_chunk_frames(C, S);
+    const uint32_t L = (SPLIT && !p.split_batch) ? td_split_chunk_frames(C, S) : td_chunk_frames(C, S);
     const uint32_t nch = 64u / C;
     const uint32_t cap = nch * L;                                   // frames one wave can scan at once
     const uint32_t pieces = (S + cap - 1) / cap;                    // equal tiles per sub-block
@@ -477,7 +477,8 @@ static hipError_t td_launch_w(const TdParams &p, hipStream_t s)
     uint32_t wave_floats = (halo + tile_len) * C + td_slack_floats(C) + kMaxChannels;
     wave_floats = (wave_floats + 3u) & ~3u;
     // SPLIT: eight waves share the call where eight slices fit the LDS (up to 16 channels or so), four otherwise
-    uint32_t nwb = SPLIT ? (uint32_t)kTdSplitWaves : (uint32_t)kTdWavesPerBlock;
+    // (a batch's streams: four waves each — the grid is n_streams workgroups, and sixteen waves per CU are what the LDS slices allow)
+    uint32_t nwb = (SPLIT && !p.split_batch) ? (uint32_t)kTdSplitWaves : (uint32_t)kTdWavesPerBlock;
     if (SPLIT && (size_t)wave_floats * 4 * nwb + sizeof(TdShare) > 160 * 1024) nwb = (uint32_t)kTdWavesPerBlock;
     const size_t lds = (size_t)wave_floats * 4 * nwb + (SPLIT ? sizeof(TdShare) : 0);
     auto fn = k_time_domain<FACTOR, RING, CT, WAVE, WPS, SPLIT>;
@@ -486,8 +487,8 @@ static hipError_t td_launch_w(const TdParams &p, hipStream_t s)
         return hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     if (pe != hipSuccess) return pe;
-    const uint32_t waves = p.n_streams * p.nseg;
-    const uint32_t blocks = SPLIT ? p.n_streams : (waves + kTdWavesPerBlock - 1) / kTdWavesPerBlock;      // SPLIT: a workgroup per stream
+    const uint32_t waves = p.n_streams * (p.fixup ? p.nseg - 1u : p.nseg);
+    const uint32_t blocks = SPLIT ? waves : (waves + kTdWavesPerBlock - 1) / kTdWavesPerBlock;      // SPLIT: a workgroup per (stream, segment)
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * nwb), lds, s, p, L, tile_len, wave_floats, halo);
     return hipGetLastError();
@@ -545,11 +546,20 @@ static uint32_t td_device_cus()
     return n;
 }
 
+// batches whose streams are walked by a whole workgroup (TdParams::split_batch): the same two register builds by grid size
+template <int FACTOR, int CT, int WAVE>
+static hipError_t td_launch_split_batch(const TdParams &p, hipStream_t s)
+{
+    const uint64_t blocks = (uint64_t)p.n_streams * p.nseg;
+    if (SS_TD_WAVES == 4 && blocks <= 3ull * td_device_cus()) return td_launch_w<FACTOR, false, CT, WAVE, 3, true>(p, s);
+    return td_launch_w<FACTOR, false, CT, WAVE, SS_TD_WAVES, true>(p, s);
+}
+
 template <int FACTOR, bool RING, int CT, int WAVE>
 static hipError_t td_launch(const TdParams &p, hipStream_t s)
 {
     // a workgroup is four waves, one per SIMD: three workgroups per CU hold the whole grid -> the spill-free build
-    const uint64_t waves = (uint64_t)p.n_streams * p.nseg;
+    const uint64_t waves = (uint64_t)p.n_streams * (p.fixup ? p.nseg - 1u : p.nseg);
     const uint64_t blocks = (waves + kTdWavesPerBlock - 1) / kTdWavesPerBlock;
     if (SS_TD_WAVES == 4 && blocks <= 3ull * td_device_cus()) return td_launch_w<FACTOR, RING, CT, WAVE, 3>(p, s);
     return td_launch_w<FACTOR, RING, CT, WAVE, SS_TD_WAVES>(p, s);
@@ -576,6 +586,15 @@ static int td_wave_int4(const TdParams &p)
 template <int FACTOR, bool RING>
 static hipError_t td_launch_c(const TdParams &p, hipStream_t s, const FftBatchParams *tick_fft, bool *fused)
 {
+    if (!RING && p.split_batch) {  // (the host sets it only for the shapes instantiated here: stereo and eight channels, nseg == 1, no ragged lengths)
+        if (p.nseg != 1 || p.frames_of || (p.channels != 2 && p.channels != 8)) return hipErrorInvalidValue;
+        if (p.channels == 8) return p.wave_out ? td_launch_split_batch<FACTOR, 8, 1>(p, s) : td_launch_split_batch<FACTOR, 8, 0>(p, s);
+        if (!p.wave_out) return td_launch_split_batch<FACTOR, 2, 0>(p, s);
+        const int fast = td_wave_int4(p);
+        if (fast == 2) return td_launch_split_batch<FACTOR, 2, 2>(p, s);
+        if (fast == 3) return td_launch_split_batch<FACTOR, 2, 3>(p, s);
+        return td_launch_split_batch<FACTOR, 2, 1>(p, s);
+    }
     if (!RING && p.wave_out) {    // fused decimation is a batch feature (never together with the ring)
         if (p.channels == 8) return td_launch<FACTOR, false, 8, 1>(p, s);      // BASELINE config 5
         if (p.channels == 6) return td_launch<FACTOR, false, 6, 1>(p, s);      // 5.1
@@ -631,6 +650,17 @@ hipError_t launch_time_domain(const TdParams &p, hipStream_t s, const FftBatchPa
         case 2: return ring ? td_launch_c<2, true>(p, s, tick_fft, fused) : td_launch_c<2, false>(p, s, nullptr, fused);
         default: return ring ? td_launch_c<0, true>(p, s, tick_fft, fused) : td_launch_c<0, false>(p, s, nullptr, fused);
     }
+}
+
+// Second launch of the exact segment hand-over: filter and energies only (the FACTOR = 0, WAVE = 0 instantiations), one wave per
+// segment > 0 over its first fix_sub sub-blocks, from the state the segment in front of it left in p.seg_state.
+hipError_t launch_time_domain_fixup(const TdParams &p, hipStream_t s)
+{
+    if (p.n_streams == 0 || p.n_frames == 0 || p.nseg < 2 || !p.seg_state || !p.fix_sub) return hipSuccess;
+    TdParams q = p;
+    q.fixup = 1u; q.wave_out = nullptr; q.wave_window = 0; q.halo_frames = 0; q.tp_factor = 0; q.split_batch = 0u;
+    bool fused = false;
+    return td_launch_c<0, false>(q, s, nullptr, &fused);
 }
 
 }  // namespace ssk

@@ -36,22 +36,40 @@ def _threads():
 F32, F16X3 = L.SS_TP_ARITH_F32, L.SS_TP_ARITH_F16X3
 
 
-@pytest.mark.parametrize("overlap,arith", [(0, None), (1, None), (2, None), (0, F32), (0, F16X3)])
-def test_config3_bench_geometry_matches_oracle(oracle, overlap, arith):
+AUTO, RUN_IN, WHOLE = L.SS_TD_AUTO, L.SS_TD_RUN_IN, L.SS_TD_WHOLE_STREAMS
+
+
+@pytest.mark.parametrize("overlap,arith,td_mode", [(0, None, AUTO), (1, None, AUTO), (2, None, AUTO), (0, F32, AUTO), (0, F16X3, AUTO),
+                                                    (0, None, RUN_IN), (0, None, WHOLE), (0, F16X3, WHOLE)])
+def test_config3_bench_geometry_matches_oracle(oracle, overlap, arith, td_mode):
     """BASELINE config 3 exactly as bench.py runs it: 1024 synthetic streams x 10 s x 48 kHz stereo, N = 4096,
-    hop 1024.  The geometry the shape selects (116 windows per spectrum workgroup, 4 time segments per stream with a
-    run-in) is asserted, then eight streams — first, last and the ones either side of every quarter — are compared in
+    hop 1024.  The geometry the shape selects (116 windows per spectrum workgroup, 4 time segments per stream) is asserted,
+    then eight streams — first, last and the ones either side of every quarter — are compared in
     full with the oracle (every window of both rows, LUFS, LRA, both peaks, every decimation bin), and the corpus
-    histograms with the sum of all 1024 per-stream oracle histograms."""
+    histograms with the sum of all 1024 per-stream oracle histograms.
+    arith: the 4x true peak at the reference's f32 width (the default, None, which bench.py's headline times:
+    v_mfma_f32_16x16x4_f32 on the stereo tile path), set explicitly, and as the opt-in f16x3 split.
+    td_mode: how the time-domain kernel walks a stream (ss_batch_set_time_domain_mode) — the default (time segments with the
+    exact state hand-over: a fix-up launch over the first two sub-blocks of segments 1..3), the run-in form of earlier rounds,
+    and whole-stream workgroups."""
     rate, frames, ns = 48000, 480000, 1024
     b = ssa.Batch(rate, 2, ns, frames, 4096, 1024, flags=L.SS_BATCH_ALL)
     b.synthesize(0x5EED0000, 0)
     b.set_overlap(overlap)
+    b.set_time_domain_mode(td_mode)
+    assert b.true_peak_arith == F32                              # the default is the reference's width
+    if arith is not None:
+        b.set_true_peak_arith(arith)
+    assert b.true_peak_arith == (F32 if arith is None else arith)
     b.run(); b.sync()
     g, lay = b.geometry, b.layout
     assert (lay.n_windows, lay.n_bins) == (464, 1705)
     assert g.fft_windows_per_block == 116 and g.fft_blocks == 4096
-    assert g.td_segments == 4 and g.td_segment_subblocks == 25 and g.td_warm_subblocks == 1
+    if td_mode == WHOLE:
+        assert (g.td_split, g.td_segments, g.td_warm_subblocks, g.td_fixup_subblocks) == (1, 1, 0, 0)
+    else:
+        assert g.td_split == 0 and g.td_segments == 4 and g.td_segment_subblocks == 25
+        assert (g.td_warm_subblocks, g.td_fixup_subblocks) == ((1, 0) if td_mode == RUN_IN else (0, 2))
     assert g.waveform_fused == 1 and g.td_true_peak_factor == 4 and g.overlap == int(overlap)
     res = b.results()
     picks = [0, 1, 255, 256, 511, 512, 1022, 1023]
@@ -93,8 +111,9 @@ def test_config3_bench_geometry_matches_oracle(oracle, overlap, arith):
         assert lufs_close(res[i].integrated_lufs, hs[i][2]), i
 
 
-@pytest.mark.parametrize("tp_factor,overlap,arith", [(4, 0, None), (0, 0, None), (4, 1, None), (4, 2, None), (4, 0, F32), (0, 0, F32), (4, 0, F16X3)])
-def test_config5_bench_shape_all_channels(oracle, tp_factor, overlap, arith):
+@pytest.mark.parametrize("tp_factor,overlap,arith,td_mode", [(4, 0, None, AUTO), (0, 0, None, AUTO), (4, 1, None, AUTO), (4, 2, None, AUTO), (4, 0, F32, AUTO),
+                                                             (0, 0, F32, AUTO), (4, 0, F16X3, AUTO), (4, 0, None, RUN_IN), (4, 0, None, WHOLE), (0, 0, None, WHOLE)])
+def test_config5_bench_shape_all_channels(oracle, tp_factor, overlap, arith, td_mode):
     """BASELINE config 5 as bench.py times it: 64 streams x 10 s x 96 kHz x 8 channels, N = 16384 per channel at hop
     1024, true peak forced to 4x (the benchmark) and at the crate's rule (2x at 96 kHz).  Four streams are checked in
     full on the meter side (LUFS, LRA, all EIGHT channels' true and sample peaks through ss_batch_peaks) and on a
@@ -106,11 +125,16 @@ def test_config5_bench_shape_all_channels(oracle, tp_factor, overlap, arith):
     if arith is not None:                                       # None: the default = SS_TP_ARITH_F32 (the 8-channel f32 tile path)
         b.set_true_peak_arith(arith)
     assert b.true_peak_arith == (F32 if arith is None else arith)
+    b.set_time_domain_mode(td_mode)
     b.run(); b.sync()
     g, lay = b.geometry, b.layout
     assert (lay.n_windows, lay.fft_channels, lay.n_bins) == (921, 8, 3410)
     assert g.td_true_peak_factor == (4 if tp_factor == 4 else 2)
-    assert g.td_segments > 1                                    # the segmented (run-in) path is what the bench times
+    if td_mode == WHOLE:
+        assert g.td_split == 1 and g.td_segments == 1
+    else:
+        assert g.td_segments > 1                                # the segmented path is what the bench times
+        assert (g.td_warm_subblocks, g.td_fixup_subblocks) == ((1, 0) if td_mode == RUN_IN else (0, 2))
     res = b.results()
     picks = [0, 21, 42, 63]
     xs = {i: b.download_input(i) for i in picks}
@@ -257,10 +281,45 @@ def test_subnormal_filter_state_is_flushed_like_the_crate(oracle, rate, slice_le
     assert lufs_close(an.get_shortterm_lufs(), mm.shortterm())
 
 
+def test_segment_handover_is_exact(oracle):
+    """The K-weighting recurrence has a long memory; a stream cut into time segments must hand the filter state on.
+    Default (SS_TD_AUTO): every segment starts from a zero state AT its boundary and a second launch re-runs the first two
+    sub-blocks of every segment > 0 from the state the segment in front of it left.  Against the ONE-segment path (a
+    4096-stream batch walks every stream with one wave, one segment) over all 1024 streams of the bench corpus:
+      * segment 0 and the re-run head of segment 1 are BIT-EQUAL (same state, same tiles, same arithmetic; the later segments'
+        heads start from a state that is itself one rounding history apart from the one-segment path's);
+      * behind them nothing of the recurrence is missing — what remains is the rounding noise of the recurrence itself, the level
+        at which the exact-by-construction whole-stream path differs from the one-segment path too (measured 3.0e-10 and 4.1e-10
+        at the same near-silent sub-block; tools/probe_handover.py) — while the run-in form of earlier rounds is 9.4e-8 off at the
+        first sub-block of a segment (its truncation)."""
+    rate, frames, ns = 48000, 480000, 1024
+    FL = L.SS_BATCH_LUFS | L.SS_BATCH_TRUE_PEAK | L.SS_BATCH_WAVEFORM
+    one = ssa.Batch(rate, 2, 4096, frames, 4096, 1024, flags=FL)
+    one.synthesize(0x5EED0000, 0); one.run(); one.sync()
+    assert (one.geometry.td_segments, one.geometry.td_split) == (1, 0)
+    ref = np.stack([one.subblocks(i) for i in range(ns)]).reshape(ns, 100, 2)
+    one.close()
+    b = ssa.Batch(rate, 2, ns, frames, 4096, 1024, flags=FL)
+    b.synthesize(0x5EED0000, 0)
+    worst = {}
+    for mode in (AUTO, WHOLE, RUN_IN):
+        b.set_time_domain_mode(mode); b.run(); b.sync()
+        d = np.stack([b.subblocks(i) for i in range(ns)]).reshape(ns, 100, 2)
+        rel = np.abs(d - ref) / np.maximum(np.abs(ref), 1e-300)
+        worst[mode] = float(rel.max())
+        if mode == AUTO:
+            g = b.geometry
+            assert (g.td_segments, g.td_segment_subblocks, g.td_fixup_subblocks) == (4, 25, 2)
+            assert np.array_equal(d[:, :27], ref[:, :27]), "segment 0 and the re-run head of segment 1 equal the one-segment path bit for bit"
+    assert worst[AUTO] <= 2e-9 and worst[WHOLE] <= 2e-9, worst      # rounding noise of the recurrence (3e-10 / 4e-10 measured)
+    assert worst[AUTO] <= 0.1 * worst[RUN_IN], worst                 # ... and no longer the run-in's truncation (9.4e-8)
+    b.close()
+
+
 def test_segmented_run_in_on_dc_offset_material(oracle):
-    """Time segments > 0 start their filter one sub-block (0.1 s) early from a zero state (the high-pass section's
-    near-double pole makes the residual decay like n r^n; DC-offset material is its worst case).  The segmented batch
-    path and the single-segment streaming path must land every gating block in the same 0.1 LU histogram bin."""
+    """DC-offset material is the worst case of the segment hand-over (the high-pass section's near-double pole: the state is
+    4e4 times the offset and decays like n r^n).  The segmented batch path (default: exact hand-over by the fix-up launch) and
+    the single-segment streaming path must land every gating block in the same 0.1 LU histogram bin."""
     rate, frames = 48000, 48000 * 10
     rng = np.random.default_rng(5)
     x = np.empty(2 * frames, np.float32)
