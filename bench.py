@@ -124,17 +124,17 @@ def cpu_baseline(batch, rate, fft_n, hop, budget_s=15.0, all_cores_budget_s=8.0)
     return out, check
 
 
-def gpu_sclk_mhz():
-    """Current shader clock of the rank's GPU from sysfs (the line pp_dpm_sclk marks with '*'), or None where it cannot be read."""
+def gpu_sclk_mhz(dev=0):
+    """Current shader clock of GPU `dev` as rocm-smi reports it ("sclk clock level: 1: (2034Mhz)"), or None where it cannot be
+    read.  (sysfs lists every card of the host, visible or not: rocm-smi numbers the visible ones.)  About 0.3 s per call."""
     try:
-        import glob
         import re
-        for path in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
-            for line in open(path).read().splitlines():
-                if line.rstrip().endswith("*"):
-                    m = re.search(r"(\d+)\s*[Mm][Hh]z", line)
-                    if m:
-                        return int(m.group(1))
+        import subprocess
+        txt = subprocess.run(["rocm-smi", "--showclocks"], capture_output=True, text=True, timeout=20).stdout
+        for line in txt.splitlines():
+            m = re.search(r"GPU\[(\d+)\]\s*:\s*sclk clock level:\s*\S+\s*\((\d+)\s*[Mm][Hh]z\)", line)
+            if m and int(m.group(1)) == dev:
+                return int(m.group(2))
     except Exception:
         pass
     return None
@@ -488,16 +488,21 @@ def main():
     if comm is None:
         # a sustained run of the same step (>= 1 s): clocks and thermals of the driver's short headline are otherwise invisible
         n_sus = max(200, int(math.ceil(1.2 / (dt / args.steps))))
-        sclk0 = gpu_sclk_mhz()
+        sclk0 = gpu_sclk_mhz(dev)
+        import threading
+        clk = [None]
+        th = threading.Thread(target=lambda: (time.sleep(0.35), clk.__setitem__(0, gpu_sclk_mhz(dev))))   # read while the steps run
         t1 = time.perf_counter()
+        th.start()
         for _ in range(n_sus):
             step()
-        mid_clk = gpu_sclk_mhz()                                 # read while the queue is still draining
         fence()
         dts = time.perf_counter() - t1
+        th.join()
+        mid_clk = clk[0]
         b.sync()
         sustained = {"steps": n_sus, "seconds": dts, "ms_per_step": dts / n_sus * 1e3, "value": samples_per_step * n_sus / dts,
-                     "sclk_mhz_before": sclk0, "sclk_mhz_during": mid_clk,
+                     "sclk_mhz_idle_before": sclk0, "sclk_mhz_under_load": mid_clk,
                      "what": "the timed step again, back to back for >= 1 s right behind the headline's steps (same batch, same mode)"}
 
         def tp_error(nstreams=4):
@@ -590,6 +595,9 @@ def main():
                                 "time-domain kernel, then the spectrum kernel on a second HIP stream beside the chain's tail (gating / histograms)"][ov_mode],
                        "geometry": {"fft_windows_per_block": geo.fft_windows_per_block, "fft_blocks": geo.fft_blocks,
                                     "td_segments": geo.td_segments, "td_segment_subblocks": geo.td_segment_subblocks,
+                                    "td_handover": ("whole-stream workgroups" if geo.td_split else
+                                                    f"exact: fix-up launch over the first {geo.td_fixup_subblocks} sub-blocks of segments > 0" if geo.td_fixup_subblocks else
+                                                    f"{geo.td_warm_subblocks} sub-block run-in" if geo.td_warm_subblocks else "one segment"),
                                     "waveform_fused": geo.waveform_fused},
                        "sustained": sustained,
                        "corpus_integrated_lufs": corpus_i, "corpus_lra": corpus_lra,

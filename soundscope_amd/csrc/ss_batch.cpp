@@ -213,6 +213,14 @@ int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
             if (tgt > L.n_windows / 16) tgt = L.n_windows / 16;
             if (tgt < 1) tgt = 1;
             uint32_t wpb = (L.n_windows + tgt - 1) / tgt;
+            // ... unless runs of sixteen leave most of the chip idle (one file, a handful of streams): then the pass is bound by
+            // the length of a run, not by its constants — as many workgroups as the chip holds at once (three per CU), runs of two
+            // windows at least (config 2, one 10 s stream: 29 workgroups x 16 windows 50 us -> 232 x 2)
+            const uint64_t total = (uint64_t)cfg->n_streams * L.n_windows;
+            if ((uint64_t)cfg->n_streams * ((L.n_windows + wpb - 1) / (wpb ? wpb : 1)) < 512u) {
+                const uint64_t w = (total + 767u) / 768u;
+                wpb = (uint32_t)(w < 2 ? 2 : w);
+            }
             wpb = (wpb + 1) & ~1u;
             b->windows_per_block = wpb < 2 ? 2 : wpb;
         }

@@ -24,17 +24,17 @@ namespace ssk {
 //  24-frame halo.  Waves never synchronise with each other: no s_barrier in
 //  the kernel, 16 waves per CU hide each other's LDS / HBM latency.
 //
-//  * Segments.  A stream is cut into `nseg` runs of whole sub-blocks so that a
-//    batch of a few hundred streams still fills 4096 wave slots.  Segment k > 0
-//    starts its filter `warm` sub-blocks (1 = 0.1 s) early from a zero state and
-//    discards that run-in: what the missing history would have added to the output is
-//    the tail of the K-weighting impulse response — the slowest pole pair (|z| = 0.99502
-//    at 48 kHz, e^-240 per second at any rate, a near-double pole) leaves e^-24 (1 + 24)
-//    ~ 1e-9 of a DC step after 0.1 s; measured on DC-offset + infrasonic material the
-//    sub-block energies stay within 3e-10 of a sequential f64 filter, the arithmetic noise
-//    of the recurrence on such material.  Far below the 0.01 dB bar or a 0.1 LU histogram
-//    bin (tests pin the latter), but not "to the last bit".  Segment 0 (and every
-//    streaming call, nseg = 1) starts from the true carried state.
+//  * Segments.  A stream is cut into `nseg` runs of whole sub-blocks so that a batch of a few hundred streams still fills
+//    4096 wave slots.  The recurrence has a long memory (the slowest pole pair: |z| = 0.99502 at 48 kHz, e^-240 per second at any
+//    rate, a near-double pole), so the state has to be handed from one segment to the next — EXACTLY, in two launches: every
+//    segment starts from a zero state at its boundary and leaves the state behind its last frame in seg_state; the fix-up launch
+//    (launch_time_domain_fixup: filter and energies only) then re-runs the first fix_sub = 2 sub-blocks of every segment > 0 from
+//    the state the segment in front of it left and overwrites their energies.  Behind those 0.2 s the zero start differs from the
+//    true trajectory by e^-48 (1 + 48) = 7e-20 of the state — under the 1e-11 at which any two evaluation orders of this
+//    recurrence differ (profiles/r05_ab_td_handover.txt).  Segment 0 (and every streaming call, nseg = 1) starts from the true
+//    carried state.  (warm_sub > 0, SS_TD_RUN_IN: the form of rounds 1-4 — a segment starts `warm` sub-blocks early from a zero
+//    state and drops that run-in; a truncation, 9.4e-8 at a segment's first sub-block on the bench corpus — kept for comparison.)
+//    (split_batch, SS_TD_WHOLE_STREAMS: no segments at all — see SPLIT below.)
 //  * K-weighting on the f64 VALU.  Each lane owns one (chunk of L frames,
 //    channel); the recurrence is cut by  state_out = A^L state_in + zero_state:
 //      pass 1: per chunk, run the state recurrence from zero              (4 FMA)
@@ -634,6 +634,7 @@ static hipError_t td_launch_c(const TdParams &p, hipStream_t s, const FftBatchPa
             return p.channels == 2 ? td_launch_w<FACTOR, RING, 2, 0, 3, true>(q, s) : td_launch_w<FACTOR, RING, 0, 0, 3, true>(q, s);
         }
     }
+    if (!RING && p.channels == 8) return td_launch<FACTOR, false, 8, 0>(p, s);      // (config 5 without decimation; its fix-up launch)
     return p.channels == 2 ? td_launch<FACTOR, RING, 2, 0>(p, s) : td_launch<FACTOR, RING, 0, 0>(p, s);
 }
 
