@@ -308,7 +308,8 @@ typedef struct ss_batch_geometry {
     uint32_t waveform_fused;         /* 1: decimation runs inside the time-domain kernel              */
     uint32_t overlap;                /* ss_batch_set_overlap mode: 0, 1 or 2                          */
     uint32_t td_split;               /* 1: a stream is one segment walked by the four waves of a workgroup, the filter state handed
-                                      *    from tile to tile (the whole recurrence: no run-in); td_segments is 1 then              */
+                                      *    from tile to tile (the whole recurrence: no run-in); td_segments is 1 then.  2: a handful of
+                                      *    streams: every SEGMENT's tiles dealt to the eight waves of a workgroup (latency)          */
     uint32_t td_fixup_subblocks;     /* sub-blocks at the head of every segment > 0 re-run from the exact state by the second launch */
 } ss_batch_geometry;                 /* 40 bytes (32 up to ABI version 1) */
 int ss_batch_geometry_get(const ss_batch *b, ss_batch_geometry *out);

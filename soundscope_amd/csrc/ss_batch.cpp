@@ -23,6 +23,7 @@ struct ss_batch {
     uint32_t windows_per_block = 16;
     uint32_t td_nseg = 1, td_seg_sub = 0;
     bool td_split = false;          // whole-stream workgroups (choose_td_geometry)
+    bool td_split_segments = false; // the same per time segment, eight waves each (a handful of streams)
     int td_mode = 0;                // ss_batch_set_time_domain_mode
     bool wave_fused = false;     // decimation runs inside the time-domain kernel
     uint32_t wave_halo = 0;
@@ -127,11 +128,14 @@ static void choose_td_geometry(ss_batch *b)
         const double useful = nseg > 1 ? (double)seg / (double)(seg + kTdWarmSub) : 1.0;
         return useful * waves / (std::ceil(waves / W0) * W0);
     };
+    // shortest segment: with the exact hand-over the state a segment leaves is only as good as the segment is long (it started from
+    // zero): kTdFixSub sub-blocks at least, so that what it hands on has converged like the fix-up's own re-run
+    const uint32_t min_seg = b->td_mode == 1 ? kTdWarmSub : kTdFixSub;
     uint32_t best_seg = 0;
     double best = nsub ? score_of(nsub, 1) : 0.0;                         // one segment: no run-in
     for (uint32_t want = 2; want <= nsub; want++) {                     // balanced segments: seg = ceil(nsub / want)
         const uint32_t seg = (nsub + want - 1) / want;
-        if (seg < kTdWarmSub) break;
+        if (seg < min_seg) break;
         const double sc = score_of(seg, (nsub + seg - 1) / seg);
         if (sc > best * 1.0000001) { best = sc; best_seg = seg; }
     }
@@ -144,13 +148,23 @@ static void choose_td_geometry(ss_batch *b)
     // (measured at the bench shape: the coupled waves of a workgroup run 16 % behind independent segment waves — the chain makes a
     // workgroup as slow as its slowest wave, tile by tile — so the automatic choice wants a clear win in fill)
     b->td_split = split_ok && (b->td_mode == 2 || (b->td_mode == 0 && 0.8 * split_score > best));
+    b->td_split_segments = false;
     if (b->td_split) {
         b->td_nseg = 1; b->td_seg_sub = 0;
-    } else if (best_seg >= kTdWarmSub && best_seg < nsub) {
+    } else if (best_seg >= min_seg && best_seg < nsub) {
         b->td_seg_sub = best_seg;
         b->td_nseg = (nsub + best_seg - 1) / best_seg;
     } else {
         b->td_nseg = 1; b->td_seg_sub = 0;
+    }
+    // A handful of streams (one file): even the shortest segments leave most of the chip idle, and a pass takes as long as ONE
+    // wave needs for its segment's tiles, one after the other.  There a segment's tiles are dealt to the eight waves of a
+    // workgroup instead (the whole-stream form, per segment): if eight waves per shortest segment still fit the chip at once.
+    const uint32_t nseg_min = (nsub + min_seg - 1) / min_seg;
+    if (split_ok && b->td_mode == 0 && !b->td_split && nsub > min_seg && 8.0 * cfg->n_streams * nseg_min <= W0) {
+        b->td_split_segments = true;
+        b->td_seg_sub = min_seg;
+        b->td_nseg = nseg_min;
     }
 }
 
@@ -623,7 +637,7 @@ int ss_batch_run(ss_batch *b)
         }
         p.frames_of = b->ragged ? b->frames_d.p : nullptr;
         p.tp_f32 = b->tp_arith == SS_TP_ARITH_F32 ? 1u : 0u;
-        p.split_batch = (b->td_split && !b->ragged) ? 1u : 0u;      // (ragged lengths: one wave per stream walks its single segment)
+        p.split_batch = b->ragged ? 0u : (b->td_split ? 1u : (b->td_split_segments ? 2u : 0u));      // (ragged lengths: one wave per stream / segment)
         if (b->wave_fused && !b->ragged) { p.wave_out = b->wave.p; p.wave_stride = (uint64_t)2 * b->wave_window; p.wave_window = b->wave_window; p.halo_frames = b->wave_halo; }
         HIPCHK(ssk::launch_time_domain(p, b->stream));
         if (exact_segments) HIPCHK(ssk::launch_time_domain_fixup(p, b->stream));
@@ -787,7 +801,7 @@ int ss_batch_geometry_get(const ss_batch *b, ss_batch_geometry *out)
         out->td_segments = b->td_nseg;
         out->td_segment_subblocks = b->td_seg_sub;
         out->td_warm_subblocks = (b->td_nseg > 1 && b->td_mode == 1) ? kTdWarmSub : 0;
-        out->td_split = b->td_split ? 1u : 0u;
+        out->td_split = b->td_split ? 1u : (b->td_split_segments ? 2u : 0u);
         out->td_fixup_subblocks = (b->td_nseg > 1 && b->td_mode != 1) ? (b->td_seg_sub < kTdFixSub ? b->td_seg_sub : kTdFixSub) : 0;
         out->td_true_peak_factor = (uint32_t)b->tp_factor;
     }

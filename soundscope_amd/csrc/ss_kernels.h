@@ -157,7 +157,9 @@ struct TdParams {
     // fix_sub sub-blocks of every segment > 0 from the state the segment in front of it left, and overwrites their energies.
     double *seg_state;
     uint32_t fixup, fix_sub;
-    uint32_t split_batch;         // 1 (batches, nseg == 1): a stream is ONE segment walked by the four waves of a workgroup, the filter
+    uint32_t split_batch;         // 2: the same with eight waves per (stream, SEGMENT) — a handful of streams cut into short segments,
+                                  // where the length of the chain of tiles is what a pass takes.
+                                  // 1 (batches, nseg == 1): a stream is ONE segment walked by the four waves of a workgroup, the filter
                                   // state handed from tile to tile through LDS (SPLIT with the batch's chunk length) — no run-in, nothing
                                   // of the recurrence truncated
     // a tick's short-term reading inside the same launch (k_tick only; st_out == nullptr: off).  The window of st_frames frames

@@ -466,7 +466,9 @@ static hipError_t td_launch_w(const TdParams &p, hipStream_t s)
 {
     const uint32_t C = p.channels;
     const uint32_t S = p.s100;
-    const uint32_t L = (SPLIT && !p.split_batch) ? td_split_chunk_frames(C, S) : td_chunk_frames(C, S);
+    // chunk length: the batch's (whole tiles of whole chunks, occupancy) — or, where one call / one short segment is shared by eight
+    // waves (streaming calls; split_batch == 2), the one that lets eight tiles cover it in ONE round
+    const uint32_t L = (SPLIT && p.split_batch != 1u) ? td_split_chunk_frames(C, S) : td_chunk_frames(C, S);
     const uint32_t nch = 64u / C;
     const uint32_t cap = nch * L;                                   // frames one wave can scan at once
     const uint32_t pieces = (S + cap - 1) / cap;                    // equal tiles per sub-block
@@ -477,8 +479,9 @@ static hipError_t td_launch_w(const TdParams &p, hipStream_t s)
     uint32_t wave_floats = (halo + tile_len) * C + td_slack_floats(C) + kMaxChannels;
     wave_floats = (wave_floats + 3u) & ~3u;
     // SPLIT: eight waves share the call where eight slices fit the LDS (up to 16 channels or so), four otherwise
-    // (a batch's streams: four waves each — the grid is n_streams workgroups, and sixteen waves per CU are what the LDS slices allow)
-    uint32_t nwb = (SPLIT && !p.split_batch) ? (uint32_t)kTdSplitWaves : (uint32_t)kTdWavesPerBlock;
+    // (a batch's streams: four waves each — the grid is n_streams workgroups, and sixteen waves per CU are what the LDS slices allow;
+    // split_batch == 2, a handful of streams cut into short segments: eight, latency is what counts there)
+    uint32_t nwb = (SPLIT && p.split_batch != 1u) ? (uint32_t)kTdSplitWaves : (uint32_t)kTdWavesPerBlock;
     if (SPLIT && (size_t)wave_floats * 4 * nwb + sizeof(TdShare) > 160 * 1024) nwb = (uint32_t)kTdWavesPerBlock;
     const size_t lds = (size_t)wave_floats * 4 * nwb + (SPLIT ? sizeof(TdShare) : 0);
     auto fn = k_time_domain<FACTOR, RING, CT, WAVE, WPS, SPLIT>;
@@ -550,8 +553,8 @@ static uint32_t td_device_cus()
 template <int FACTOR, int CT, int WAVE>
 static hipError_t td_launch_split_batch(const TdParams &p, hipStream_t s)
 {
-    const uint64_t blocks = (uint64_t)p.n_streams * p.nseg;
-    if (SS_TD_WAVES == 4 && blocks <= 3ull * td_device_cus()) return td_launch_w<FACTOR, false, CT, WAVE, 3, true>(p, s);
+    const uint64_t blocks = (uint64_t)p.n_streams * (p.fixup ? p.nseg - 1u : p.nseg);
+    if (SS_TD_WAVES == 4 && (p.split_batch == 2u || blocks <= 3ull * td_device_cus())) return td_launch_w<FACTOR, false, CT, WAVE, 3, true>(p, s);
     return td_launch_w<FACTOR, false, CT, WAVE, SS_TD_WAVES, true>(p, s);
 }
 
@@ -574,7 +577,7 @@ static int td_wave_int4(const TdParams &p)
     const uint64_t spp = len / p.wave_window;
     if (spp < 4 || spp > 1000 || (spp & 3u)) return 0;         // the fused path itself stops at 1000 samples per bin
     const uint32_t C = p.channels, S = p.s100;
-    const uint32_t L = td_chunk_frames(C, S);
+    const uint32_t L = p.split_batch == 2u ? td_split_chunk_frames(C, S) : td_chunk_frames(C, S);
     const uint32_t cap = (64u / C) * L;
     const uint32_t pieces = (S + cap - 1) / cap;
     uint32_t tile_len = (S + pieces - 1) / pieces;
@@ -587,7 +590,7 @@ template <int FACTOR, bool RING>
 static hipError_t td_launch_c(const TdParams &p, hipStream_t s, const FftBatchParams *tick_fft, bool *fused)
 {
     if (!RING && p.split_batch) {  // (the host sets it only for the shapes instantiated here: stereo and eight channels, nseg == 1, no ragged lengths)
-        if (p.nseg != 1 || p.frames_of || (p.channels != 2 && p.channels != 8)) return hipErrorInvalidValue;
+        if (p.frames_of || (p.channels != 2 && p.channels != 8)) return hipErrorInvalidValue;
         if (p.channels == 8) return p.wave_out ? td_launch_split_batch<FACTOR, 8, 1>(p, s) : td_launch_split_batch<FACTOR, 8, 0>(p, s);
         if (!p.wave_out) return td_launch_split_batch<FACTOR, 2, 0>(p, s);
         const int fast = td_wave_int4(p);
@@ -659,7 +662,7 @@ hipError_t launch_time_domain_fixup(const TdParams &p, hipStream_t s)
 {
     if (p.n_streams == 0 || p.n_frames == 0 || p.nseg < 2 || !p.seg_state || !p.fix_sub) return hipSuccess;
     TdParams q = p;
-    q.fixup = 1u; q.wave_out = nullptr; q.wave_window = 0; q.halo_frames = 0; q.tp_factor = 0; q.split_batch = 0u;
+    q.fixup = 1u; q.wave_out = nullptr; q.wave_window = 0; q.halo_frames = 0; q.tp_factor = 0;      // (split_batch as in the main launch)
     bool fused = false;
     return td_launch_c<0, false>(q, s, nullptr, &fused);
 }
