@@ -26,14 +26,20 @@ def shard_streams(n_total: int, rank: int, world: int):
 class Comm:
     """One rank of the job's communicator (ss_comm)."""
 
-    def __init__(self, rank=None, world=None, rendezvous_file=None, transport="rccl"):
+    def __init__(self, rank=None, world=None, rendezvous_file=None, transport="rccl", device=None):
+        """rank None: everything from the launcher's environment (ss_comm_init_from_env: RANK, WORLD_SIZE, the rank's GPU from
+        SS_COMM_DEVICE or LOCAL_RANK).  device (RCCL): the rank's GPU, made current INSIDE the call, behind the HSA IPC default —
+        a rank creates its communicator before any other GPU call and does not call ss_set_device first (include/soundscope_hip.h)."""
         t = {"rccl": L.SS_COMM_RCCL, "host-tcp": L.SS_COMM_HOST_TCP}[transport]
         self._h = C.c_void_p()
         if rank is None:
             rc = L.lib().ss_comm_init_from_env(t, C.byref(self._h))
         else:
             f = rendezvous_file.encode() if rendezvous_file else None
-            rc = L.lib().ss_comm_init(t, int(rank), int(world), f, C.byref(self._h))
+            if device is None:
+                rc = L.lib().ss_comm_init(t, int(rank), int(world), f, C.byref(self._h))
+            else:
+                rc = L.lib().ss_comm_init_on_device(t, int(rank), int(world), int(device), f, C.byref(self._h))
         if rc != L.SS_OK:
             self._h = None
             _check(rc)

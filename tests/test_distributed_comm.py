@@ -151,3 +151,21 @@ def test_back_to_back_inits_on_one_path(tmp_path):
     [t.start() for t in ts]
     [t.join(120) for t in ts]
     assert not errs, errs
+
+
+def test_comm_init_on_device_entry_point_and_its_argument_checks():
+    """ss_comm_init_on_device (round 5): the rank's GPU is an argument, bound inside the call behind the HSA IPC default, so that a
+    rank off device 0 need not (must not) call ss_set_device first.  On a machine without a GPU: the host transport ignores
+    the device, a negative device is refused, and the RCCL transport fails with SS_ERR_DEVICE instead of touching anything."""
+    import ctypes as C
+    import numpy as np
+    from soundscope_amd import _lib as L
+    from soundscope_amd.distributed import Comm
+    c = Comm(0, 1, None, transport="host-tcp", device=5)
+    assert (c.rank, c.size, c.transport) == (0, 1, "host-tcp")
+    assert list(c.allreduce_sum_u64(np.array([7, 9], np.uint64))) == [7, 9]
+    c.close()
+    h = C.c_void_p()
+    assert L.lib().ss_comm_init_on_device(L.SS_COMM_HOST_TCP, 0, 1, -1, None, C.byref(h)) == L.SS_ERR_INVALID_ARG
+    if L.lib().ss_device_count() <= 0:
+        assert L.lib().ss_comm_init_on_device(L.SS_COMM_RCCL, 0, 1, 0, None, C.byref(h)) == L.SS_ERR_DEVICE
