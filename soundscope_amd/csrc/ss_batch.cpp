@@ -123,9 +123,13 @@ static void choose_td_geometry(ss_batch *b)
     const uint32_t C = cfg->channels;
     const uint32_t nsub = L.n_subblocks;
     const double W0 = 256.0 * ssk::td_resident_waves_per_cu(C, b->td->host.s100, b->wave_fused ? b->wave_halo : 0);
+    // what a segment boundary costs, in sub-blocks of full work: the run-in (mode 1), or the fix-up's re-run of kTdFixSub sub-blocks
+    // at about 0.8 of a full tile each (filter and energies are most of a tile) — config 5's sweep seg = 2 ... 10 with the fix-up:
+    // 2.39 / 2.21 / 2.13 / 2.53 / 2.65 / 3.60 ms, best at 4
+    const double boundary_cost = b->td_mode == 1 ? (double)kTdWarmSub : 0.8 * (double)kTdFixSub;
     auto score_of = [&](uint32_t seg, uint32_t nseg) {
         const double waves = (double)cfg->n_streams * nseg;
-        const double useful = nseg > 1 ? (double)seg / (double)(seg + kTdWarmSub) : 1.0;
+        const double useful = nseg > 1 ? (double)seg / ((double)seg + boundary_cost) : 1.0;
         return useful * waves / (std::ceil(waves / W0) * W0);
     };
     // shortest segment: with the exact hand-over the state a segment leaves is only as good as the segment is long (it started from
