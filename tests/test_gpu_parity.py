@@ -850,10 +850,13 @@ def test_batch_create_rejects_nonsense():
             ssa.Batch(**args)
 
 
-@pytest.mark.parametrize("rate,fft_n", [(48000, 4096), (44100, 16384)])
-def test_ragged_batch_matches_oracle_per_stream(oracle, rate, fft_n):
+@pytest.mark.parametrize("rate,fft_n,td_mode", [(48000, 4096, L.SS_TD_AUTO), (44100, 16384, L.SS_TD_AUTO), (48000, 4096, L.SS_TD_RUN_IN),
+                                                 (48000, 4096, L.SS_TD_WHOLE_STREAMS)])
+def test_ragged_batch_matches_oracle_per_stream(oracle, rate, fft_n, td_mode):
     """Streams of different lengths in one batch (ss_batch_set_lengths): every stream equals its own oracle pass —
-    window count, spectra, loudness, LRA, peaks, decimation — including one shorter than a window and an empty one."""
+    window count, spectra, loudness, LRA, peaks, decimation — including one shorter than a window and an empty one.  In every
+    hand-over mode of the time-domain kernel (ragged lengths fall back to one wave per stream / segment; the fix-up launch then
+    meets segments that lie beyond a stream's end)."""
     lens = [rate * 5 + 333, rate * 2, fft_n + 1024, fft_n - 1, rate * 3 + 4799, 0, 1]
     slot = max(lens)
     xs = [make_stereo(700 + i, n, rate, level=0.25 + 0.1 * i) for i, n in enumerate(lens)]
@@ -862,6 +865,7 @@ def test_ragged_batch_matches_oracle_per_stream(oracle, rate, fft_n):
     for i, x in enumerate(xs):
         buf[i, :x.size] = x
     b = ssa.Batch(rate, 2, len(lens), slot, fft_n, 1024)
+    b.set_time_domain_mode(td_mode)
     b.set_lengths(lens)
     b.upload(0, buf.reshape(-1))
     b.run(); b.sync()
