@@ -10,7 +10,6 @@ from soundscope_amd import _lib as L
 from scipy.signal import lfilter
 FL = L.SS_BATCH_LUFS | L.SS_BATCH_TRUE_PEAK | L.SS_BATCH_WAVEFORM
 rate, frames = 48000, 480000
-k = np.zeros(10); L.lib().ss_inspect_kweight.argtypes = None
 def kweight():
     import ctypes as C
     b5 = (C.c_double * 5)(); a5 = (C.c_double * 5)()
