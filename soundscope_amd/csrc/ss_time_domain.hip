@@ -303,7 +303,7 @@ __device__ __forceinline__ void ring_window_partial(const TdParams &p, uint32_t 
     if (last_here && threadIdx.x < 64u) tick_reading_finish(p, threadIdx.x);
 }
 
-template <int FACTOR, bool RING, int CT, int WAVE, int WPS, bool SPLIT = false>
+template <int FACTOR, bool RING, int CT, int WAVE, int WPS, bool SPLIT = false, bool LATE = false>
 __global__ __launch_bounds__(64 * (SPLIT ? kTdSplitWaves : kTdWavesPerBlock), WPS) void k_time_domain(TdParams p, uint32_t L, uint32_t tile_len,
                                                                                       uint32_t wave_lds_floats, uint32_t halo_frames)
 {
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(64 * kTdSplitWaves, 3) void k_tick(TdParams p, uint
 #endif
         return;
     }
-    constexpr bool RING = true, SPLIT = true;
+    constexpr bool RING = true, SPLIT = true, LATE = true;
     constexpr int WAVE = 0, WPS = 3;
     const uint32_t block_id = 0u;
 #include "ss_td_body.inc"
@@ -461,7 +461,7 @@ uint32_t td_resident_waves_per_cu(uint32_t C, uint32_t s100, uint32_t halo_frame
     return blocks * kTdWavesPerBlock;
 }
 
-template <int FACTOR, bool RING, int CT, int WAVE, int WPS, bool SPLIT = false>
+template <int FACTOR, bool RING, int CT, int WAVE, int WPS, bool SPLIT = false, bool LATE = false>
 static hipError_t td_launch_w(const TdParams &p, hipStream_t s)
 {
     const uint32_t C = p.channels;
@@ -484,7 +484,7 @@ static hipError_t td_launch_w(const TdParams &p, hipStream_t s)
     uint32_t nwb = (SPLIT && p.split_batch != 1u) ? (uint32_t)kTdSplitWaves : (uint32_t)kTdWavesPerBlock;
     if (SPLIT && (size_t)wave_floats * 4 * nwb + sizeof(TdShare) > 160 * 1024) nwb = (uint32_t)kTdWavesPerBlock;
     const size_t lds = (size_t)wave_floats * 4 * nwb + (SPLIT ? sizeof(TdShare) : 0);
-    auto fn = k_time_domain<FACTOR, RING, CT, WAVE, WPS, SPLIT>;
+    auto fn = k_time_domain<FACTOR, RING, CT, WAVE, WPS, SPLIT, LATE>;
     static DevicePrep prepared;                     // one per kernel instantiation
     const hipError_t pe = prepare_on_device(prepared, [fn] {
         return hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -554,7 +554,10 @@ template <int FACTOR, int CT, int WAVE>
 static hipError_t td_launch_split_batch(const TdParams &p, hipStream_t s)
 {
     const uint64_t blocks = (uint64_t)p.n_streams * (p.fixup ? p.nseg - 1u : p.nseg);
-    if (SS_TD_WAVES == 4 && (p.split_batch == 2u || blocks <= 3ull * td_device_cus())) return td_launch_w<FACTOR, false, CT, WAVE, 3, true>(p, s);
+    // a handful of streams cut into short segments: eight waves per segment, the state applied behind the scan (LATE) — the chain
+    // of a segment's tiles is what the launch takes
+    if (p.split_batch == 2u) return td_launch_w<FACTOR, false, CT, WAVE, 2, true, true>(p, s);      // (two waves per SIMD: nothing spilled; the grid is small by definition)
+    if (SS_TD_WAVES == 4 && blocks <= 3ull * td_device_cus()) return td_launch_w<FACTOR, false, CT, WAVE, 3, true>(p, s);
     return td_launch_w<FACTOR, false, CT, WAVE, SS_TD_WAVES, true>(p, s);
 }
 
@@ -634,7 +637,7 @@ static hipError_t td_launch_c(const TdParams &p, hipStream_t s, const FftBatchPa
             }
             TdParams q = p;
             q.st_out = nullptr;                                          // (the reading needs k_tick's ring workgroups)
-            return p.channels == 2 ? td_launch_w<FACTOR, RING, 2, 0, 3, true>(q, s) : td_launch_w<FACTOR, RING, 0, 0, 3, true>(q, s);
+            return p.channels == 2 ? td_launch_w<FACTOR, RING, 2, 0, 3, true, true>(q, s) : td_launch_w<FACTOR, RING, 0, 0, 3, true, true>(q, s);
         }
     }
     if (!RING && p.channels == 8) return td_launch<FACTOR, false, 8, 0>(p, s);      // (config 5 without decimation; its fix-up launch)
