@@ -1134,23 +1134,49 @@ int ssh::integrated_oneshot(uint32_t rate, uint32_t channels, const float *sampl
     }
     if (n == 0) { *out = -INFINITY; return SS_OK; }    // no blocks: loudness_global() = -inf
     if (!samples) return SS_ERR_INVALID_ARG;
-    ss_batch_config cfg{};
-    cfg.sample_rate = rate; cfg.channels = channels; cfg.n_streams = 1; cfg.flags = SS_BATCH_LUFS;
-    cfg.frames_per_stream = n / channels; cfg.fft_n = 0; cfg.hop_frames = 0;
+    // A one-stream, loudness-only batch pass.  Building and tearing down a batch is fourteen device allocations and as many
+    // hipFree calls (20-50 us each: most of what opening a file cost), so ONE batch is kept per process for inputs of up to
+    // 64 MB — created with a quarter of headroom and re-used through the ragged-length path (ss_batch_set_lengths) for every
+    // later call of the same (device, rate, channel count) that fits; the pass runs under a lock.  Longer inputs take a
+    // batch of their own as before.
+    const uint64_t frames = n / channels;
+    constexpr size_t kCacheMaxFloats = (size_t)16 << 20;
+    struct Slot { ss_batch *b = nullptr; uint32_t rate = 0, channels = 0; uint64_t cap = 0; int device = -1; };
+    static std::mutex mu;
+    static Slot slot;
+    std::unique_lock<std::mutex> lk(mu, std::defer_lock);
     ss_batch *b = nullptr;
-    rc = ss_batch_create(&cfg, &b);
-    if (rc) return rc;
-    if (on_device) {
-        if (!hip_ok(hipMemcpyAsync(b->pcm.p, samples, n * sizeof(float), hipMemcpyDeviceToDevice, b->stream),
-                    "hipMemcpyAsync(D2D)")) rc = SS_ERR_DEVICE;
+    bool cached = false;
+    if (n <= kCacheMaxFloats) {
+        lk.lock();
+        const int dev = current_device();
+        if (!(slot.b && slot.device == dev && slot.rate == rate && slot.channels == channels && slot.cap >= frames)) {
+            if (slot.b) { ss_batch_destroy(slot.b); slot = Slot{}; }
+            ss_batch_config cfg{};
+            cfg.sample_rate = rate; cfg.channels = channels; cfg.n_streams = 1; cfg.flags = SS_BATCH_LUFS;
+            cfg.frames_per_stream = frames + frames / 4 + rate; cfg.fft_n = 0; cfg.hop_frames = 0;
+            rc = ss_batch_create(&cfg, &slot.b);
+            if (rc) { slot = Slot{}; return rc; }
+            slot.rate = rate; slot.channels = channels; slot.cap = cfg.frames_per_stream; slot.device = dev;
+        }
+        b = slot.b;
+        cached = true;
+        rc = ss_batch_set_lengths(b, &frames, 1);
+        if (rc) return rc;
     } else {
-        rc = ss_batch_upload(b, 0, 1, samples);
+        ss_batch_config cfg{};
+        cfg.sample_rate = rate; cfg.channels = channels; cfg.n_streams = 1; cfg.flags = SS_BATCH_LUFS;
+        cfg.frames_per_stream = frames; cfg.fft_n = 0; cfg.hop_frames = 0;
+        rc = ss_batch_create(&cfg, &b);
+        if (rc) return rc;
     }
+    if (!hip_ok(hipMemcpyAsync(b->pcm.p, samples, n * sizeof(float), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, b->stream),
+                "hipMemcpyAsync(one-shot input)")) rc = SS_ERR_DEVICE;
     if (!rc) rc = ss_batch_run(b);
     if (!rc) rc = ss_batch_sync(b);
     ss_stream_result r{};
     if (!rc) rc = ss_batch_results(b, &r, 1);
-    ss_batch_destroy(b);
+    if (!cached) ss_batch_destroy(b);
     if (rc) return rc;
     *out = r.integrated_lufs;
     return SS_OK;

@@ -61,7 +61,7 @@ struct DevBuf {
     void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
     hipError_t upload(const std::vector<T> &h)
     {
-        hipError_t e = alloc(h.size());
+        hipError_t e = h.size() == n ? hipSuccess : alloc(h.size());      // (same size: the allocation is kept — a free and a malloc are 30-250 us)
         if (e != hipSuccess || h.empty()) return e;
         return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
     }
