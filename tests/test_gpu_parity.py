@@ -334,6 +334,39 @@ def test_calculate_integrated_lufs(oracle):
     assert an.calculate_integrated_lufs(2, st) == pytest.approx(-23.0, abs=0.1)
 
 
+def test_calculate_integrated_lufs_reuses_its_batch_across_shapes(oracle):
+    """calculate_integrated_lufs / receive_audio_file keep ONE loudness-only batch per process and re-use it through the ragged-length
+    path for every input that fits (a batch's fourteen allocations and frees were most of what opening a file cost).  A sequence
+    that shrinks, grows past the kept capacity, changes the rate and the channel count, hits the empty and the sub-block-short
+    cases in between, and comes from two handles and two threads: every value equals the oracle's for that input alone."""
+    import threading
+    cases = [(48000, 2, 3.0, 31), (48000, 2, 1.2, 32), (48000, 2, 3.0, 31), (48000, 2, 7.5, 33), (48000, 2, 0.05, 34), (44100, 2, 2.0, 35),
+             (48000, 1, 2.5, 36), (48000, 6, 1.5, 37), (48000, 2, 0.0, 38), (96000, 2, 2.0, 39), (48000, 2, 7.5, 33)]
+    handles = {}
+    for rate, ch, secs, seed in cases:
+        frames = int(rate * secs)
+        x = (make_stereo(seed, frames, rate, level=0.1 + 0.05 * (seed % 7), gap=(seed % 2 == 0)) if ch == 2
+             else make_multich(seed, frames, ch, rate)) if frames else np.zeros(0, np.float32)
+        an = handles.get(rate)
+        if an is None:
+            an = handles[rate] = ssa.Analyzer(); an.create_loudness_meter(2, rate)
+        got = an.calculate_integrated_lufs(ch, x)
+        ref = oracle.calculate_integrated_lufs(rate, ch, x)
+        assert lufs_close(got, ref), (rate, ch, secs, got, ref)
+    # two threads at once (the kept batch is used under a lock)
+    rate = 48000
+    xs = [make_stereo(50 + i, rate * (2 + i), rate, level=0.2) for i in range(4)]
+    want = [oracle.calculate_integrated_lufs(rate, 2, x) for x in xs]
+    out = [None] * 4
+    def work(i):
+        a = ssa.Analyzer(); a.create_loudness_meter(2, rate)
+        for _ in range(5):
+            out[i] = a.calculate_integrated_lufs(2, xs[i])
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert all(lufs_close(out[i], want[i]) for i in range(4)), (out, want)
+
+
 # ---------------------------------------------------------------- batch
 def _check_batch_against_oracle(oracle, b, xs, rate, fft_n, hop, tp_factor=0):
     lay = b.layout
