@@ -11,6 +11,7 @@
 #include "ss_fft_dev.h"
 #include <atomic>
 #include <cstdlib>
+#include <cstdio>
 
 #ifndef SS_TD_WAVES
 #define SS_TD_WAVES 4    // min waves per SIMD the time-domain kernel is register-allocated for
@@ -396,6 +397,14 @@ static hipError_t td_launch_w(const TdParams &p, hipStream_t s)
     const uint32_t waves = p.n_streams * (p.fixup ? p.nseg - 1u : p.nseg);
     const uint32_t blocks = SPLIT ? waves : (waves + kTdWavesPerBlock - 1) / kTdWavesPerBlock;      // SPLIT: a workgroup per (stream, segment)
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+#ifdef SS_TUNING        // development builds only: name the instantiation a launch takes (tools/probe_td_wps.py)
+    if (std::getenv("SS_TD_VERBOSE")) {
+        hipFuncAttributes a{};
+        (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(fn));
+        std::fprintf(stderr, "k_time_domain<%d,%d,%d,%d,%d,%d,%d> grid %u x %u lds %zu scratch %zu B/lane vgpr %d\n", FACTOR, (int)RING, CT, WAVE, WPS,
+                     (int)SPLIT, (int)LATE, blocks, 64 * nwb, lds, (size_t)a.localSizeBytes, a.numRegs);
+    }
+#endif
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * nwb), lds, s, p, L, tile_len, wave_floats, halo);
     return hipGetLastError();
 }
@@ -460,7 +469,11 @@ static hipError_t td_launch_split_batch(const TdParams &p, hipStream_t s)
     // a handful of streams cut into short segments: eight waves per segment, the state applied behind the scan (LATE) — the chain
     // of a segment's tiles is what the launch takes
     if (p.split_batch == 2u) return td_launch_w<FACTOR, false, CT, WAVE, 2, true, true>(p, s);      // (two waves per SIMD: nothing spilled; the grid is small by definition)
-    if (SS_TD_WAVES == 4 && blocks <= 3ull * td_device_cus()) return td_launch_w<FACTOR, false, CT, WAVE, 3, true>(p, s);
+    bool three = SS_TD_WAVES == 4 && blocks <= 3ull * td_device_cus();
+#ifdef SS_TUNING        // development builds only: SS_TD_WPS=3|4 forces a register build
+    if (const char *e = std::getenv("SS_TD_WPS")) three = SS_TD_WAVES == 4 && std::atoi(e) == 3;
+#endif
+    if (three) return td_launch_w<FACTOR, false, CT, WAVE, 3, true>(p, s);
     return td_launch_w<FACTOR, false, CT, WAVE, SS_TD_WAVES, true>(p, s);
 }
 
@@ -468,9 +481,14 @@ template <int FACTOR, bool RING, int CT, int WAVE>
 static hipError_t td_launch(const TdParams &p, hipStream_t s)
 {
     // a workgroup is four waves, one per SIMD: three workgroups per CU hold the whole grid -> the spill-free build
+    if constexpr (RING) return td_launch_w<FACTOR, RING, CT, WAVE, 3>(p, s);      // a streaming call is one stream: one workgroup
     const uint64_t waves = (uint64_t)p.n_streams * (p.fixup ? p.nseg - 1u : p.nseg);
     const uint64_t blocks = (waves + kTdWavesPerBlock - 1) / kTdWavesPerBlock;
-    if (SS_TD_WAVES == 4 && blocks <= 3ull * td_device_cus()) return td_launch_w<FACTOR, RING, CT, WAVE, 3>(p, s);
+    bool three = SS_TD_WAVES == 4 && blocks <= 3ull * td_device_cus();
+#ifdef SS_TUNING        // development builds only: SS_TD_WPS=3|4 forces a register build
+    if (const char *e = std::getenv("SS_TD_WPS")) three = SS_TD_WAVES == 4 && std::atoi(e) == 3;
+#endif
+    if (three) return td_launch_w<FACTOR, RING, CT, WAVE, 3>(p, s);
     return td_launch_w<FACTOR, RING, CT, WAVE, SS_TD_WAVES>(p, s);
 }
 

@@ -10,8 +10,9 @@
 #   d  columns tests and timing of the shipped form
 #   f  whole-stream workgroups vs time segments at the bench shape (tools/probe_handover.py supersedes it)
 #   g  hand-over modes against the one-segment path, mismatches by sub-block index
+#   h  k_time_domain's two register builds on big grids, shape by shape (tools/probe_td_wps.py, needs tools/bin/tune.so)
 set -u
-step=${1:?a|b|c|d|f|g}
+step=${1:?a|b|c|d|f|g|h}
 
 step_a() {
 # round 5, call A: suite with the f32 default, then same-box A/B of k_fft4096_ms1 builds (TW6 / TW9 / TW12 resident pass-1 twiddles,
@@ -160,6 +161,12 @@ for c in range(2):
     print("stream 0 ch", c, "one-segment max rel vs scipy f64:", float(np.max(np.abs(ref.reshape(ns, 100, 2)[0, :, c] - e) / e)))
 PY
 cat $out/modes2.log
+}
+
+step_h() {
+out=gpurun_out/r5h; mkdir -p $out
+SOUNDSCOPE_HIP_LIB=$PWD/tools/bin/tune.so python tools/probe_td_wps.py 10 > $out/wps.log 2> $out/wps.err
+cat $out/wps.log; grep -E '##|k_time_domain<' $out/wps.err | uniq
 }
 
 step_$step
