@@ -50,5 +50,7 @@ def test_bench_two_rank_launch_fails_fast_without_a_gpu():
     out = p.stdout + p.stderr
     assert p.returncode != 0, out[-2000:]
     assert took < 60.0, f"the launch took {took:.0f} s to fail"
-    assert out.count("bench.py needs a GPU") == 2, out[-3000:]          # one clear line per rank
+    # one clear line per rank that got as far as looking for a device: the launcher terminates the peers of the first rank that
+    # fails (its monitor polls every 0.1 s), so on a loaded host the slower rank may be stopped while it still imports
+    assert 1 <= out.count("bench.py needs a GPU") <= 2, out[-3000:]
     assert '"metric"' not in p.stdout                                    # and no bench line from a run that measured nothing
