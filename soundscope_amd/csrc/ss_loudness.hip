@@ -35,8 +35,9 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
-// one wave evaluates gate and LRA on an LDS histogram pair (block, short-term)
-__device__ void eval_hist(const unsigned long long *hb, const unsigned long long *hs,
+// one wave evaluates gate and LRA on an LDS histogram pair (block, short-term); inlined: `en` / `bd` are LDS copies of the tables
+// in the latency-bound callers (every dependent table read is then an LDS access, not a round trip to L2)
+__device__ __forceinline__ void eval_hist(const unsigned long long *hb, const unsigned long long *hs,
                           const double *__restrict__ en, const double *__restrict__ bd,
                           double *out_i, double *out_lra)
 {
@@ -119,11 +120,11 @@ __device__ __forceinline__ uint32_t ring_back(uint32_t jm, uint32_t q, uint32_t 
 // each channel added oldest first.  All loads of a batch are issued before the first addition — written as a loop of
 // `cs += P[...]` the thirty terms of a short-term block were thirty dependent round trips to memory (12 us of a tick, and
 // the whole of this kernel's time on a long stream).
-template <int N, bool DIRECT>
+template <int N, bool DIRECT, int KB = (N < 10 ? N : 10)>
 __device__ __forceinline__ double window_energy(const double *__restrict__ P, uint32_t jm, uint32_t cap, uint32_t C,
                                                 const double *__restrict__ weights)
 {
-    constexpr int kBatch = N < 10 ? N : 10;
+    constexpr int kBatch = KB;
     static_assert(N % kBatch == 0, "whole batches");
     uint32_t s0 = DIRECT ? jm - (uint32_t)(N - 1) : ring_back(jm, (uint32_t)(N - 1), cap);      // slot of the oldest term
     double sum = 0.0;
@@ -148,20 +149,66 @@ __device__ __forceinline__ double window_energy(const double *__restrict__ P, ui
     return sum;
 }
 
+// The same sums for the latency-bound launches (a handful of streams: the kernel's time is its chain of dependent round trips to
+// memory, not its work): channels two at a time, every term of both and their weights requested before anything is used — ONE
+// round trip per pair of channels where the form above takes one for the weight and N / 10 per channel behind it.  Same additions
+// in the same order (a channel whose weight is zero is loaded and dropped, as the `continue` above drops it unread).
+template <int N, bool DIRECT>
+__device__ __forceinline__ double window_energy_eager(const double *__restrict__ P, uint32_t jm, uint32_t cap, uint32_t C,
+                                                      const double *__restrict__ weights)
+{
+    const uint32_t s0 = DIRECT ? jm - (uint32_t)(N - 1) : ring_back(jm, (uint32_t)(N - 1), cap);
+    double sum = 0.0;
+    for (uint32_t c = 0; c < C; c += 2) {
+        const bool two = c + 1u < C;
+        const uint32_t c1 = two ? c + 1u : c;
+        const double w0 = weights[c], w1 = weights[c1];
+        double v0[N], v1[N];
+        uint32_t sl = s0;
+#pragma unroll
+        for (int q = 0; q < N; q++) {
+            v0[q] = P[(size_t)sl * C + c];
+            v1[q] = P[(size_t)sl * C + c1];
+            sl = DIRECT ? sl + 1u : (sl + 1u == cap ? 0u : sl + 1u);
+        }
+        double cs0 = 0.0, cs1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < N; q++) { cs0 += v0[q]; cs1 += v1[q]; }
+        if (w0 != 0.0) sum += w0 * cs0;
+        if (two && w1 != 0.0) sum += w1 * cs1;
+    }
+    return sum;
+}
+
 // One workgroup per stream; the gating blocks of a stream are independent (histogram increments are LDS atomics), so a
 // long stream (config 2's 600 s: 6000 sub-blocks) is spread over up to 1024 threads — a thread's iteration is a chain of
 // dependent loads, so the kernel's time is its iteration count; wave 0 then evaluates gate and LRA.
-__global__ __launch_bounds__(1024) void k_finalize(FinalizeParams p)
+// SMALL (a handful of streams: config 2, a file open, calculate_integrated_lufs): the two tables the gate reads — bin energies and
+// bin boundaries, 16 KB — come into LDS with the histograms, and the sub-block sums are requested eagerly: the kernel's chain of
+// dependent trips to L2 / HBM is four long instead of eighteen (config 2: 22.5 -> 20 us, config 5: 31 -> 25 us, profiles/r05_small_batch_finalize.txt).  The big grids keep
+// the lean form: 16 KB more LDS traffic per workgroup buys nothing where a thousand workgroups hide each other's latency.
+template <bool SMALL>
+__global__ __launch_bounds__(SMALL ? 256 : 1024) void k_finalize(FinalizeParams p)
 {
     __shared__ unsigned long long hb[kHistBins];
     __shared__ unsigned long long hs[kHistBins];
     __shared__ unsigned int counts[2];
+    __shared__ double tab[SMALL ? 2 * kHistBins + 1 : 1];          // SMALL: [energies 1000][bounds 1001]
     const uint32_t stream = blockIdx.x;
     const int lane = threadIdx.x, nthr = (int)blockDim.x;
     unsigned long long *gh = reinterpret_cast<unsigned long long *>(p.hist) + (size_t)stream * 2 * kHistBins;
     unsigned long long *corpus = reinterpret_cast<unsigned long long *>(p.corpus_hist);
-    for (int i = lane; i < kHistBins; i += nthr) { hb[i] = gh[i]; hs[i] = gh[kHistBins + i]; }
+    for (int i = lane; i < kHistBins; i += nthr) {
+        hb[i] = gh[i]; hs[i] = gh[kHistBins + i];
+        if (SMALL) { tab[i] = p.hist_energies[i]; tab[kHistBins + i] = p.hist_bounds[i]; }
+    }
+    if (SMALL && lane == 0) tab[2 * kHistBins] = p.hist_bounds[kHistBins];
     if (lane < 2) counts[lane] = 0;
+    const double *en = SMALL ? tab : p.hist_energies;
+    const double *bd = SMALL ? tab + kHistBins : p.hist_bounds;
+    const double bd0 = p.hist_bounds[0];                                                  // (read before the barrier: in flight with the rest)
+    // gating block ending with sub-block j: j-3..j ; short-term block: j-29..j when (j-29) % 10 == 0
+    const uint64_t sub_end = p.sub_end_of ? p.sub_end_of[stream] : p.sub_end;          // ragged batches
     __syncthreads();
 
     const uint32_t C = p.channels;
@@ -169,15 +216,16 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeParams p)
     const double *P = p.subblocks + (size_t)stream * p.sub_stride;
     const uint32_t cap = p.sub_cap;
     const bool direct = p.sub_end <= (uint64_t)cap && p.sub_begin == 0;               // batches: slot == sub-block index
-    // gating block ending with sub-block j: j-3..j ; short-term block: j-29..j when (j-29) % 10 == 0
-    const uint64_t sub_end = p.sub_end_of ? p.sub_end_of[stream] : p.sub_end;          // ragged batches
     uint32_t nb = 0, ns = 0;
     // gating blocks: one per sub-block j >= 3
     for (uint64_t j = (p.sub_begin > 3 ? p.sub_begin : 3) + lane; j < sub_end; j += nthr) {
         const uint32_t jm = direct ? (uint32_t)j : (uint32_t)(j % cap);
-        const double sum = (direct ? window_energy<4, true>(P, jm, cap, C, p.weights) : window_energy<4, false>(P, jm, cap, C, p.weights)) / (4.0 * S);
+        double sum;
+        if (SMALL) sum = direct ? window_energy_eager<4, true>(P, jm, cap, C, p.weights) : window_energy_eager<4, false>(P, jm, cap, C, p.weights);
+        else sum = direct ? window_energy<4, true>(P, jm, cap, C, p.weights) : window_energy<4, false>(P, jm, cap, C, p.weights);
+        sum /= 4.0 * S;
         nb++;
-        if (sum >= p.hist_bounds[0]) atomicAdd(&hb[hist_index(p.hist_bounds, sum)], 1ull);
+        if (sum >= bd0) atomicAdd(&hb[hist_index(bd, sum)], 1ull);
     }
     // short-term blocks: j = 29 + 10 m.  Dealt densely (thread = m), not as every tenth lane of the loop above
     {
@@ -186,9 +234,12 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeParams p)
             const uint64_t j = 29 + 10 * m;
             if (j >= sub_end) break;
             const uint32_t jm = direct ? (uint32_t)j : (uint32_t)(j % cap);
-            const double sum = (direct ? window_energy<30, true>(P, jm, cap, C, p.weights) : window_energy<30, false>(P, jm, cap, C, p.weights)) / (30.0 * S);
+            double sum;
+            if (SMALL) sum = direct ? window_energy_eager<30, true>(P, jm, cap, C, p.weights) : window_energy_eager<30, false>(P, jm, cap, C, p.weights);
+            else sum = direct ? window_energy<30, true>(P, jm, cap, C, p.weights) : window_energy<30, false>(P, jm, cap, C, p.weights);
+            sum /= 30.0 * S;
             ns++;
-            if (sum >= p.hist_bounds[0]) atomicAdd(&hs[hist_index(p.hist_bounds, sum)], 1ull);
+            if (sum >= bd0) atomicAdd(&hs[hist_index(bd, sum)], 1ull);
         }
     }
     if (nb) atomicAdd(&counts[0], nb);
@@ -206,7 +257,7 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeParams p)
     }
     if (p.out_counts && lane < 2) p.out_counts[stream * 2 + lane] += counts[lane];
     if (lane < 64)          // (wave 0; the histograms in LDS are complete: the barrier above)
-        eval_hist(hb, hs, p.hist_energies, p.hist_bounds,
+        eval_hist(hb, hs, en, bd,
                   p.out_integrated ? &p.out_integrated[stream] : nullptr,
                   p.out_lra ? &p.out_lra[stream] : nullptr);
 }
@@ -215,7 +266,15 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeParams p)
 // with the histogram updated in place by global atomics instead of a 16 KB round trip through LDS.
 __global__ __launch_bounds__(64) void k_finalize_stream(FinalizeParams p)
 {
+    // one wave, and every step waits for the one before it: the tables the gate reads (bin energies, bin boundaries) are staged in
+    // LDS first — ONE round trip to L2 instead of one per dependent table read (two per histogram index, eight in eval_hist)
+    __shared__ double tab[2 * kHistBins + 1];
     const int lane = threadIdx.x;
+    for (int i = lane; i < kHistBins; i += 64) { tab[i] = p.hist_energies[i]; tab[kHistBins + i] = p.hist_bounds[i]; }
+    if (lane == 0) tab[2 * kHistBins] = p.hist_bounds[kHistBins];
+    const double *en = tab, *bd = tab + kHistBins;
+    const double bd0 = p.hist_bounds[0];
+    __syncthreads();
     unsigned long long *gh = reinterpret_cast<unsigned long long *>(p.hist);
     const uint32_t C = p.channels;
     const double S = (double)p.k->s100;
@@ -223,18 +282,18 @@ __global__ __launch_bounds__(64) void k_finalize_stream(FinalizeParams p)
     uint32_t nb = 0, ns = 0;
     const uint32_t cap = p.sub_cap;
     for (uint64_t j = (p.sub_begin > 3 ? p.sub_begin : 3) + lane; j < p.sub_end; j += 64) {
-        const double sum = window_energy<4, false>(P, (uint32_t)(j % cap), cap, C, p.weights) / (4.0 * S);
+        const double sum = window_energy_eager<4, false>(P, (uint32_t)(j % cap), cap, C, p.weights) / (4.0 * S);
         nb++;
-        if (sum >= p.hist_bounds[0]) atomicAdd(&gh[hist_index(p.hist_bounds, sum)], 1ull);
+        if (sum >= bd0) atomicAdd(&gh[hist_index(bd, sum)], 1ull);
     }
     {
         const uint64_t m_begin = p.sub_begin > 29 ? (p.sub_begin - 29 + 9) / 10 : 0;
         for (uint64_t m = m_begin + lane;; m += 64) {
             const uint64_t j = 29 + 10 * m;
             if (j >= p.sub_end) break;
-            const double sum = window_energy<30, false>(P, (uint32_t)(j % cap), cap, C, p.weights) / (30.0 * S);
+            const double sum = window_energy_eager<30, false>(P, (uint32_t)(j % cap), cap, C, p.weights) / (30.0 * S);
             ns++;
-            if (sum >= p.hist_bounds[0]) atomicAdd(&gh[kHistBins + hist_index(p.hist_bounds, sum)], 1ull);
+            if (sum >= bd0) atomicAdd(&gh[kHistBins + hist_index(bd, sum)], 1ull);
         }
     }
     if (p.out_counts) {
@@ -256,7 +315,7 @@ __global__ __launch_bounds__(64) void k_finalize_stream(FinalizeParams p)
             p.readings_peaks_dst[64 + lane] = p.readings_peaks_src[64 + lane];
         }
         __syncthreads();
-        eval_hist(hb, hs, p.hist_energies, p.hist_bounds, &p.readings_out[0], &p.readings_out[1]);
+        eval_hist(hb, hs, en, bd, &p.readings_out[0], &p.readings_out[1]);
         if (p.readings_flag) {
             __threadfence_system();
             __syncthreads();
@@ -275,7 +334,9 @@ hipError_t launch_finalize(const FinalizeParams &p, hipStream_t s)
         // threads at the bench shape: 0.043 / 0.036 / 0.033 / 0.045 ms), sixteen for a long stream
         const uint64_t nsub = p.sub_end - p.sub_begin;
         const uint32_t threads = nsub > 2048 ? 1024u : 256u;
-        hipLaunchKernelGGL(k_finalize, dim3(p.n_streams), dim3(threads), 0, s, p);
+        // a handful of short streams: the launch is a chain of memory round trips, not work -> the form that shortens the chain
+        if (p.n_streams <= 64u && threads == 256u) hipLaunchKernelGGL(k_finalize<true>, dim3(p.n_streams), dim3(threads), 0, s, p);
+        else hipLaunchKernelGGL(k_finalize<false>, dim3(p.n_streams), dim3(threads), 0, s, p);
     }
     return hipGetLastError();
 }
@@ -285,13 +346,18 @@ __global__ __launch_bounds__(64) void k_hist_eval(const unsigned long long *hist
 {
     __shared__ unsigned long long hb[kHistBins];
     __shared__ unsigned long long hs[kHistBins];
-    for (int i = threadIdx.x; i < kHistBins; i += 64) { hb[i] = hist2000[i]; hs[i] = hist2000[kHistBins + i]; }
+    __shared__ double tab[2 * kHistBins + 1];               // the two tables beside the histograms: one round trip for all four
+    for (int i = threadIdx.x; i < kHistBins; i += 64) {
+        hb[i] = hist2000[i]; hs[i] = hist2000[kHistBins + i];
+        tab[i] = en[i]; tab[kHistBins + i] = bd[i];
+    }
+    if (threadIdx.x == 0) tab[2 * kHistBins] = bd[kHistBins];
     if (x.peaks_dst) {
         x.peaks_dst[threadIdx.x] = x.peaks_src[threadIdx.x];
         x.peaks_dst[64 + threadIdx.x] = x.peaks_src[64 + threadIdx.x];
     }
     __syncthreads();
-    eval_hist(hb, hs, en, bd, &out2[0], &out2[1]);
+    eval_hist(hb, hs, tab, tab + kHistBins, &out2[0], &out2[1]);
     if (x.flag) {
         __threadfence_system();
         __syncthreads();

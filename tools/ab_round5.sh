@@ -10,9 +10,10 @@
 #   d  columns tests and timing of the shipped form
 #   f  whole-stream workgroups vs time segments at the bench shape (tools/probe_handover.py supersedes it)
 #   g  hand-over modes against the one-segment path, mismatches by sub-block index
+#   i  small-batch gating (k_finalize<SMALL>, tables in LDS): loudness tests, then head.so vs the tree on the one-stream probes
 #   h  k_time_domain's two register builds on big grids, shape by shape (tools/probe_td_wps.py, needs tools/bin/tune.so)
 set -u
-step=${1:?a|b|c|d|f|g|h}
+step=${1:?a|b|c|d|f|g|h|i}
 
 step_a() {
 # round 5, call A: suite with the f32 default, then same-box A/B of k_fft4096_ms1 builds (TW6 / TW9 / TW12 resident pass-1 twiddles,
@@ -167,6 +168,23 @@ step_h() {
 out=gpurun_out/r5h; mkdir -p $out
 SOUNDSCOPE_HIP_LIB=$PWD/tools/bin/tune.so python tools/probe_td_wps.py 10 > $out/wps.log 2> $out/wps.err
 cat $out/wps.log; grep -E '##|k_time_domain<' $out/wps.err | uniq
+}
+
+step_i() {
+out=gpurun_out/r5i; mkdir -p $out
+python -m pytest tests -m gpu -q -x -k "parity or known or golden or session or tick or capture or independent or ragged or lufs or loud or gate or hist or corpus" > $out/tests.log 2>&1; tail -3 $out/tests.log
+for rep in 1 2; do
+for lib in head default; do
+  echo "=== $lib (rep $rep)"
+  if [ $lib = default ]; then unset SOUNDSCOPE_HIP_LIB; else export SOUNDSCOPE_HIP_LIB=$PWD/tools/bin/$lib.so; fi
+  python tools/probe_single_file.py 2>&1 | grep -v "^ *$"
+  python tools/probe_getters.py
+  python tools/probe_cfg5.py 64 2>&1 | grep -E "k_finalize|k_time|sum|wall"
+  python tools/perf_probe.py 1024 10 | grep -E "k_finalize|sum"
+done
+done > $out/ab.log 2>&1
+unset SOUNDSCOPE_HIP_LIB
+cat $out/ab.log
 }
 
 step_$step
