@@ -926,6 +926,57 @@ def test_ragged_batch_matches_oracle_per_stream(oracle, rate, fft_n, td_mode):
         assert np.array_equal(b.waveform(i).reshape(-1), ref["wave"][:, 1].astype(np.float32))
 
 
+@pytest.mark.parametrize("td_mode", [L.SS_TD_AUTO, L.SS_TD_RUN_IN, L.SS_TD_WHOLE_STREAMS])
+@pytest.mark.parametrize("channels,rate,lens", [(8, 22050, [0, 4608]), (2, 48000, [0, 0]), (2, 48000, [100, 48000 * 2]), (8, 96000, [9599, 96000]),
+                                                (1, 44100, [0, 4410 * 3 + 1])])
+def test_ragged_batch_whose_first_stream_ends_in_front_of_the_segments(oracle, td_mode, channels, rate, lens):
+    """A ragged batch whose FIRST stream is empty, or shorter than the 0.1 s run-in: in the run-in mode the waves of the segments
+    behind its end stepped back from the clamped start and read in front of the batch's buffer — a memory fault
+    (tools/fuzz_batch.py seed 117; a stream further back read its neighbour's slot instead, harmlessly).  Every mode, every stream
+    against the oracle."""
+    slot = max(max(lens), 32825)
+    xs = [make_multich(900 + i, n, channels, rate) for i, n in enumerate(lens)]
+    buf = np.full((len(lens), slot * channels), 7.0, np.float32)
+    for i, x in enumerate(xs):
+        buf[i, :x.size] = x
+    b = ssa.Batch(rate, channels, len(lens), slot, 4096, 1024, flags=L.SS_BATCH_LUFS | L.SS_BATCH_TRUE_PEAK | L.SS_BATCH_WAVEFORM,
+                  true_peak_factor=4)
+    try:
+        b.set_time_domain_mode(td_mode)
+    except ssa.AnalyzerError:
+        pass                                                 # (whole-stream workgroups exist for stereo and eight channels)
+    b.set_lengths(lens)
+    b.upload(0, buf.reshape(-1))
+    for _ in range(2):
+        b.run(); b.sync()
+    res = b.results()
+    for i, x in enumerate(xs):
+        if lens[i] == 0:
+            assert res[i].integrated_lufs == -np.inf and res[i].loudness_range == 0.0
+            continue
+        m = oracle.Meter(channels, rate, force_tp_factor=4); m.add_frames(x)
+        assert lufs_close(res[i].integrated_lufs, m.integrated())
+        assert abs(res[i].loudness_range - m.loudness_range()) <= TOL_DB
+        tp, sp = b.peaks(i)
+        for c in range(channels):
+            assert rel_close(tp[c], m.true_peak(c)) and sp[c] == m.sample_peak(c), (i, c)
+        want = oracle.get_waveform(x, lens[i] / rate)[:, 1].astype(np.float32)
+        assert np.array_equal(b.waveform(i).reshape(-1), want, equal_nan=True), i
+    b.close()
+
+
+@pytest.mark.parametrize("seed", [3, 24, 46, 66, 101, 110, 111, 117, 240, 577])
+def test_randomised_batch_programme_against_oracle(oracle, seed):
+    """tools/fuzz_batch.py: random rate / channels / stream count / length / window / hop / true-peak factor and arithmetic /
+    hand-over mode / ragged lengths, every checked stream against the oracle.  The committed seeds are the first run's findings
+    (117: the run-in mode's read in front of the buffer) and a spread of the geometry rules; the tool runs hundreds."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_batch
+    ok, msg = fuzz_batch.programme(seed)
+    assert ok, msg
+
+
 def test_analyze_streams_of_different_lengths(oracle):
     """soundscope_amd.pipeline.analyze_streams: a list of decoded files of different lengths (here s16), chunked into
     ragged batches; results come back in input order and equal one oracle meter pass per file."""
