@@ -263,11 +263,8 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
 __device__ __forceinline__ void fft4096_floor_rows(int t, uint32_t n_bins, float db_offset, const float *__restrict__ offpink,
                                                 float *o_first, float *o_second, bool first_zero, bool second_zero)
 {
-    constexpr float kDb = 3.01029995663981195f;
-    const float lg0 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint((-150.0f - db_offset) / kDb)));
     const uint32_t ngroups = (n_bins + 3) >> 2;
     __builtin_amdgcn_s_waitcnt(0);                  // the ordinary stores of these rows have left the wave: these come after them
-    (void)kDb; (void)lg0;
     for (uint32_t g = (uint32_t)t; g < ngroups; g += 256u) {
         const float4 op = *reinterpret_cast<const float4 *>(offpink + 4 * g);
         // -150 + pink, with pink = table - offset: EXACTLY -150 where the table carries no compensation (ss_get_fft's, which
@@ -285,8 +282,6 @@ __device__ __forceinline__ void fft4096_floor_columns(int t, uint32_t n_bins, fl
                                                       float *colbuf, const uint16_t *bincol, const float *col_init, uint32_t cols,
                                                       bool first_zero, bool second_zero)
 {
-    constexpr float kDb = 3.01029995663981195f;
-    const float lg0 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint((-150.0f - db_offset) / kDb)));
     __syncthreads();
     for (uint32_t c = (uint32_t)t; c < cols; c += 256u) {
         if (first_zero) colbuf[c] = col_init[c];
@@ -295,7 +290,8 @@ __device__ __forceinline__ void fft4096_floor_columns(int t, uint32_t n_bins, fl
     __syncthreads();
     for (uint32_t k = (uint32_t)t; k < n_bins; k += 256u) {
         const uint32_t c = bincol[k];                                   // (global memory: this path is rare)
-        const float v = fmaf(lg0, kDb, offpink[k]);
+        const float v = -150.0f + (offpink[k] - db_offset);           // the SAME expression as fft4096_floor_rows (fmaf(lg0, kDb, offpink) rounds
+                                                                       // differently: 2 ulp at 88.2 kHz, tools/fuzz_columns.py seed 87)
         if (first_zero) lds_fmax((lds_f32 *)colbuf + c, v);
         if (second_zero) lds_fmax((lds_f32 *)colbuf + kColStride + c, v);
     }

@@ -83,6 +83,40 @@ def test_wav_parse_rejects_garbage_and_truncation():
     assert e.value.code == L.SS_ERR_UNSUPPORTED
 
 
+def test_wav_parse_mutated_headers_never_point_outside_the_file():
+    """Randomised: valid headers of every supported and a few unsupported formats with a handful of bytes flipped and / or the file cut
+    short — the parser either refuses or returns a data range that lies inside the buffer it was given (the copy is exact-sized: an
+    over-read would leave the allocation)."""
+    import ctypes as C
+    rng = np.random.default_rng(20250928)
+    lib = L.lib()
+    accepted = 0
+    for _ in range(4000):
+        ch, bits = int(rng.integers(0, 9)), int(rng.choice([8, 16, 24, 32, 64, 12]))
+        tag, rate = int(rng.choice([1, 3, 7])), int(rng.choice([0, 8000, 44100, 48000, 2 ** 31]))
+        fb = bits // 8 * ch
+        ext = rng.random() < 0.3
+        fmt = struct.pack("<HHIIHH", 0xFFFE if ext else tag, ch, rate, (rate * fb) & 0xFFFFFFFF, fb & 0xFFFF, bits)
+        if ext:
+            fmt += struct.pack("<HHI", 22, bits, 3) + struct.pack("<H", tag) + b"\0" * 14
+        data = bytes(rng.integers(0, 256, int(rng.integers(0, 40)) * fb, dtype=np.uint8))
+        junk = b"LIST" + struct.pack("<I", 3) + b"abc\0" if rng.random() < 0.3 else b""
+        body = b"WAVE" + junk + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", len(data)) + data
+        b = bytearray(b"RIFF" + struct.pack("<I", len(body)) + body)
+        for _ in range(int(rng.integers(0, 6))):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        if rng.random() < 0.3:
+            b = b[:int(rng.integers(0, len(b) + 1))]
+        buf = (C.c_ubyte * max(len(b), 1)).from_buffer_copy(bytes(b) if len(b) else b"\0")
+        info = L.WavInfo()
+        if lib.ss_wav_parse(buf, len(b), C.byref(info)) == L.SS_OK:
+            accepted += 1
+            assert info.data_offset + info.data_bytes <= len(b)
+            assert info.channels > 0 and info.format > 0
+            assert info.frames * lib.ss_pcm_sample_bytes(info.format) * info.channels <= info.data_bytes
+    assert accepted > 200                                     # (the mutations leave plenty of valid files)
+
+
 def test_oracle_pcm_conversion_values(oracle):
     assert oracle.pcm_to_f32(bytes([0, 128, 255]), 1).tolist() == [-1.0, 0.0, 127 / 128]
     assert oracle.pcm_to_f32(struct.pack("<hhh", -32768, 0, 32767), 2).tolist() == [-1.0, 0.0, 32767 / 32768]

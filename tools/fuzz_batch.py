@@ -54,6 +54,10 @@ def plan(seed):
         if rng.random() < 0.3:
             g0 = int(rng.integers(0, slot)); x.reshape(slot, ch)[g0:g0 + slot // 3] *= 1e-4
         elif rng.random() < 0.3: x += np.float32(0.05)
+        r2 = np.random.default_rng(seed * 11 + k + 10 ** 6).random()      # (its own generator: the seeds of earlier runs keep their shapes)
+        if r2 < 0.12 and ch == 2: x[1::2] = x[0::2]                        # dual mono: the side row is the -150 dB floor + pink
+        elif r2 < 0.24: x[: ch * (slot // 2)] = 0.0                        # digital silence in front of the programme: empty rows, the floor again
+        elif r2 < 0.30 and ch > 1: x.reshape(slot, ch)[:, ch - 1] = 0.0    # one silent channel
         content.append(x)
     lens = [slot] * ns
     if ragged:
