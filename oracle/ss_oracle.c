@@ -187,6 +187,9 @@ int so_get_fft_ex(uint32_t sample_rate, const float *x, size_t n,
     if (n & (n - 1)) { free(win); return SO_ERR_NOT_POW2; }
     float nyq = (float)sample_rate / 2.0f;
     if (20000.0f > nyq) { free(win); return SO_ERR_FREQ_LIMIT; } /* Range(20,20000).verify */
+    /* the transform: microfft 0.6.0's real FFTs end at 32768 points and spectrum-analyzer 1.7.0 panics for longer inputs
+     * (behind the checks above) — restated as a status, the library's SS_ERR_UNSUPPORTED */
+    if (n > 32768) { free(win); return SO_ERR_UNSUPPORTED; }
 
     float *re = (float *)malloc((n / 2 + 1) * sizeof(float));
     float *im = (float *)malloc((n / 2 + 1) * sizeof(float));
@@ -664,8 +667,13 @@ int so_meter_add_frames_f32(so_meter *m, const float *src, size_t n_samples)
             calc_gating_block(m, m->s100 * 4, 1);                       /* Mode::I */
             m->st_counter += m->needed_frames;                          /* Mode::LRA */
             if (m->st_counter == m->s100 * 30) {
-                double e = calc_gating_block(m, m->s100 * 30, 0);
-                if (e >= g_hist_bounds[0]) m->st_hist[find_histogram_index(e)]++;
+                /* `if let Ok(st_energy) = self.energy_shortterm()`: energy_in_interval refuses an interval longer than the ring
+                 * (InvalidMode) — thirty sub-blocks are at rates under 145 Hz that round up to their sub-block (16 Hz: 60 > 48 frames) —
+                 * and the block is skipped */
+                if (m->s100 * 30 <= m->audio_data_frames) {
+                    double e = calc_gating_block(m, m->s100 * 30, 0);
+                    if (e >= g_hist_bounds[0]) m->st_hist[find_histogram_index(e)]++;
+                }
                 m->st_counter = m->s100 * 20;
             }
             m->needed_frames = m->s100;

@@ -39,7 +39,8 @@ enum {
     SO_ERR_NOT_POW2 = 13,
     SO_ERR_FREQ_LIMIT = 14,
     SO_ERR_SCALING = 15,
-    SO_ERR_CAPACITY = 20
+    SO_ERR_CAPACITY = 20,
+    SO_ERR_UNSUPPORTED = 21      /* where the crates panic: a transform longer than 32768 points */
 };
 
 /* ---- spectrum (analyzer.rs:11-27, :55-105; spectrum-analyzer 1.7.0) ---- */

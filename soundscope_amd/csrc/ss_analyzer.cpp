@@ -225,7 +225,6 @@ int ss_get_fft(const ss_analyzer *hc, const float *samples, size_t n,
     // windowed samples (hann_window runs first, analyzer.rs:57)
     if (n < 2) return SS_ERR_TOO_FEW_SAMPLES;
     const bool pow2 = is_pow2(n);
-    if (n > 32768 && pow2) return SS_ERR_UNSUPPORTED;
     {
         // w[i] == 0 turns an infinite sample into NaN (0 * inf); only the first few
         // window entries can be exactly zero
@@ -245,7 +244,7 @@ int ss_get_fft(const ss_analyzer *hc, const float *samples, size_t n,
             if (std::isnan(x)) { any_nan = true; continue; }
             if (!std::isinf(x)) continue;
             if (!win) {
-                if (pow2) {
+                if (pow2 && n <= 32768) {
                     FftTables *wt = nullptr;
                     int rc = get_fft_tables(n, &wt);
                     if (rc) return rc;
@@ -267,6 +266,9 @@ int ss_get_fft(const ss_analyzer *hc, const float *samples, size_t n,
         h->fft_err_a = 20000.0f; h->fft_err_b = (float)h->rate / 2.0f;
         return SS_ERR_FREQ_LIMIT;
     }
+    // the crate's transform itself: microfft's real FFTs end at 32768 points, spectrum-analyzer panics beyond — behind every
+    // input check above (a NaN in 65536 samples is still reported as a NaN)
+    if (n > 32768) return SS_ERR_UNSUPPORTED;
 
     FftTables *ft; BinTables *bt;
     int rc = get_fft_tables(n, &ft);

@@ -135,9 +135,20 @@ static void choose_td_geometry(ss_batch *b)
     // shortest segment: with the exact hand-over the state a segment leaves is only as good as the segment is long (it started from
     // zero): kTdFixSub sub-blocks at least, so that what it hands on has converged like the fix-up's own re-run
     const uint32_t min_seg = b->td_mode == 1 ? kTdWarmSub : kTdFixSub;
+    // Time segments stand on the filter FORGETTING: a segment starts from zero, and what it hands on (fix-up) or what it ran in
+    // from (mode 1) is right once the zero-input response of the true state has died — radius^n over min_seg sub-blocks,
+    // exp(-48) = 1.6e-21 at every ordinary rate (the 38 Hz high-pass pair: n and 1 - radius scale with the rate alike).  The
+    // crate accepts rates from 16 Hz (a sub-block is 2 frames there; between ~100 Hz and ~3.4 kHz the design is not even
+    // stable): where radius^n has not fallen below 1e-18 a stream is ONE segment (tools/fuzz_handle.py: 0.1 - 1 LU off at 16 Hz).
+    bool forgets = false;
+    {
+        const double r = sst::kweight_pole_radius((double)cfg->sample_rate);
+        const double n = (double)min_seg * (double)b->td->host.s100;
+        forgets = r < 1.0 && n * std::log(r) < std::log(b->td_mode == 1 ? 1e-9 : 1e-18);       // (mode 1 is the approximate one: 4e-11 after its 0.1 s)
+    }
     uint32_t best_seg = 0;
     double best = nsub ? score_of(nsub, 1) : 0.0;                         // one segment: no run-in
-    for (uint32_t want = 2; want <= nsub; want++) {                     // balanced segments: seg = ceil(nsub / want)
+    for (uint32_t want = 2; forgets && want <= nsub; want++) {          // balanced segments: seg = ceil(nsub / want)
         const uint32_t seg = (nsub + want - 1) / want;
         if (seg < min_seg) break;
         const double sc = score_of(seg, (nsub + seg - 1) / seg);
@@ -165,7 +176,7 @@ static void choose_td_geometry(ss_batch *b)
     // wave needs for its segment's tiles, one after the other.  There a segment's tiles are dealt to the eight waves of a
     // workgroup instead (the whole-stream form, per segment): if eight waves per shortest segment still fit the chip at once.
     const uint32_t nseg_min = (nsub + min_seg - 1) / min_seg;
-    if (split_ok && b->td_mode == 0 && !b->td_split && nsub > min_seg && 8.0 * cfg->n_streams * nseg_min <= W0) {
+    if (forgets && split_ok && b->td_mode == 0 && !b->td_split && nsub > min_seg && 8.0 * cfg->n_streams * nseg_min <= W0) {
         b->td_split_segments = true;
         b->td_seg_sub = min_seg;
         b->td_nseg = nseg_min;

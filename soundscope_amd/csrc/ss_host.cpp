@@ -210,6 +210,11 @@ int get_td_tables(uint32_t rate, int factor, uint32_t channels, TdTables **out)
             for (const auto &tap : ph[f]) k.tp[f - 1][tap.delay] = tap.coeff;
     }
     k.s100 = (rate + 5) / 10;
+    {
+        uint64_t ring = (uint64_t)rate * 3000 / 1000;                    // the meter's ring (ss_analyzer.cpp: the same rule)
+        if (ring % k.s100) ring += k.s100 - ring % k.s100;
+        k.st_off = (uint64_t)k.s100 * 30 > ring ? 1u : 0u;
+    }
     std::vector<ssk::TdConst> v(1, k);
     HIPCHK(t->dev.upload(v));
     *out = t.get();

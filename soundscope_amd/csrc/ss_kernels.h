@@ -115,7 +115,9 @@ struct TdConst {                 // one per (rate, true-peak factor), device res
     int32_t tp_factor;           // 0, 2, 4
     int32_t tp_len;              // taps per branch (12 or 24)
     uint32_t s100;               // frames per 100 ms sub-block = (rate + 5) / 10
-    uint32_t pad;
+    uint32_t st_off;             // 1: no short-term blocks at this rate — thirty sub-blocks are more frames than ebur128's 3 s ring holds
+                                 // (rates under 145 Hz that round UP to their sub-block: 16 Hz -> 60 > 48), its energy_shortterm fails
+                                 // and add_frames skips the block; loudness range then reads 0
 };
 
 struct TdState {                 // per stream / per handle, device resident

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(SMALL ? 256 : 1024) void k_finalize(FinalizeParams 
         if (sum >= bd0) atomicAdd(&hb[hist_index(bd, sum)], 1ull);
     }
     // short-term blocks: j = 29 + 10 m.  Dealt densely (thread = m), not as every tenth lane of the loop above
-    {
+    if (!p.k->st_off) {
         const uint64_t m_begin = p.sub_begin > 29 ? (p.sub_begin - 29 + 9) / 10 : 0;      // first m with 29 + 10 m >= sub_begin
         for (uint64_t m = m_begin + lane;; m += nthr) {
             const uint64_t j = 29 + 10 * m;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(64) void k_finalize_stream(FinalizeParams p)
         nb++;
         if (sum >= bd0) atomicAdd(&gh[hist_index(bd, sum)], 1ull);
     }
-    {
+    if (!p.k->st_off) {
         const uint64_t m_begin = p.sub_begin > 29 ? (p.sub_begin - 29 + 9) / 10 : 0;
         for (uint64_t m = m_begin + lane;; m += 64) {
             const uint64_t j = 29 + 10 * m;

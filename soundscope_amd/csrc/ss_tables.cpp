@@ -95,6 +95,29 @@ void kweight_design(double rate, double b[5], double a[5])
     a[4] = pa[2] * ra[2];
 }
 
+// largest pole radius of the K-weighting filter at `rate` (the two biquads of kweight_design, each on its own: the roots of
+// z^2 + a1 z + a2).  Below 1 the filter forgets its state like radius^n; the crate accepts rates (16 Hz .. ~3.4 kHz) at which the
+// 1682 Hz shelf lies beyond Nyquist and the design is not stable at all.
+double kweight_pole_radius(double rate)
+{
+    auto radius = [](double a1, double a2) {
+        const double disc = a1 * a1 - 4.0 * a2;
+        if (disc < 0.0) return std::sqrt(a2);                                   // complex pair: |z|^2 = a2
+        const double r = std::sqrt(disc);
+        return std::fmax(std::fabs((-a1 + r) * 0.5), std::fabs((-a1 - r) * 0.5));
+    };
+    double f0 = 1681.974450955533, Q = 0.7071752369554196;
+    double K = std::tan(M_PI * f0 / rate);
+    double a0 = 1.0 + K / Q + K * K;
+    const double r_shelf = radius(2.0 * (K * K - 1.0) / a0, (1.0 - K / Q + K * K) / a0);
+    f0 = 38.13547087602444; Q = 0.5003270373238773;
+    K = std::tan(M_PI * f0 / rate);
+    a0 = 1.0 + K / Q + K * K;
+    const double r_hp = radius(2.0 * (K * K - 1.0) / a0, (1.0 - K / Q + K * K) / a0);
+    const double r = std::fmax(r_shelf, r_hp);
+    return std::isfinite(r) ? r : 2.0;
+}
+
 static void mat4_mul(const long double *x, const long double *y, long double *o)
 {
     long double t[16];

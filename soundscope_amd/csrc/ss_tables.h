@@ -28,6 +28,7 @@ void bin_tables(uint32_t sample_rate, size_t n, std::vector<double> &freq,
 void kweight_design(double rate, double b[5], double a[5]);
 // zero-input state transition of the DF-II state (v1..v4) over `steps` samples,
 // row-major 4x4
+double kweight_pole_radius(double rate);      // largest pole radius of the K-weighting filter (>= 1: not stable at this rate)
 void kweight_transition_pow(const double a[5], uint64_t steps, double out[16]);
 
 // ebur128 true-peak interpolator: 49-tap Hann-windowed sinc split into

@@ -85,6 +85,29 @@ def test_get_fft_error_order():
     assert code(np.zeros(1024, np.float32)) == L.SS_ERR_FREQ_LIMIT
 
 
+def test_get_fft_longer_than_the_crates_transform_is_refused_behind_the_input_checks(oracle):
+    """microfft's real FFTs end at 32768 points (spectrum-analyzer panics beyond: SS_ERR_UNSUPPORTED) — but the input checks
+    run first, in the crate's order: a NaN among 65536 samples is a NaN, 20 kHz above Nyquist is the frequency limit."""
+    an = ssa.Analyzer()
+    def code(x):
+        with pytest.raises(ssa.AnalyzerError) as e:
+            an.get_fft(x)
+        with pytest.raises(oracle.OracleError) as oe:
+            oracle.get_fft(an.sample_rate(), x)
+        assert e.value.code == oe.value.code
+        return e.value.code
+    x = np.zeros(65536, np.float32)
+    assert code(x) == L.SS_ERR_UNSUPPORTED
+    x[777] = np.nan
+    assert code(x) == L.SS_ERR_NAN
+    x[777] = np.inf
+    assert code(x) == L.SS_ERR_INFINITY
+    an.create_loudness_meter(2, 22050)
+    assert code(np.zeros(65536, np.float32)) == L.SS_ERR_FREQ_LIMIT
+    assert code(np.zeros(65536 + 2, np.float32)) == L.SS_ERR_NOT_POW2
+    an.close()
+
+
 def test_get_fft_error_payloads(oracle):
     """The two SpectrumAnalyzerError variants with a payload (analyzer.rs:60-65 -> the text at tui.rs:1439-1442) carry it across
     the ABI: ValueAboveNyquist(limit) and ScalingError(original, scaled) of the first spoiled bin."""
@@ -332,6 +355,45 @@ def test_calculate_integrated_lufs(oracle):
     s = (10 ** (-23 / 20) * np.sin(2 * np.pi * 1000 * t)).astype(np.float32)
     st = np.repeat(s, 2)
     assert an.calculate_integrated_lufs(2, st) == pytest.approx(-23.0, abs=0.1)
+
+
+@pytest.mark.parametrize("rate,frames", [(16, 4610), (16, 490), (31, 3000), (64, 5000), (199, 5000), (3400, 20000), (3500, 20000)])
+def test_rates_at_which_the_filter_does_not_forget(oracle, rate, frames):
+    """The crate accepts rates from 16 Hz: a 100 ms sub-block is two frames there and the K-weighting poles (radius 0.58) have not
+    died over a time segment; between ~100 Hz and 3.4 kHz the design is not stable at all.  The batch's time segments (each from a
+    zero state, exact hand-over by re-running their first 0.2 s) stand on the filter forgetting: at such rates a stream is ONE
+    segment (tools/fuzz_handle.py: 0.1 - 1 LU off at 16 Hz before).  Batch path, one-shot path and handle against the oracle;
+    and thirty sub-blocks are more than the 3 s ring holds at 16 Hz: no short-term blocks, loudness range 0."""
+    rng = np.random.default_rng(rate + frames)
+    x = (0.3 * rng.uniform(-1, 1, frames)).astype(np.float32)
+    ref = oracle.calculate_integrated_lufs(rate, 1, x)
+    an = ssa.Analyzer(); an.create_loudness_meter(1, rate)
+    assert lufs_close(an.calculate_integrated_lufs(1, x), ref, 1e-9)
+    m = oracle.Meter(1, rate); m.add_frames(x)
+    an.add_samples(x)
+    assert lufs_close(an.get_integrated_lufs(), m.integrated(), 1e-9)
+    assert abs(an.get_loudness_range() - m.loudness_range()) <= 1e-9
+    b = ssa.Batch(rate, 1, 3, frames, 4096, 1024, flags=L.SS_BATCH_LUFS)
+    b.upload(0, np.concatenate([x, x, x])); b.run(); b.sync()
+    g = b.geometry
+    assert (g.td_segments == 1) == (rate < 3500), (g.td_segments, rate)
+    for r in b.results():
+        assert lufs_close(r.integrated_lufs, ref, 1e-9) and abs(r.loudness_range - m.loudness_range()) <= 1e-9
+    if rate == 16:
+        assert m.loudness_range() == 0.0 and int(m.st_hist().sum()) == 0
+    an.close(); b.close()
+
+
+@pytest.mark.parametrize("seed", [3, 10, 122, 145, 202, 208])
+def test_randomised_handle_programme(oracle, seed):
+    """tools/fuzz_handle.py: a random sequence of the reference's Analyzer calls on one handle against a mirror built from the
+    oracle (the seeds are the first run's findings: low rates, the short-term blocks the crate's ring cannot hold, the order of
+    get_fft's checks)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_handle
+    ok, msg = fuzz_handle.programme(seed)
+    assert ok, msg
 
 
 def test_calculate_integrated_lufs_reuses_its_batch_across_shapes(oracle):

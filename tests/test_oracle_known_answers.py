@@ -452,3 +452,23 @@ def test_filter_ftz_models_agree_on_every_reading(oracle, rate, slice_len):
             assert not np.any((np.abs(sa) < tiny) & (sa != 0.0)), (off, c, sa)          # end-of-call model: no sub-normal is carried
     assert not a.filter_state(0).any()                                                  # the end-of-call model ends at exactly zero
     assert seen_subnormal_gap and np.abs(b.filter_state(0)).max() < 1e-300              # the per-operation model near DBL_MIN
+
+
+def test_get_fft_beyond_the_crates_longest_transform_and_short_term_blocks_beyond_its_ring(oracle):
+    """Two places where the crates stop: spectrum-analyzer panics beyond microfft's 32768-point transform (restated as status 21,
+    behind the input checks), and ebur128's energy_shortterm refuses an interval longer than its ring — thirty sub-blocks of
+    (rate + 5) / 10 frames are 60 frames at 16 Hz, the ring 48 — so add_frames adds no short-term block there."""
+    import pytest
+    x = np.zeros(65536, np.float32)
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.get_fft(48000, x)
+    assert e.value.code == 21
+    x[5] = np.nan
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.get_fft(48000, x)
+    assert e.value.code == 11
+    rng = np.random.default_rng(16)
+    m = oracle.Meter(1, 16); m.add_frames((0.3 * rng.uniform(-1, 1, 4000)).astype(np.float32))
+    assert int(m.st_hist().sum()) == 0 and m.loudness_range() == 0.0 and int(m.block_hist().sum()) > 100
+    m = oracle.Meter(1, 8005); m.add_frames((0.3 * rng.uniform(-1, 1, 8005 * 6)).astype(np.float32))   # 801 x 30 = 24030 = the ring, rounded up
+    assert int(m.st_hist().sum()) == 3

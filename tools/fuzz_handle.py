@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Randomised call sequences on ONE handle (the reference's `Analyzer`, analyzer.rs:29-183) against a mirror built from the oracle: meter
+re-creation with valid and invalid arguments (the rate sticks, the meter survives a failed call), add_samples of random lengths incl.
+partial frames, every getter, reset, get_fft of every length class (too short, not a power of two, NaN / infinite samples, above
+Nyquist, 2 .. 65536 points), the handle-less get_waveform with odd windows and NaN, calculate_integrated_lufs across shapes (the
+library keeps one loudness-only batch for it).  Statuses, values and the order of the error checks.
+python tools/fuzz_handle.py [programmes] [first seed] [-v]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import soundscope_amd as ssa
+from soundscope_amd import _lib as L
+from oracle import pyoracle as po
+from conftest import db_close, make_multich
+
+RATES = [15, 16, 8000, 22050, 32000, 40000, 44100, 48000, 48000, 96000, 192000, 705600, 2822400, 2822401]
+CHANS = [0, 1, 2, 2, 2, 3, 6, 8, 16, 64, 65]
+
+
+def close_lu(a, b, tol=0.01):
+    if np.isnan(a) or np.isnan(b): return np.isnan(a) and np.isnan(b)
+    if np.isinf(a) or np.isinf(b): return a == b
+    return abs(a - b) <= tol
+
+
+def programme(seed, steps=40):
+    rng = np.random.default_rng(seed)
+    an = ssa.Analyzer()                                      # default: 2 channels, 44100 Hz (analyzer.rs:34-45)
+    rate, ch = 44100, 2
+    m = po.Meter(2, 44100)
+    log = []
+    def fail(msg):
+        an.close()
+        return False, f"seed {seed}: " + " | ".join(log if "-vv" in sys.argv else log[-4:]) + " -> " + msg
+    def signal(n, channels):
+        x = make_multich(int(rng.integers(0, 1 << 30)), n, max(channels, 1), max(rate, 1000), level=float(rng.uniform(1e-4, 1.2)))
+        if n and rng.random() < 0.2: x[: x.size // 2] *= 1e-3
+        return x
+    def readings():
+        """the four loudness readings of handle and mirror (None = equal)"""
+        for name, got_f, ref_f in (("shortterm", an.get_shortterm_lufs, m.shortterm), ("momentary", an.get_momentary_lufs, m.momentary),
+                                   ("integrated", an.get_integrated_lufs, m.integrated), ("range", an.get_loudness_range, m.loudness_range)):
+            try: ref = ref_f()
+            except po.OracleError as e: ref = ("err", e.code)
+            try: got = got_f()
+            except ssa.AnalyzerError as e: got = ("err", e.code)
+            if isinstance(ref, tuple) or isinstance(got, tuple):
+                if not (isinstance(ref, tuple) and isinstance(got, tuple)): return f"{name}: {got} vs {ref}"
+            elif not close_lu(got, ref): return f"{name}: {got} vs {ref}"
+        return None
+    for step in range(steps):
+        if "--check-every" in sys.argv and step:
+            r = readings()
+            if r: return fail("(after the last step) " + r)
+        op = rng.choice(["create", "add", "add", "add", "getters", "getters", "reset", "fft", "fft", "wave", "oneshot"])
+        if op == "create":
+            c2, r2 = int(rng.choice(CHANS)), int(rng.choice(RATES))
+            if r2 > 200000 and c2 > 2: c2 = 2                # (the meter's ring is 3 s x rate x channels doubles)
+            log.append(f"create({c2}, {r2})")
+            valid = 1 <= c2 <= 64 and 16 <= r2 <= 2822400
+            try:
+                an.create_loudness_meter(c2, r2); ok = True
+            except ssa.AnalyzerError as e:
+                ok = False
+                if e.code != L.SS_ERR_NOMEM: return fail(f"status {e.code}")
+            if ok != valid: return fail(f"accepted {ok}, the crate accepts {valid}")
+            rate = r2                                        # analyzer.rs:50: set before the fallible call
+            if an.sample_rate() != rate: return fail(f"sample_rate {an.sample_rate()}")
+            if ok: ch = c2; m = po.Meter(ch, rate)
+        elif op == "add":
+            frames = int(rng.choice([0, 1, 7, int(rng.integers(1, max(2, m.rate // 3))), int(rng.integers(1, max(2, m.rate // 20))), 8192]))
+            frames = min(frames, 400000)
+            x = signal(frames, m.channels)
+            partial = m.channels > 1 and rng.random() < 0.1 and x.size > 1
+            if partial: x = x[:-1]
+            log.append(f"add({frames} frames{' - 1 sample' if partial else ''})")
+            try:
+                an.add_samples(x); ok = True
+            except ssa.AnalyzerError as e:
+                ok = False
+                if e.code != L.SS_ERR_NOMEM: return fail(f"status {e.code}")
+            if ok == partial: return fail(f"partial frame accepted {ok}")
+            if ok: m.add_frames(x)
+        elif op == "reset":
+            log.append("reset"); an.reset(); m.reset()
+        elif op == "getters":
+            log.append("getters")
+            r = readings()
+            if r: return fail(r)
+            try:
+                l, r = an.get_true_peak()
+                if m.channels < 2: return fail("get_true_peak worked on a mono meter")
+                for c, v in ((0, l), (1, r)):
+                    ref = max(m.true_peak(c), m.sample_peak(c))
+                    if not abs(v - ref) <= 1e-4 * max(ref, 1e-30): return fail(f"true peak ch {c}: {v} vs {ref}")
+            except ssa.AnalyzerError as e:
+                if not (m.channels < 2 and e.code == L.SS_ERR_INVALID_CHANNEL): return fail(f"get_true_peak status {e.code}")
+            c = int(rng.integers(0, m.channels + 2))
+            try:
+                v = an.get_true_peak_channel(c); s = an.get_sample_peak_channel(c)
+                if c >= m.channels: return fail(f"peak of channel {c} of {m.channels}")
+                ref = max(m.true_peak(c), m.sample_peak(c))
+                if not abs(v - ref) <= 1e-4 * max(ref, 1e-30) or s != m.sample_peak(c): return fail(f"peaks ch {c}: {v} {s} vs {ref} {m.sample_peak(c)}")
+            except ssa.AnalyzerError as e:
+                if not (c >= m.channels and e.code == L.SS_ERR_INVALID_CHANNEL): return fail(f"peak channel {c} status {e.code}")
+        elif op == "fft":
+            n = int(rng.choice([0, 1, 2, 4, 64, 1000, 1024, 2048, 4096, 4096, 8192, 16384, 16384, 32768, 65536, int(rng.integers(2, 5000))]))
+            t = np.arange(n) / max(rate, 1)
+            x = (float(rng.uniform(1e-5, 1.0)) * np.sin(2 * np.pi * float(rng.uniform(20, 15000)) * t) + 0.01 * rng.standard_normal(n)).astype(np.float32)
+            r = rng.random()
+            if n and r < 0.1: x[int(rng.integers(0, n))] = np.nan
+            elif n and r < 0.2: x[int(rng.integers(0, n))] = np.inf if rng.random() < 0.5 else -np.inf
+            elif n and r < 0.25: x[:] = 0.0
+            elif n and r < 0.28: x = (x * np.float32(3.0e38)).astype(np.float32)
+            log.append(f"fft(n {n}, rate {rate})")
+            try: ref = po.get_fft(rate, x)
+            except po.OracleError as e: ref = e.code
+            try: got = an.get_fft(x)
+            except ssa.AnalyzerError as e: got = e.code
+            if isinstance(ref, int) or isinstance(got, int):
+                if not (isinstance(ref, int) and isinstance(got, int) and ref == got):
+                    return fail(f"get_fft status {got if isinstance(got, int) else 'ok'} vs {ref if isinstance(ref, int) else 'ok'}")
+            else:
+                if got.shape != ref.shape: return fail(f"get_fft shape {got.shape} vs {ref.shape}")
+                if ref.shape[0] and not (np.array_equal(got[:, 0], ref[:, 0]) and db_close(got[:, 1], ref[:, 1], 0.01)): return fail("get_fft values")
+        elif op == "wave":
+            n = int(rng.choice([0, 1, 7, 100, 1000, 44100, int(rng.integers(0, 300000))]))
+            x = rng.uniform(-1, 1, n).astype(np.float32)
+            if n and rng.random() < 0.3: x[int(rng.integers(0, n)):][:int(rng.integers(1, 50))] = np.nan
+            if n and rng.random() < 0.1: x[int(rng.integers(0, n))] = np.inf
+            w = float(rng.choice([0.0, -1.0, 0.001, 0.3, 15.0, n / 48000.0, float(rng.uniform(0, 30)), 3.0000001]))
+            log.append(f"wave(n {n}, window {w})")
+            got, ref = ssa.Analyzer.get_waveform(x, w), po.get_waveform(x, w)
+            if got.shape != ref.shape or not np.array_equal(got, ref, equal_nan=True): return fail(f"get_waveform {got.shape} vs {ref.shape}")
+        else:
+            c2 = int(rng.choice([0, 1, 2, 2, 2, 6, 8]))
+            frames = int(rng.choice([0, 1, 4799, int(rng.integers(1, 200000)), int(rng.integers(1, 20000))]))
+            frames = min(frames, int(6e6 // max(c2, 1)))
+            x = signal(frames, c2)
+            if c2 > 1 and rng.random() < 0.1 and x.size > 1: x = x[:-1]
+            log.append(f"oneshot({c2} ch, {x.size} samples, rate {rate})")
+            got, ref = an.calculate_integrated_lufs(c2, x), po.calculate_integrated_lufs(rate, c2, x)
+            if (got is None) != (ref is None) or (got is not None and not close_lu(got, ref)): return fail(f"calculate_integrated_lufs {got} vs {ref}")
+    an.close()
+    return True, f"seed {seed}: {steps} steps" + (" [" + " | ".join(log) + "]" if "-vv" in sys.argv else "")
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    failed = 0
+    for seed in range(first, first + n):
+        try:
+            ok, msg = programme(seed)
+        except Exception as e:                               # noqa: BLE001
+            import traceback
+            ok, msg = False, f"seed {seed}: exception {type(e).__name__}: {e} @ {traceback.extract_tb(e.__traceback__)[-1].lineno}"
+        failed += 0 if ok else 1
+        if not ok or "-v" in sys.argv:
+            print(("ok   " if ok else "FAIL ") + msg, flush=True)
+    print(f"{n} handle programmes, {failed} failed")
+    sys.exit(1 if failed else 0)
