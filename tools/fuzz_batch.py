@@ -77,22 +77,35 @@ def programme(seed):
     try: b.set_time_domain_mode(mode)
     except ssa.AnalyzerError: pass
     b.set_true_peak_arith(arith)
-    if ragged: b.set_lengths(lens)
-    buf = np.full((ns, slot * ch), 7.0, np.float32)
-    for i in range(ns): buf[i, :lens[i] * ch] = content[i % kinds][:lens[i] * ch]
-    b.upload(0, buf.reshape(-1))
-    b.run(); b.sync()
-    res = b.results()
     lay = b.layout
     refs = {}
     ok, notes = True, []
     def bad(msg):
         nonlocal ok
         ok = False; notes.append(msg)
-    check = sorted(set([0, ns - 1] + [int(v) for v in rng.integers(0, ns, 6)]))
-    for i in check:
-        n = lens[i]; key = (i % kinds, n)
-        x = content[i % kinds][:n * ch]
+    # the batch is used up to three times ("--reuse"): new lengths (ragged from then on), the contents dealt differently, and the
+    # hand-over mode switched — what a pipeline that keeps its batch does (the one-shot loudness call keeps one)
+    r3 = np.random.default_rng(seed + 2 * 10 ** 6)
+    passes = 1 + (int(r3.integers(0, 3)) if "--reuse" in sys.argv else 0)
+    for pass_no in range(passes):
+      rot = 0
+      if pass_no:
+        ragged = True
+        lens = [int(r3.choice([slot, int(r3.integers(0, slot + 1)), slot // 3, 0])) for _ in range(ns)]
+        rot = int(r3.integers(0, kinds))
+        try: b.set_time_domain_mode(int(r3.choice([L.SS_TD_AUTO, L.SS_TD_RUN_IN, L.SS_TD_WHOLE_STREAMS])))
+        except ssa.AnalyzerError: pass
+      if ragged: b.set_lengths(lens)
+      buf = np.full((ns, slot * ch), 7.0, np.float32)
+      for i in range(ns): buf[i, :lens[i] * ch] = content[(i + rot) % kinds][:lens[i] * ch]
+      b.upload(0, buf.reshape(-1))
+      b.run(); b.sync()
+      res = b.results()
+      check = sorted(set([0, ns - 1] + [int(v) for v in rng.integers(0, ns, 6)]))
+      for i_ in check:
+        i = i_
+        n = lens[i]; key = ((i + rot) % kinds, n)
+        x = content[(i + rot) % kinds][:n * ch]
         if key not in refs:
             r = {}
             if n:
@@ -103,25 +116,25 @@ def programme(seed):
             refs[key] = r
         r = refs[key]
         if n == 0:
-            if not (res[i].integrated_lufs == -np.inf and res[i].loudness_range == 0.0): bad(f"stream {i}: empty stream reads {res[i].integrated_lufs} {res[i].loudness_range}")
+            if not (res[i].integrated_lufs == -np.inf and res[i].loudness_range == 0.0): bad(f"pass {pass_no} stream {i}: empty stream reads {res[i].integrated_lufs} {res[i].loudness_range}")
             continue
         if flags & L.SS_BATCH_LUFS:
-            if not lufs_close(res[i].integrated_lufs, r["I"]): bad(f"stream {i}: I {res[i].integrated_lufs} vs {r['I']}")
-            if not abs(res[i].loudness_range - r["lra"]) <= 0.01: bad(f"stream {i}: LRA {res[i].loudness_range} vs {r['lra']}")
+            if not lufs_close(res[i].integrated_lufs, r["I"]): bad(f"pass {pass_no} stream {i}: I {res[i].integrated_lufs} vs {r['I']}")
+            if not abs(res[i].loudness_range - r["lra"]) <= 0.01: bad(f"pass {pass_no} stream {i}: LRA {res[i].loudness_range} vs {r['lra']}")
         tp, sp = b.peaks(i)
         if flags & L.SS_BATCH_TRUE_PEAK:
             for c in range(ch):
-                if not abs(tp[c] - r["tp"][c]) <= 1e-4 * max(abs(r["tp"][c]), 1e-30): bad(f"stream {i} ch {c}: true peak {tp[c]} vs {r['tp'][c]}")
-                if sp[c] != r["sp"][c]: bad(f"stream {i} ch {c}: sample peak {sp[c]} vs {r['sp'][c]}")
+                if not abs(tp[c] - r["tp"][c]) <= 1e-4 * max(abs(r["tp"][c]), 1e-30): bad(f"pass {pass_no} stream {i} ch {c}: true peak {tp[c]} vs {r['tp'][c]}")
+                if sp[c] != r["sp"][c]: bad(f"pass {pass_no} stream {i} ch {c}: sample peak {sp[c]} vs {r['sp'][c]}")
         if flags & L.SS_BATCH_WAVEFORM:
             w = b.waveform(i).reshape(-1)
             want = r["wave"][:, 1].astype(np.float32)
             if ragged: w = w[:want.size]
-            if not (w.size == want.size and np.array_equal(w, want, equal_nan=True)): bad(f"stream {i}: waveform differs ({w.size} vs {want.size} points)")
+            if not (w.size == want.size and np.array_equal(w, want, equal_nan=True)): bad(f"pass {pass_no} stream {i}: waveform differs ({w.size} vs {want.size} points)")
         if flags & L.SS_BATCH_FFT:
             nw = max(0, n // hop - fft_n // hop)
             got_nw = b.stream_shape(i).n_windows if ragged else lay.n_windows
-            if got_nw != nw: bad(f"stream {i}: {got_nw} windows vs {nw}")
+            if got_nw != nw: bad(f"pass {pass_no} stream {i}: {got_nw} windows vs {nw}")
             elif nw:
                 fft = b.fft(i)
                 xm = x.reshape(n, ch)
@@ -131,7 +144,7 @@ def programme(seed):
                     start = (wdx + fft_n // hop + 1) * hop - fft_n      # positions p = k hop with N < p <= F, window [p - N, p) (tui.rs:1489)
                     for c in sorted(set([0, len(sig) - 1])):
                         ref = po.get_fft(rate, sig[c][start:start + fft_n])[:, 1]
-                        if not db_close(fft[wdx, c], ref, 0.01): bad(f"stream {i} window {wdx} ch {c}: spectrum row differs {db_report(fft[wdx, c], ref)} row peak {float(ref.max()):.1f} dB")
+                        if not db_close(fft[wdx, c], ref, 0.01): bad(f"pass {pass_no} stream {i} window {wdx} ch {c}: spectrum row differs {db_report(fft[wdx, c], ref)} row peak {float(ref.max()):.1f} dB")
     g = b.geometry
     b.close()
     return ok, what + f" [segments {g.td_segments} x {g.td_segment_subblocks}, split {g.td_split}, fixup {g.td_fixup_subblocks}]" + ("" if ok else " -> " + "; ".join(notes[:6]))
