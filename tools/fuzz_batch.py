@@ -3,7 +3,7 @@
 round), window / hop, true-peak factor and arithmetic, time-domain hand-over mode, now and then ragged lengths — the shapes the
 batch's geometry rules (segments, fix-up launch, split segments, whole-stream workgroups, small-batch gating, spectrum run lengths)
 switch on.  Per stream: integrated loudness, range, every channel's true and sample peak, the decimated waveform bit for bit, three
-spectrum rows.      python tools/fuzz_batch.py [programmes] [first seed] [--big] [-v]"""
+spectrum rows.      python tools/fuzz_batch.py [programmes] [first seed] [--big] [--wide] [--reuse] [-v]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,11 +29,13 @@ def plan(seed):
     rng = np.random.default_rng(seed)
     rate = int(rng.choice(RATES)); ch = int(rng.choice(CHANNELS)); ns = int(rng.choice(STREAMS))
     big = "--big" in sys.argv                                # long streams: many segments, the fix-up launch, long spectrum runs
-    secs = float(np.exp(rng.uniform(np.log(2.0 if big else 0.02), np.log(40.0 if big else 25.0))))
+    wide = "--wide" in sys.argv                              # grids of more than 768 workgroups: the four-waves-per-SIMD kernel builds
+    if wide: ns = int(rng.choice([700, 1024, 1500, 3000]))
+    secs = float(np.exp(rng.uniform(np.log(2.0 if big else 0.02), np.log(40.0 if big else (1.5 if wide else 25.0)))))
     budget = 24_000_000 if big else 6_000_000                # samples of DISTINCT content per programme (the oracle's time)
     kinds = int(min(ns, rng.integers(1, 5)))
     slot = max(1, min(int(rate * secs) + int(rng.integers(0, 97)), budget // (kinds * ch)))
-    while ns * slot * ch > 400_000_000: ns = max(1, ns // 2)
+    while ns * slot * ch > (300_000_000 if wide else 400_000_000): slot = max(1, slot // 2) if wide else slot; ns = ns if wide else max(1, ns // 2)
     kinds = min(kinds, ns)
     fft_ok = rate >= 40000
     fft_n, hop = [(4096, 1024), (4096, 1024), (4096, 512), (4096, 1000), (16384, 1024), (2048, 512)][int(rng.integers(0, 6))]
