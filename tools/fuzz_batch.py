@@ -79,6 +79,8 @@ def programme(seed):
     try: b.set_time_domain_mode(mode)
     except ssa.AnalyzerError: pass
     b.set_true_peak_arith(arith)
+    ov = int(np.random.default_rng(seed + 3 * 10 ** 6).choice([0, 0, 1, 2]))      # the spectrum kernel beside the time-domain chain (opt-in modes)
+    if ov: b.set_overlap(ov)
     lay = b.layout
     refs = {}
     ok, notes = True, []
