@@ -397,6 +397,7 @@ def main():
         raise SystemExit("ss_set_device failed: " + lib.ss_last_device_error().decode())
     comm = None
     if world > 1:
+        os.environ["SS_COMM_DEVICE"] = str(dev)   # the communicator's GPU = this rank's GPU (LOCAL_RANK, or 0 in the shared-GPU launch check)
         # The ranks must agree on the transport BEFORE using it.  With --allow-host-fallback every rank first joins a host-TCP
         # control communicator, tries RCCL (the library makes ncclCommInitRank all-or-nothing across ranks and bounds it with
         # a watchdog), and the ranks then sum their verdicts over the control channel: RCCL is used only if every rank has

@@ -365,16 +365,33 @@ static int comm_init_impl(int transport, int rank, int world, int device, const 
     std::string err;
     ncclUniqueId id;
     std::memset(&id, 0, sizeof id);
-    if (transport == SS_COMM_RCCL) {
+    // What can go wrong on THIS rank before the ranks have met — no such device, no librccl, no memory — is kept as a verdict
+    // (world > 1) and exchanged right behind the join: every rank then fails within seconds with the reason, instead of the
+    // healthy ones waiting out SS_COMM_TIMEOUT_S at the rendezvous or inside ncclCommInitRank for a rank that has already left
+    // (tools/launch_path_two_ranks.sh: a rank whose LOCAL_RANK names no device cost its peer 2 x 180 s).
+    std::string local_why;
+    auto local_setup = [&]() -> bool {
+        if (transport != SS_COMM_RCCL) return true;
         if (world > 1) default_hsa_ipc_mode();            // before this call's (possibly the process' first) HIP call
-        if (ss_device_count() <= 0) return SS_ERR_DEVICE;
+        if (ss_device_count() <= 0) { local_why = "no HIP device"; return false; }
         // device >= 0 (ss_comm_init_on_device, ss_comm_init_from_env): this call makes the rank's GPU current ITSELF, behind the
         // setenv above — the order a rank off device 0 cannot get by calling ss_set_device first (that call starts the HSA runtime)
-        if (device >= 0) COMM_HIP(hipSetDevice(device));
-        COMM_HIP(hipGetDevice(&c->device));
-        if (!rccl_open(c->rccl, err)) return fail(err);
-        if (rank == 0) COMM_NCCL(c, c->rccl.GetUniqueId(&id));
-    }
+        hipError_t e = device >= 0 ? hipSetDevice(device) : hipSuccess;
+        if (e != hipSuccess) { local_why = "hipSetDevice(" + std::to_string(device) + "): " + hipGetErrorString(e); return false; }
+        e = hipGetDevice(&c->device);
+        if (e != hipSuccess) { local_why = std::string("hipGetDevice: ") + hipGetErrorString(e); return false; }
+        if (!rccl_open(c->rccl, local_why)) return false;
+        if (rank == 0) {
+            const ncclResult_t r = c->rccl.GetUniqueId(&id);
+            if (r != ncclSuccess) { local_why = std::string("ncclGetUniqueId: ") + c->rccl.GetErrorString(r); return false; }
+        }
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc(&c->dev_scratch, ss_comm::kScratchBytes);
+        if (e != hipSuccess) { local_why = std::string("stream / scratch: ") + hipGetErrorString(e); return false; }
+        return true;
+    };
+    const bool local_ok = local_setup();
+    if (!local_ok && world == 1) return fail(local_why);
     int port = 0;
     if (world > 1) {
         if (rank == 0) {
@@ -403,9 +420,12 @@ static int comm_init_impl(int transport, int rank, int world, int device, const 
                 return fail("rendezvous file holds no RCCL id (mixed transports?)");
         }
     }
+    if (world > 1) {                                        // the ranks have met: does every one of them stand?
+        uint64_t bad = local_ok ? 0 : 1;
+        const int rc = tcp_allreduce(c, &bad, 1, 0);
+        if (rc != SS_OK || bad) return fail(!local_ok ? local_why : rc != SS_OK ? std::string("the join handshake broke") : std::string("another rank could not set up its device or librccl"));
+    }
     if (transport == SS_COMM_RCCL) {
-        COMM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        COMM_HIP(hipMalloc(&c->dev_scratch, ss_comm::kScratchBytes));
         // ncclCommInitRank blocks until every rank has called it; a rank that failed earlier would leave the others there
         // for good, so it runs under a watchdog (the helper thread is abandoned on a timeout: the process is about to fail)
         struct InitJob { Rccl *r; ncclComm_t comm = nullptr; int world, rank, device; ncclUniqueId id; };

@@ -169,3 +169,31 @@ def test_comm_init_on_device_entry_point_and_its_argument_checks():
     assert L.lib().ss_comm_init_on_device(L.SS_COMM_HOST_TCP, 0, 1, -1, None, C.byref(h)) == L.SS_ERR_INVALID_ARG
     if L.lib().ss_device_count() <= 0:
         assert L.lib().ss_comm_init_on_device(L.SS_COMM_RCCL, 0, 1, 0, None, C.byref(h)) == L.SS_ERR_DEVICE
+
+
+def test_a_rank_that_cannot_set_up_takes_every_rank_down_within_seconds(tmp_path):
+    """RCCL transport, two ranks, no usable GPU on this box: what goes wrong on a rank BEFORE the ranks meet (no device, a device
+    ordinal that does not exist, no librccl) is exchanged right behind the join, so every rank fails within seconds and names the
+    reason — the healthy ones do not wait out SS_COMM_TIMEOUT_S for a peer that has already left (a rank whose LOCAL_RANK named
+    no device cost its peer 2 x 180 s: tools/launch_path_two_ranks.sh).  Here both ranks lack a device."""
+    import time
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the device-less form; tools/probe_comm_bad_rank.py is the one-bad-rank form for a GPU box")
+    f = str(tmp_path / "rdzv")
+    code = ("import sys, time; sys.path.insert(0, %r)\n"
+            "from soundscope_amd.distributed import Comm\n"
+            "t0 = time.time()\n"
+            "try:\n"
+            "    Comm(int(sys.argv[1]), 2, sys.argv[2], transport='rccl', device=int(sys.argv[1]))\n"
+            "    print('CREATED')\n"
+            "except Exception as e:\n"
+            "    print(f'REFUSED {time.time() - t0:.1f} {e}')\n") % ROOT
+    env = dict(os.environ, SS_COMM_TIMEOUT_S="60")
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), f], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in (1, 0)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert time.time() - t0 < 30.0, outs
+    for o in outs:
+        assert "REFUSED" in o and "no HIP device" in o, o
