@@ -29,6 +29,8 @@ def programme(seed, steps=40):
     an = ssa.Analyzer()                                      # default: 2 channels, 44100 Hz (analyzer.rs:34-45)
     rate, ch = 44100, 2
     m = po.Meter(2, 44100)
+    tpf = 0                                                  # ss_analyzer_set_true_peak_factor: applies at the next configure or reset
+    r4 = np.random.default_rng(seed + 4 * 10 ** 6)           # (its own generator: earlier runs' seeds keep their sequences)
     log = []
     def fail(msg):
         an.close()
@@ -50,6 +52,10 @@ def programme(seed, steps=40):
             elif not close_lu(got, ref): return f"{name}: {got} vs {ref}"
         return None
     for step in range(steps):
+        if r4.random() < 0.08:                               # now and then: another true-peak factor (pending) / the other arithmetic (at once)
+            tpf = int(r4.choice([0, 2, 4])); an.set_true_peak_factor(tpf); log.append(f"tp_factor({tpf})")
+        if r4.random() < 0.08:
+            a = int(r4.choice([L.SS_TP_ARITH_F32, L.SS_TP_ARITH_F16X3])); an.set_true_peak_arith(a); log.append(f"tp_arith({a})")
         if "--check-every" in sys.argv and step:
             r = readings()
             if r: return fail("(after the last step) " + r)
@@ -67,7 +73,7 @@ def programme(seed, steps=40):
             if ok != valid: return fail(f"accepted {ok}, the crate accepts {valid}")
             rate = r2                                        # analyzer.rs:50: set before the fallible call
             if an.sample_rate() != rate: return fail(f"sample_rate {an.sample_rate()}")
-            if ok: ch = c2; m = po.Meter(ch, rate)
+            if ok: ch = c2; m = po.Meter(ch, rate, force_tp_factor=tpf)
         elif op == "add":
             frames = int(rng.choice([0, 1, 7, int(rng.integers(1, max(2, m.rate // 3))), int(rng.integers(1, max(2, m.rate // 20))), 8192]))
             frames = min(frames, 400000)
@@ -83,7 +89,7 @@ def programme(seed, steps=40):
             if ok == partial: return fail(f"partial frame accepted {ok}")
             if ok: m.add_frames(x)
         elif op == "reset":
-            log.append("reset"); an.reset(); m.reset()
+            log.append("reset"); an.reset(); m = po.Meter(m.channels, m.rate, force_tp_factor=tpf)       # (a fresh mirror = a reset one, with the pending factor)
         elif op == "getters":
             log.append("getters")
             r = readings()
