@@ -24,6 +24,7 @@ pmc() {   # pmc <name> <probe script> <probe args> <counters...>
   fi
   rm -rf $out/pmc_$name
 }
+[ "${SKIP_PMC:-0}" = 1 ] && { cat $out/bench.json | head -c 600; echo; cat $out/kernel_stats.txt | head -24; exit 0; }     # bench line + kernel trace only
 for cfg in "c3 tools/perf_probe.py 1024_2" "c5 tools/probe_cfg5.py 64"; do
   set -- $cfg; n=$1; probe=$2; pargs=${3//_/ }
   pmc ${n}_fetch $probe "$pargs" FETCH_SIZE
