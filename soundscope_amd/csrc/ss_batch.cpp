@@ -655,14 +655,21 @@ int ss_batch_run(ss_batch *b)
         p.split_batch = b->ragged ? 0u : (b->td_split ? 1u : (b->td_split_segments ? 2u : 0u));      // (ragged lengths: one wave per stream / segment)
         if (b->wave_fused && !b->ragged) { p.wave_out = b->wave.p; p.wave_stride = (uint64_t)2 * b->wave_window; p.wave_window = b->wave_window; p.halo_frames = b->wave_halo; }
         HIPCHK(ssk::launch_time_domain(p, b->stream));
+        if (mode == 2) {
+            // the tail starts HERE: the hand-over's second launch (filter and energies of every segment's first 0.2 s: one wave per
+            // segment, a chain of ten short tiles each — latency, not throughput, and no matrix-core work) runs beside the spectrum
+            // kernel like the gating behind it
+            HIPCHK(hipEventRecord(b->ev_fork, b->stream));
+            HIPCHK(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
+            rc = launch_spectrum(); if (rc) return rc;
+        }
         if (exact_segments) HIPCHK(ssk::launch_time_domain_fixup(p, b->stream));
-    }
-    HIPCHK(rec(2 * SS_KERNEL_TIME_DOMAIN + 1));
-    if (mode == 2) {
+    } else if (mode == 2) {                                  // (no time-domain work at all: the spectrum kernel is the pass)
         HIPCHK(hipEventRecord(b->ev_fork, b->stream));
         HIPCHK(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
         rc = launch_spectrum(); if (rc) return rc;
     }
+    HIPCHK(rec(2 * SS_KERNEL_TIME_DOMAIN + 1));
 
     HIPCHK(rec(2 * SS_KERNEL_FINALIZE));
     if (td) {
