@@ -204,6 +204,13 @@ int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
         if (rc) return rc;
     }
     if (cfg->true_peak_factor != 0 && cfg->true_peak_factor != 2 && cfg->true_peak_factor != 4) return SS_ERR_INVALID_ARG;
+    {   // sizes that cannot be a buffer: refused before any product of them is formed (a wrapped product would allocate a small
+        // buffer and index far beyond it).  2^40 samples = 4 TB of f32, fourteen times the HBM of the card.
+        unsigned long long samples = 0;
+        if (F > (1ull << 40) || __builtin_mul_overflow((unsigned long long)cfg->n_streams, (unsigned long long)F, &samples) ||
+            __builtin_mul_overflow(samples, (unsigned long long)C, &samples) || samples > (1ull << 40))
+            return SS_ERR_NOMEM;
+    }
     HIPCHK(stream_acquire(&b->stream));
     ss_batch_layout &L = b->lay;
     L.input_bytes = (uint64_t)cfg->n_streams * F * C * sizeof(float);

@@ -943,6 +943,14 @@ def test_batch_create_rejects_nonsense():
         args.update(kw)
         with pytest.raises(ssa.AnalyzerError):
             ssa.Batch(**args)
+    # sizes whose product wraps 64 bits, or is simply no buffer: refused as out of memory, nothing allocated, nothing indexed
+    for kw in (dict(n_streams=2 ** 32 - 1, frames_per_stream=2 ** 40), dict(n_streams=2 ** 31, frames_per_stream=2 ** 33, channels=64),
+               dict(frames_per_stream=2 ** 41), dict(n_streams=2 ** 20, frames_per_stream=2 ** 21, channels=8)):
+        args = dict(sample_rate=48000, channels=2, n_streams=1, frames_per_stream=48000, fft_n=4096, hop_frames=1024)
+        args.update(kw)
+        with pytest.raises(ssa.AnalyzerError) as e:
+            ssa.Batch(**args)
+        assert e.value.code == L.SS_ERR_NOMEM
 
 
 @pytest.mark.parametrize("rate,fft_n,td_mode", [(48000, 4096, L.SS_TD_AUTO), (44100, 16384, L.SS_TD_AUTO), (48000, 4096, L.SS_TD_RUN_IN),
