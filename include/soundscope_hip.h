@@ -395,6 +395,11 @@ double ss_corpus_loudness_range(const uint64_t *st_hist1000);
  *  setenv; plain ss_comm_init keeps whatever device is current (for callers that export the variable in the launcher, as
  *  bench.py does).  When the variable is wrong the failure surfaces as "hipIpcGetMemHandle: invalid argument" inside
  *  ncclCommInitRank; the error text of a failed init names the variable.
+ *  Failure is all-or-nothing and prompt: what goes wrong on one rank before the ranks meet (no such device, no librccl, no
+ *  memory) and the outcome of ncclCommInitRank are exchanged over the join sockets, so every rank returns SS_ERR_DEVICE within
+ *  seconds and ss_last_device_error names the reason (the failing rank's own, "another rank ..." elsewhere).  Only a rank that
+ *  never arrives (its process died) is waited for: SS_COMM_TIMEOUT_S seconds (default 180) at the rendezvous and again
+ *  inside ncclCommInitRank.
  * ------------------------------------------------------------------------- */
 typedef struct ss_comm ss_comm;
 enum { SS_COMM_RCCL = 0, SS_COMM_HOST_TCP = 1 };
