@@ -22,6 +22,7 @@ def programme(seed):
     mm = po.Meter(ch, rate)
     total = 0
     worst = {"st": 0.0, "mom": 0.0, "state": 0.0}
+    peak_scale = 0.0
     n_calls = int(rng.integers(8, 40))
     for k in range(n_calls):
         kind = rng.integers(0, 6)
@@ -35,7 +36,8 @@ def programme(seed):
         for c in range(ch):
             f0 = rng.uniform(40, 5000)
             x[:, c] = level * (np.sin(2 * np.pi * f0 * t + c) + 0.3 * rng.standard_normal(frames))
-        if rng.integers(0, 7) == 0: x[:] = 0.0
+        silent = rng.integers(0, 7) == 0
+        if silent: x[:] = 0.0
         xs = np.ascontiguousarray(x.reshape(-1))
         an.add_samples(xs); mm.add_frames(xs)
         total += frames
@@ -47,9 +49,13 @@ def programme(seed):
         if scale > 1e-280:
             d = float(np.max(np.abs(gs - os_)) / scale)
             worst["state"] = max(worst["state"], d)
+            if "-v" in sys.argv: print(f"   call {k}: {frames} frames, level {20 * np.log10(level):.0f} dB{', SILENT' if silent else ''}: |state| {scale:.3e}, off by {d:.2e}", flush=True)
             # (192 kHz: the chunk scan's difference coordinates are good for 1e-4 .. 1e-3 of a state that has decayed through a
             # silence — the same on one wave and on eight; the readings above do not see it)
-            if d > (1e-5 if rate <= 96000 else 2e-3): return f"seed {seed} ({rate} Hz, {ch} ch) call {k} ({frames} frames): state off by {d:.2e} of its largest component"
+            peak_scale = max(peak_scale, scale)
+            # ... and a state that has decayed through one silence after another (seed 70123: from 2e4 to 2e-37) is held to the
+            # programme's own scale: an error 1e-24 of the largest state the filter has carried is below anything a sample can feel
+            if d > (1e-5 if rate <= 96000 else 2e-3) and d * scale > 1e-24 * peak_scale: return f"seed {seed} ({rate} Hz, {ch} ch) call {k} ({frames} frames): state off by {d:.2e} of its largest component"
     gi, oi = an.get_integrated_lufs(), mm.integrated()
     if not close_lu(gi, oi, 1e-6): return f"seed {seed}: integrated {gi} vs {oi}"
     for c in range(ch):
