@@ -148,7 +148,9 @@ def programme(seed):
                     start = (wdx + fft_n // hop + 1) * hop - fft_n      # positions p = k hop with N < p <= F, window [p - N, p) (tui.rs:1489)
                     for c in sorted(set([0, len(sig) - 1])):
                         ref = po.get_fft(rate, sig[c][start:start + fft_n])[:, 1]
-                        if not db_close(fft[wdx, c], ref, 0.01): bad(f"pass {pass_no} stream {i} window {wdx} ch {c}: spectrum row differs {db_report(fft[wdx, c], ref)} row peak {float(ref.max()):.1f} dB")
+                        # (0.015 dB here, 0.01 in the committed tests: at the metric's edge, 70 dB under the row's peak, the difference of two
+                        # f32 transforms' rounding noise is 0.004 dB typical — over thousands of random rows the tail reaches 0.011, seed 102143)
+                        if not db_close(fft[wdx, c], ref, 0.015): bad(f"pass {pass_no} stream {i} window {wdx} ch {c}: spectrum row differs {db_report(fft[wdx, c], ref)} row peak {float(ref.max()):.1f} dB")
     g = b.geometry
     b.close()
     return ok, what + f" [segments {g.td_segments} x {g.td_segment_subblocks}, split {g.td_split}, fixup {g.td_fixup_subblocks}]" + ("" if ok else " -> " + "; ".join(notes[:6]))

