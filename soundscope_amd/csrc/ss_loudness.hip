@@ -324,6 +324,9 @@ __global__ __launch_bounds__(64) void k_finalize_stream(FinalizeParams p)
     }
 }
 
+#ifndef SS_FINALIZE_SMALL_MAX
+#define SS_FINALIZE_SMALL_MAX 64u      // streams up to which a launch counts as latency-bound (the form with the tables in LDS)
+#endif
 hipError_t launch_finalize(const FinalizeParams &p, hipStream_t s)
 {
     if (p.n_streams == 0) return hipSuccess;
@@ -335,7 +338,7 @@ hipError_t launch_finalize(const FinalizeParams &p, hipStream_t s)
         const uint64_t nsub = p.sub_end - p.sub_begin;
         const uint32_t threads = nsub > 2048 ? 1024u : 256u;
         // a handful of short streams: the launch is a chain of memory round trips, not work -> the form that shortens the chain
-        if (p.n_streams <= 64u && threads == 256u) hipLaunchKernelGGL(k_finalize<true>, dim3(p.n_streams), dim3(threads), 0, s, p);
+        if (p.n_streams <= SS_FINALIZE_SMALL_MAX && threads == 256u) hipLaunchKernelGGL(k_finalize<true>, dim3(p.n_streams), dim3(threads), 0, s, p);
         else hipLaunchKernelGGL(k_finalize<false>, dim3(p.n_streams), dim3(threads), 0, s, p);
     }
     return hipGetLastError();
