@@ -600,7 +600,8 @@ def main():
                                 "time-domain kernel, then the spectrum kernel on a second HIP stream beside the chain's tail (gating / histograms)"][ov_mode],
                        "geometry": {"fft_windows_per_block": geo.fft_windows_per_block, "fft_blocks": geo.fft_blocks,
                                     "td_segments": geo.td_segments, "td_segment_subblocks": geo.td_segment_subblocks,
-                                    "td_handover": ("whole-stream workgroups" if geo.td_split else
+                                    "td_handover": ("whole-stream workgroups" if geo.td_split == 1 else
+                                                    f"segments on eight waves, {geo.td_warm_subblocks} sub-block filter run-in inside the launch" if geo.td_split == 2 else
                                                     f"exact: fix-up launch over the first {geo.td_fixup_subblocks} sub-blocks of segments > 0" if geo.td_fixup_subblocks else
                                                     f"{geo.td_warm_subblocks} sub-block run-in" if geo.td_warm_subblocks else "one segment"),
                                     "waveform_fused": geo.waveform_fused},

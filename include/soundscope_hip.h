@@ -303,13 +303,15 @@ typedef struct ss_batch_geometry {
     uint32_t fft_blocks;             /* spectrum workgroups per pass                                  */
     uint32_t td_segments;            /* time segments per stream in the time-domain kernel            */
     uint32_t td_segment_subblocks;   /* 100 ms sub-blocks per segment (0: one segment)                */
-    uint32_t td_warm_subblocks;      /* filter run-in of segments > 0 (SS_TD_RUN_IN only)             */
+    uint32_t td_warm_subblocks;      /* filter run-in of segments > 0 (SS_TD_RUN_IN: 1; td_split == 2: 2) */
     uint32_t td_true_peak_factor;    /* 0, 2, 4                                                       */
     uint32_t waveform_fused;         /* 1: decimation runs inside the time-domain kernel              */
     uint32_t overlap;                /* ss_batch_set_overlap mode: 0, 1 or 2                          */
     uint32_t td_split;               /* 1: a stream is one segment walked by the four waves of a workgroup, the filter state handed
                                       *    from tile to tile (the whole recurrence: no run-in); td_segments is 1 then.  2: a handful of
-                                      *    streams: every SEGMENT's tiles dealt to the eight waves of a workgroup (latency)          */
+                                      *    streams: every SEGMENT's tiles dealt to the eight waves of a workgroup (latency); a segment
+                                      *    then runs the filter over the td_warm_subblocks (2) in front of it inside the one launch —
+                                      *    the state the second launch would start from — and td_fixup_subblocks is 0              */
     uint32_t td_fixup_subblocks;     /* sub-blocks at the head of every segment > 0 re-run from the exact state by the second launch */
 } ss_batch_geometry;                 /* 40 bytes (32 up to ABI version 1) */
 int ss_batch_geometry_get(const ss_batch *b, ss_batch_geometry *out);
@@ -323,6 +325,9 @@ int ss_batch_geometry_get(const ss_batch *b, ss_batch_geometry *out);
  *                          Segment 0 and the re-run head of segment 1 equal the one-segment path bit for bit; elsewhere the
  *                          difference is the rounding noise of the recurrence (3e-10 at worst on the bench corpus, the same as
  *                          for the exact-by-construction SS_TD_WHOLE_STREAMS), not a dropped term (tests pin both).
+ *                          A handful of streams (one file; td_split == 2 in the geometry): the same segments on eight waves each,
+ *                          and every segment runs the filter over the 0.2 s in front of it, from zero, inside the ONE launch —
+ *                          the state the second launch would have started from, without a second launch.
  *   SS_TD_RUN_IN           the form of rounds 1-4, kept for comparison: a segment > 0 starts its filter 0.1 s early from a zero
  *                          state and drops that run-in (3e-10 on sub-block energies of DC-offset material: a truncation).
  *   SS_TD_WHOLE_STREAMS    stereo / eight channels, equal lengths: a stream is ONE segment walked by the four waves of a

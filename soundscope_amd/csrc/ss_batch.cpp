@@ -115,6 +115,9 @@ extern "C" {
 //    length that maximises   useful fraction  seg / (seg + warm)  x  fill of the last round  waves / (ceil(waves / W0) W0)
 //    (ranks the measured config-5 sweep seg = 2..13 in the right order; measured within noise for config 3).
 // mode (ss_batch_set_time_domain_mode): 0 the better score of the two, 1 segments, 2 whole-stream workgroups where the shape allows.
+#ifndef SS_TD_SPLIT_LONG_RUN_IN
+#define SS_TD_SPLIT_LONG_RUN_IN 1      // 0: split segments hand over through the second launch like every other segmented batch (A/B builds)
+#endif
 static void choose_td_geometry(ss_batch *b)
 {
     if (!b->td) return;
@@ -649,8 +652,13 @@ int ss_batch_run(ss_batch *b)
         p.s100 = b->td->host.s100; p.nseg = b->td_nseg; p.seg_sub = b->td_seg_sub;
         // segments > 0: exact hand-over (no run-in; their first kTdFixSub sub-blocks re-run from the true state by the second launch
         // below), or — mode 1 — the 0.1 s run-in from a zero state of rounds 1-4
-        const bool exact_segments = b->td_nseg > 1 && b->td_mode != 1;
-        p.warm_sub = exact_segments ? 0u : kTdWarmSub;
+        // ... or, a handful of streams cut into the shortest segments (td_split_segments: the pass is a latency chain, and a second
+        // launch is a fifth of it): every segment runs the FILTER over the kTdFixSub sub-blocks in front of it, from zero, inside the
+        // one launch — the state it starts its own frames with is what the second launch would have started from (a zero-state run
+        // over 0.2 s: 1.6e-21 of the true state's response left), the run-in tiles cost the filter passes only, no second launch
+        const bool long_run_in = b->td_nseg > 1 && b->td_mode == 0 && b->td_split_segments && SS_TD_SPLIT_LONG_RUN_IN;
+        const bool exact_segments = b->td_nseg > 1 && b->td_mode != 1 && !long_run_in;
+        p.warm_sub = long_run_in ? kTdFixSub : (exact_segments ? 0u : kTdWarmSub);
         if (exact_segments) {
             const size_t need = (size_t)c.n_streams * b->td_nseg * C * 4;
             if (b->seg_state.n < need) HIPCHK(b->seg_state.alloc(need));
@@ -831,7 +839,9 @@ int ss_batch_geometry_get(const ss_batch *b, ss_batch_geometry *out)
         out->td_segment_subblocks = b->td_seg_sub;
         out->td_warm_subblocks = (b->td_nseg > 1 && b->td_mode == 1) ? kTdWarmSub : 0;
         out->td_split = b->td_split ? 1u : (b->td_split_segments ? 2u : 0u);
-        out->td_fixup_subblocks = (b->td_nseg > 1 && b->td_mode != 1) ? (b->td_seg_sub < kTdFixSub ? b->td_seg_sub : kTdFixSub) : 0;
+        const bool long_run_in = b->td_nseg > 1 && b->td_mode == 0 && b->td_split_segments && SS_TD_SPLIT_LONG_RUN_IN;
+        out->td_fixup_subblocks = (b->td_nseg > 1 && b->td_mode != 1 && !long_run_in) ? (b->td_seg_sub < kTdFixSub ? b->td_seg_sub : kTdFixSub) : 0;
+        if (long_run_in) out->td_warm_subblocks = kTdFixSub;
         out->td_true_peak_factor = (uint32_t)b->tp_factor;
     }
     out->waveform_fused = (b->wave_fused && !b->ragged) ? 1u : 0u;

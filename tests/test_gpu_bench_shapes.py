@@ -316,6 +316,40 @@ def test_segment_handover_is_exact(oracle):
     b.close()
 
 
+def test_single_file_segments_run_in_over_the_segment_in_front(oracle):
+    """One file (BASELINE config 2): the stream is cut into 0.2 s segments whose tiles are dealt to the eight waves of a workgroup,
+    and — the pass being a latency chain — every segment runs the FILTER over the 0.2 s in front of it, from zero, inside the one
+    launch instead of leaving that to a second one (84 -> 74 us per pass).  The state a segment then starts its own frames with is
+    what the second launch would have started from: against the exact-by-construction whole-stream walk the sub-block energies differ
+    by the recurrence's rounding noise, on the bench material and on DC-offset material (the hand-over's worst case); results equal
+    the oracle's."""
+    rate, frames = 48000, 480000
+    FL = L.SS_BATCH_LUFS | L.SS_BATCH_TRUE_PEAK | L.SS_BATCH_WAVEFORM
+    rng = np.random.default_rng(5)
+    dc = np.empty(2 * frames, np.float32)
+    dc[0::2] = (0.5 + 0.01 * rng.standard_normal(frames)).astype(np.float32)
+    dc[1::2] = (-0.3 + 0.2 * np.sin(2 * np.pi * 5 * np.arange(frames) / rate)).astype(np.float32)
+    for material in ("bench", "dc"):
+        b = ssa.Batch(rate, 2, 1, frames, 4096, 1024, flags=FL)
+        if material == "bench": b.synthesize(0x5EED0000, 0)
+        else: b.upload(0, dc)
+        b.run(); b.sync()
+        g = b.geometry
+        assert (g.td_split, g.td_segments, g.td_segment_subblocks, g.td_fixup_subblocks, g.td_warm_subblocks) == (2, 50, 2, 0, 2)
+        got = b.subblocks(0).copy()
+        r = b.results()[0]
+        x = b.download_input(0)
+        b.set_time_domain_mode(WHOLE); b.run(); b.sync()
+        assert b.geometry.td_segments == 1
+        ref = b.subblocks(0)
+        rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300)
+        assert rel.max() <= 2e-9, (material, float(rel.max()))
+        assert np.array_equal(got[:2], ref[:2])               # segment 0 starts from the true (zero) state
+        m = oracle.Meter(2, rate); m.add_frames(x)
+        assert abs(r.integrated_lufs - m.integrated()) <= 1e-9 and abs(r.loudness_range - m.loudness_range()) <= 1e-9
+        b.close()
+
+
 def test_segmented_run_in_on_dc_offset_material(oracle):
     """DC-offset material is the worst case of the segment hand-over (the high-pass section's near-double pole: the state is
     4e4 times the offset and decays like n r^n).  The segmented batch path (default: exact hand-over by the fix-up launch) and
