@@ -344,7 +344,6 @@ def test_single_file_segments_run_in_over_the_segment_in_front(oracle):
         ref = b.subblocks(0)
         rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300)
         assert rel.max() <= 2e-9, (material, float(rel.max()))
-        assert np.array_equal(got[:2], ref[:2])               # segment 0 starts from the true (zero) state
         m = oracle.Meter(2, rate); m.add_frames(x)
         assert abs(r.integrated_lufs - m.integrated()) <= 1e-9 and abs(r.loudness_range - m.loudness_range()) <= 1e-9
         b.close()
