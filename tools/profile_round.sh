@@ -9,11 +9,13 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
+if [ "${SKIP_BENCH:-0}" != 1 ]; then        # (SKIP_BENCH=1: the PMC passes only)
 python $root/bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err
 rocprofv3 --kernel-trace --stats -d $out/kt -o kt -- python $root/bench.py --steps 20 --warmup 5 > $out/kt_bench.json 2> $out/kt.err
 db=$(find $out/kt -name '*.db' | head -1)
 [ -n "$db" ] && python $root/tools/rocpd_summary.py "$db" $out/kernel_stats.txt
 rm -rf $out/kt
+fi
 pmc() {   # pmc <name> <probe script> <probe args> <counters...>
   name=$1; probe=$2; pargs=$3; shift 3
   timeout 600 rocprofv3 --pmc "$@" -d $out/pmc_$name -o p -- python $root/$probe $pargs > $out/pmc_$name.log 2>&1
@@ -34,4 +36,4 @@ for cfg in "c3 tools/perf_probe.py 1024_2" "c5 tools/probe_cfg5.py 64"; do
   pmc ${n}_mfma $probe "$pargs" SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F16 SQ_INSTS_VALU_FMA_F64 GRBM_GUI_ACTIVE
   pmc ${n}_wait $probe "$pargs" SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD
 done
-cat $out/bench.json | head -c 600; echo; cat $out/kernel_stats.txt | head -20
+[ -f $out/bench.json ] && { cat $out/bench.json | head -c 600; echo; cat $out/kernel_stats.txt | head -20; }; cat $out/pmc_summary.txt | cut -c1-200 | head -60
