@@ -134,6 +134,12 @@ uint32_t ss_sample_rate(const ss_analyzer *h);
  * sample_rate only; does not touch the handle's meter. */
 int ss_calculate_integrated_lufs(ss_analyzer *h, uint32_t channels,
                                  const float *samples, size_t n, double *out);
+/* Process-wide caches.  calculate_integrated_lufs (and ss_session_open_file, which calls it) keeps ONE loudness-only batch per
+ * process for inputs of up to 64 MB — sized by its first caller with a quarter of headroom, up to ~80 MB of HBM plus the batch's
+ * side buffers — and runs under a lock: concurrent calls from several threads are serialised.  The way an input is cut into
+ * time segments follows the input's own length, not the kept batch's size, so a reading does not depend on what the process
+ * analysed before.  ss_release_caches frees the kept batch (the next call builds a new one); always SS_OK. */
+int ss_release_caches(void);
 /* get_mid_and_side_samples(samples)                   audio_player.rs:400-419
  * mid/side need n/2 floats each; *out_frames = n/2. */
 int ss_mid_side(const float *interleaved, size_t n, float *mid, float *side,
@@ -315,6 +321,10 @@ typedef struct ss_batch_geometry {
     uint32_t td_fixup_subblocks;     /* sub-blocks at the head of every segment > 0 re-run from the exact state by the second launch */
 } ss_batch_geometry;                 /* 40 bytes (32 up to ABI version 1) */
 int ss_batch_geometry_get(const ss_batch *b, ss_batch_geometry *out);
+/* the same for a caller built against an older (shorter) or newer (longer) struct: writes min(out_bytes, sizeof(ss_batch_geometry))
+ * bytes, never more than the caller has — a client compiled against the 32-byte struct of ABI version 1 passes 32 and gets the
+ * fields it knows (ss_batch_geometry_get itself writes the whole 40-byte struct and is for callers that check ss_abi_version()) */
+int ss_batch_geometry_get_sized(const ss_batch *b, void *out, size_t out_bytes);
 /* how the time-domain kernel walks a stream.  The K-weighting recurrence has a long memory (poles at |z| = 0.995): a stream cut
  * into time segments for parallelism must hand the filter state from one segment to the next.
  *   SS_TD_AUTO (default)   time segments, one wave each, EXACT hand-over: every segment starts at its boundary from a zero state,
@@ -396,7 +406,10 @@ double ss_corpus_loudness_range(const uint64_t *st_hist1000);
  *  the HSA runtime reads it at the process' first HIP call.  Loading the library changes nothing in the environment; the
  *  ss_comm_init* calls (RCCL, world > 1) set the variable if it is unset, which is in time only when they make the process'
  *  FIRST HIP call.  A rank therefore does NOT call ss_set_device first: ss_comm_init_on_device(…, device, …) and
- *  ss_comm_init_from_env (device = SS_COMM_DEVICE, else LOCAL_RANK) make the rank's GPU current themselves, behind the
+ *  ss_comm_init_from_env (device = SS_COMM_DEVICE — explicit: it must parse as a number and name a visible device —, else
+ *  LOCAL_RANK; where the launcher masks ONE GPU per rank, ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES per task as under
+ *  SLURM, LOCAL_RANK still counts 0 .. n-1 against a single visible device: a LOCAL_RANK beyond the visible devices is
+ *  taken modulo their count, i.e. device 0 there) make the rank's GPU current themselves, behind the
  *  setenv; plain ss_comm_init keeps whatever device is current (for callers that export the variable in the launcher, as
  *  bench.py does).  When the variable is wrong the failure surfaces as "hipIpcGetMemHandle: invalid argument" inside
  *  ncclCommInitRank; the error text of a failed init names the variable.

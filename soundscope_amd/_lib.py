@@ -41,6 +41,7 @@ SYMBOLS = [
     "ss_comm_transport_name", "ss_comm_library_version", "ss_comm_barrier", "ss_comm_allreduce_u64_sum", "ss_comm_allreduce_f64_max",
     "ss_batch_allreduce_histograms", "ss_batch_traffic_floor",
     "ss_batch_corpus_gate_enqueue", "ss_batch_corpus_gate_read", "ss_batch_checksums", "ss_inspect_filter_state", "ss_batch_set_true_peak_arith", "ss_batch_get_true_peak_arith", "ss_batch_set_time_domain_mode", "ss_batch_set_columns_gain",
+    "ss_release_caches", "ss_batch_geometry_get_sized",
     "ss_inspect_kweight", "ss_inspect_true_peak", "ss_inspect_hann", "ss_inspect_bins", "ss_inspect_histogram",
 ]
 
@@ -218,6 +219,8 @@ def _bind(lib):
         "ss_batch_get_true_peak_arith": (C.c_int, [vp]),
         "ss_batch_set_time_domain_mode": (C.c_int, [vp, C.c_int]),
         "ss_batch_set_columns_gain": (C.c_int, [vp, C.c_int, C.c_float]),
+        "ss_release_caches": (C.c_int, []),
+        "ss_batch_geometry_get_sized": (C.c_int, [vp, vp, C.c_size_t]),
         "ss_inspect_kweight": (C.c_int, [C.c_uint32, f64p, f64p]),
         "ss_inspect_true_peak": (C.c_int, [C.c_int, f32p, C.c_uint32, C.POINTER(C.c_uint32)]),
         "ss_inspect_hann": (C.c_int, [C.c_uint32, f32p]),

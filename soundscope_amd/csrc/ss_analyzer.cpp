@@ -485,6 +485,7 @@ int ssh::add_samples_impl(ss_analyzer *h, const float *samples, size_t n, bool o
             f.hist = h->hist.p; f.corpus_hist = nullptr; f.n_streams = 1; f.channels = C;
             f.sub_begin = sb0; f.sub_end = sb1;
             f.out_integrated = nullptr; f.out_lra = nullptr; f.out_counts = h->counts.p;
+            f.state = h->state.p;
             // a caller that has something shorter to put in front (a tick's short-term reading) launches the gating of a
             // single-piece call itself, on the same stream
             if (deferred && on_device && take == frames) *deferred = f;
@@ -664,6 +665,12 @@ int ss_inspect_filter_state(ss_analyzer *h, uint32_t channel, double v4[4])
     if (!h || !v4) return SS_ERR_INVALID_ARG;
     if (!h->meter_ok) return SS_ERR_INVALID_MODE;
     if (channel >= h->channels) return SS_ERR_INVALID_CHANNEL;
+    {   // a channel the crate maps to Channel::Unused is not filtered there at all: its state stays what reset left.  (The device
+        // runs the recurrence on every channel — the lanes are there anyway — and no reading ever looks at such a channel.)
+        std::vector<double> w(h->channels);
+        sst::channel_weights(h->channels, w.data());
+        if (w[channel] == 0.0) { v4[0] = v4[1] = v4[2] = v4[3] = 0.0; return SS_OK; }
+    }
     HIPCHK(hipMemcpyAsync(v4, &h->state.p->v[channel][0], 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return SS_OK;

@@ -22,6 +22,7 @@ struct ss_batch {
     uint32_t wave_window = 0;
     uint32_t windows_per_block = 16;
     uint32_t td_nseg = 1, td_seg_sub = 0;
+    uint32_t td_nsub_hint = 0;      // ragged batches: sub-blocks of the LONGEST stream (the geometry follows the lengths, not the slot size)
     bool td_split = false;          // whole-stream workgroups (choose_td_geometry)
     bool td_split_segments = false; // the same per time segment, eight waves each (a handful of streams)
     int td_mode = 0;                // ss_batch_set_time_domain_mode
@@ -124,7 +125,7 @@ static void choose_td_geometry(ss_batch *b)
     const ss_batch_config *cfg = &b->cfg;
     const ss_batch_layout &L = b->lay;
     const uint32_t C = cfg->channels;
-    const uint32_t nsub = L.n_subblocks;
+    const uint32_t nsub = b->ragged ? b->td_nsub_hint : L.n_subblocks;
     const double W0 = 256.0 * ssk::td_resident_waves_per_cu(C, b->td->host.s100, b->wave_fused ? b->wave_halo : 0);
     // what a segment boundary costs, in sub-blocks of full work: the run-in (mode 1), or the fix-up's re-run of kTdFixSub sub-blocks
     // at about 0.8 of a full tile each (filter and energies are most of a tile) — config 5's sweep seg = 2 ... 10 with the fix-up:
@@ -449,6 +450,12 @@ int ss_batch_set_lengths(ss_batch *b, const uint64_t *frames, uint32_t count)
     HIPCHK(b->wave_window_d.upload(b->wave_window_h));
     HIPCHK(b->wave_samples_d.upload(b->wave_samples_h));
     b->ragged = true;
+    // the time-domain geometry follows the lengths actually set (the longest stream), not the slot size the batch was created with:
+    // a batch that is kept and re-used — the one-shot loudness call keeps one — then cuts the same input the same way whatever
+    // was analysed before it (the low bits of a reading do not depend on the process' history)
+    b->td_nsub_hint = 0;
+    for (uint32_t i = 0; i < count; i++) if (b->sub_h[i] > b->td_nsub_hint) b->td_nsub_hint = b->sub_h[i];
+    choose_td_geometry(b);
     return SS_OK;
 }
 
@@ -699,6 +706,7 @@ int ss_batch_run(ss_batch *b)
         f.sub_begin = 0; f.sub_end = L.n_subblocks;
         f.sub_end_of = b->ragged ? b->sub_d.p : nullptr;
         f.out_integrated = b->integrated.p; f.out_lra = b->lra.p; f.out_counts = b->counts.p;
+        f.state = b->state.p;
         HIPCHK(ssk::launch_finalize(f, b->stream));
     }
     HIPCHK(rec(2 * SS_KERNEL_FINALIZE + 1));
@@ -838,7 +846,8 @@ int ss_batch_geometry_get(const ss_batch *b, ss_batch_geometry *out)
         out->td_segments = b->td_nseg;
         out->td_segment_subblocks = b->td_seg_sub;
         out->td_warm_subblocks = (b->td_nseg > 1 && b->td_mode == 1) ? kTdWarmSub : 0;
-        out->td_split = b->td_split ? 1u : (b->td_split_segments ? 2u : 0u);
+        // (ragged lengths: one wave per stream / segment whatever the shape would have allowed — ss_batch_run)
+        out->td_split = b->ragged ? 0u : (b->td_split ? 1u : (b->td_split_segments ? 2u : 0u));
         const bool long_run_in = b->td_nseg > 1 && b->td_mode == 0 && b->td_split_segments && SS_TD_SPLIT_LONG_RUN_IN;
         out->td_fixup_subblocks = (b->td_nseg > 1 && b->td_mode != 1 && !long_run_in) ? (b->td_seg_sub < kTdFixSub ? b->td_seg_sub : kTdFixSub) : 0;
         if (long_run_in) out->td_warm_subblocks = kTdFixSub;
@@ -846,6 +855,16 @@ int ss_batch_geometry_get(const ss_batch *b, ss_batch_geometry *out)
     }
     out->waveform_fused = (b->wave_fused && !b->ragged) ? 1u : 0u;
     out->overlap = (uint32_t)b->overlap;
+    return SS_OK;
+}
+
+int ss_batch_geometry_get_sized(const ss_batch *b, void *out, size_t out_bytes)
+{
+    if (!b || !out) return SS_ERR_INVALID_ARG;
+    ss_batch_geometry g;
+    const int rc = ss_batch_geometry_get(b, &g);
+    if (rc) return rc;
+    std::memcpy(out, &g, out_bytes < sizeof g ? out_bytes : sizeof g);
     return SS_OK;
 }
 
@@ -1156,6 +1175,18 @@ const char *ss_kernel_name(int kernel)
 // Analyzer::calculate_integrated_lufs (analyzer.rs:170-182): fresh meter at the
 // handle's sample rate, whole buffer fed in 2*sr-sample chunks, loudness_global.
 }  // extern "C"
+namespace oneshot {
+// the one loudness-only batch the process keeps for calculate_integrated_lufs / receive_audio_file (see integrated_oneshot)
+struct Slot { ss_batch *b = nullptr; uint32_t rate = 0, channels = 0; uint64_t cap = 0; int device = -1; };
+static std::mutex mu;
+static Slot slot;
+}  // namespace oneshot
+extern "C" int ss_release_caches(void)
+{
+    std::lock_guard<std::mutex> lk(oneshot::mu);
+    if (oneshot::slot.b) { ss_batch_destroy(oneshot::slot.b); oneshot::slot = oneshot::Slot{}; }
+    return SS_OK;
+}
 int ssh::integrated_oneshot(uint32_t rate, uint32_t channels, const float *samples, size_t n,
                             bool on_device, double *out)
 {
@@ -1176,10 +1207,8 @@ int ssh::integrated_oneshot(uint32_t rate, uint32_t channels, const float *sampl
     // batch of their own as before.
     const uint64_t frames = n / channels;
     constexpr size_t kCacheMaxFloats = (size_t)16 << 20;
-    struct Slot { ss_batch *b = nullptr; uint32_t rate = 0, channels = 0; uint64_t cap = 0; int device = -1; };
-    static std::mutex mu;
-    static Slot slot;
-    std::unique_lock<std::mutex> lk(mu, std::defer_lock);
+    using oneshot::Slot; using oneshot::slot;
+    std::unique_lock<std::mutex> lk(oneshot::mu, std::defer_lock);
     ss_batch *b = nullptr;
     bool cached = false;
     if (n <= kCacheMaxFloats) {

@@ -352,7 +352,10 @@ void ss_comm_destroy(ss_comm *c)
     delete c;
 }
 
-static int comm_init_impl(int transport, int rank, int world, int device, const char *rendezvous_file, ss_comm **out)
+// device_wraps: `device` came from LOCAL_RANK — a value beyond the visible devices maps onto them (see ss_comm_init_from_env);
+// env_error: the environment named no usable device at all (this rank's verdict, exchanged like any other local failure)
+static int comm_init_impl(int transport, int rank, int world, int device, const char *rendezvous_file, ss_comm **out,
+                          bool device_wraps = false, const char *env_error = nullptr)
 {
     if (!out) return SS_ERR_INVALID_ARG;
     *out = nullptr;
@@ -373,7 +376,10 @@ static int comm_init_impl(int transport, int rank, int world, int device, const 
     auto local_setup = [&]() -> bool {
         if (transport != SS_COMM_RCCL) return true;
         if (world > 1) default_hsa_ipc_mode();            // before this call's (possibly the process' first) HIP call
-        if (ss_device_count() <= 0) { local_why = "no HIP device"; return false; }
+        if (env_error) { local_why = env_error; return false; }
+        const int n_dev = ss_device_count();
+        if (n_dev <= 0) { local_why = "no HIP device"; return false; }
+        if (device_wraps && device >= n_dev) device = device % n_dev;      // one masked GPU per rank: every rank's device 0
         // device >= 0 (ss_comm_init_on_device, ss_comm_init_from_env): this call makes the rank's GPU current ITSELF, behind the
         // setenv above — the order a rank off device 0 cannot get by calling ss_set_device first (that call starts the HSA runtime)
         hipError_t e = device >= 0 ? hipSetDevice(device) : hipSuccess;
@@ -508,11 +514,30 @@ int ss_comm_init_from_env(int transport, ss_comm **out)
         const char *mp = std::getenv("MASTER_PORT");
         file = "/tmp/ss_comm_" + std::to_string(ppid) + "_" + std::to_string(start) + "_" + (mp ? mp : "0") + ".rdzv";
     }
-    // the rank's GPU: SS_COMM_DEVICE, else LOCAL_RANK (one process per GPU), else whatever device is current
+    // the rank's GPU: SS_COMM_DEVICE (explicit: must name a visible device, anything else is an error), else LOCAL_RANK (one process
+    // per GPU), else whatever device is current.  Launchers that MASK one GPU per task (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES
+    // per rank, usual under SLURM) leave every rank with a single visible device 0 while LOCAL_RANK still counts 0 .. n-1: a
+    // LOCAL_RANK beyond the visible devices maps onto them (device 0 when there is one, LOCAL_RANK modulo the count otherwise).
     int device = -1;
-    if (const char *d = std::getenv("SS_COMM_DEVICE")) device = std::atoi(d);
-    else if (const char *l = std::getenv("LOCAL_RANK")) device = std::atoi(l);
-    return comm_init_impl(transport, rank, world, transport == SS_COMM_RCCL ? device : -1, file.c_str(), out);
+    bool wrap = false;
+    std::string bad;                       // a value that names no device: becomes this rank's verdict, so that its peers hear of it too
+    auto parse_int = [](const char *t, long *v) {
+        char *end = nullptr;
+        errno = 0;
+        *v = std::strtol(t, &end, 10);
+        return end != t && *end == '\0' && errno == 0 && *v >= 0 && *v <= 1 << 20;
+    };
+    if (transport == SS_COMM_RCCL) {
+        long v = 0;
+        if (const char *d = std::getenv("SS_COMM_DEVICE")) {
+            if (parse_int(d, &v)) device = (int)v;
+            else bad = std::string("SS_COMM_DEVICE is not a device ordinal: '") + d + "'";
+        } else if (const char *l = std::getenv("LOCAL_RANK")) {
+            if (parse_int(l, &v)) { device = (int)v; wrap = true; }
+            else bad = std::string("LOCAL_RANK is not a number: '") + l + "'";
+        }
+    }
+    return comm_init_impl(transport, rank, world, transport == SS_COMM_RCCL ? device : -1, file.c_str(), out, wrap, bad.empty() ? nullptr : bad.c_str());
 }
 
 int ss_comm_rank(const ss_comm *c) { return c ? c->rank : -1; }

@@ -127,6 +127,12 @@ struct TdState {                 // per stream / per handle, device resident
     float sample_peak[kMaxChannels];
     float true_peak[kMaxChannels];
     uint64_t frames_fed;                 // since reset
+    // Non-finite input (NaN, +-Inf).  In the crate such a sample poisons the channel's DF-II state for good: every later filtered
+    // sample, hence every later gating block, is NaN and `sum >= boundary` never holds again.  A wave notes the FIRST sub-block
+    // in which it met one: bad_key[c] = ~index (0 = none yet, so the zero fill of a reset is "none" and atomicMax keeps the
+    // earliest); the gating kernels read every sub-block of a weighted channel BEHIND that one as NaN — which a launch cut into
+    // time segments (each starting from a zero state) would otherwise not know.
+    uint32_t bad_key[kMaxChannels];
 };
 
 struct TdParams {
@@ -199,6 +205,7 @@ struct FinalizeParams {
     double *out_lra;                 // [stream] (nullable)
     uint32_t *out_counts;            // [stream][2] gating / short-term blocks evaluated (nullable)
     const uint32_t *sub_end_of;   // ragged batches: sub-blocks of each stream (nullable = sub_end for all)
+    const TdState *state;         // [stream]: bad_key (first sub-block with a non-finite sample per channel); nullable
     // streaming form only (one handle): behind the histogram updates the same wave takes the handle's readings — (integrated,
     // range) into readings_out, the peaks and the flag as in ReadingsExtra below (readings_out == nullptr: off)
     double *readings_out;

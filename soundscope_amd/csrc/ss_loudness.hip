@@ -35,6 +35,20 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
+// First sub-block of a stream in which a WEIGHTED channel met a non-finite sample (TdState::bad_key), 0xFFFFFFFF if none: one whole
+// wave asks, every lane gets the answer.  The crate's filter state is NaN from that sample on, for good: every window that ends
+// BEHIND this sub-block has a NaN energy (`sum >= boundary` fails: no histogram entry), whichever segment of a launch computed
+// its sub-blocks from whichever starting state; the window that ends WITH it holds what the recurrence itself produced (NaN, or
+// +Inf if the sample was an infinity in the sub-block's very last frame).  Channels the crate does not filter (weight 0) never count.
+__device__ __forceinline__ uint32_t first_bad_subblock(const TdState *st, uint32_t C, const double *__restrict__ weights, uint32_t lane)
+{
+    uint32_t key = 0u;
+    if (st) for (uint32_t c = lane; c < C; c += 64u) { const uint32_t k = st->bad_key[c]; if (weights[c] != 0.0 && k > key) key = k; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)key, o, 64); key = t > key ? t : key; }
+    return ~key;
+}
+
 // one wave evaluates gate and LRA on an LDS histogram pair (block, short-term); inlined: `en` / `bd` are LDS copies of the tables
 // in the latency-bound callers (every dependent table read is then an LDS access, not a round trip to L2)
 __device__ __forceinline__ void eval_hist(const unsigned long long *hb, const unsigned long long *hs,
@@ -193,6 +207,7 @@ __global__ __launch_bounds__(SMALL ? 256 : 1024) void k_finalize(FinalizeParams 
     __shared__ unsigned long long hb[kHistBins];
     __shared__ unsigned long long hs[kHistBins];
     __shared__ unsigned int counts[2];
+    __shared__ uint32_t bad_from_s;
     __shared__ double tab[SMALL ? 2 * kHistBins + 1 : 1];          // SMALL: [energies 1000][bounds 1001]
     const uint32_t stream = blockIdx.x;
     const int lane = threadIdx.x, nthr = (int)blockDim.x;
@@ -204,6 +219,10 @@ __global__ __launch_bounds__(SMALL ? 256 : 1024) void k_finalize(FinalizeParams 
     }
     if (SMALL && lane == 0) tab[2 * kHistBins] = p.hist_bounds[kHistBins];
     if (lane < 2) counts[lane] = 0;
+    if (lane < 64) {
+        const uint32_t bf = first_bad_subblock(p.state ? p.state + stream : nullptr, p.channels, p.weights, (uint32_t)lane);
+        if (lane == 0) bad_from_s = bf;
+    }
     const double *en = SMALL ? tab : p.hist_energies;
     const double *bd = SMALL ? tab + kHistBins : p.hist_bounds;
     const double bd0 = p.hist_bounds[0];                                                  // (read before the barrier: in flight with the rest)
@@ -216,6 +235,7 @@ __global__ __launch_bounds__(SMALL ? 256 : 1024) void k_finalize(FinalizeParams 
     const double *P = p.subblocks + (size_t)stream * p.sub_stride;
     const uint32_t cap = p.sub_cap;
     const bool direct = p.sub_end <= (uint64_t)cap && p.sub_begin == 0;               // batches: slot == sub-block index
+    const uint64_t bad_from = bad_from_s;
     uint32_t nb = 0, ns = 0;
     // gating blocks: one per sub-block j >= 3
     for (uint64_t j = (p.sub_begin > 3 ? p.sub_begin : 3) + lane; j < sub_end; j += nthr) {
@@ -225,6 +245,7 @@ __global__ __launch_bounds__(SMALL ? 256 : 1024) void k_finalize(FinalizeParams 
         else sum = direct ? window_energy<4, true>(P, jm, cap, C, p.weights) : window_energy<4, false>(P, jm, cap, C, p.weights);
         sum /= 4.0 * S;
         nb++;
+        if (j > bad_from) sum = __builtin_nan("");
         if (sum >= bd0) atomicAdd(&hb[hist_index(bd, sum)], 1ull);
     }
     // short-term blocks: j = 29 + 10 m.  Dealt densely (thread = m), not as every tenth lane of the loop above
@@ -239,6 +260,7 @@ __global__ __launch_bounds__(SMALL ? 256 : 1024) void k_finalize(FinalizeParams 
             else sum = direct ? window_energy<30, true>(P, jm, cap, C, p.weights) : window_energy<30, false>(P, jm, cap, C, p.weights);
             sum /= 30.0 * S;
             ns++;
+            if (j > bad_from) sum = __builtin_nan("");
             if (sum >= bd0) atomicAdd(&hs[hist_index(bd, sum)], 1ull);
         }
     }
@@ -274,6 +296,7 @@ __global__ __launch_bounds__(64) void k_finalize_stream(FinalizeParams p)
     if (lane == 0) tab[2 * kHistBins] = p.hist_bounds[kHistBins];
     const double *en = tab, *bd = tab + kHistBins;
     const double bd0 = p.hist_bounds[0];
+    const uint64_t bad_from = first_bad_subblock(p.state, p.channels, p.weights, (uint32_t)lane);
     __syncthreads();
     unsigned long long *gh = reinterpret_cast<unsigned long long *>(p.hist);
     const uint32_t C = p.channels;
@@ -282,7 +305,8 @@ __global__ __launch_bounds__(64) void k_finalize_stream(FinalizeParams p)
     uint32_t nb = 0, ns = 0;
     const uint32_t cap = p.sub_cap;
     for (uint64_t j = (p.sub_begin > 3 ? p.sub_begin : 3) + lane; j < p.sub_end; j += 64) {
-        const double sum = window_energy_eager<4, false>(P, (uint32_t)(j % cap), cap, C, p.weights) / (4.0 * S);
+        double sum = window_energy_eager<4, false>(P, (uint32_t)(j % cap), cap, C, p.weights) / (4.0 * S);
+        if (j > bad_from) sum = __builtin_nan("");
         nb++;
         if (sum >= bd0) atomicAdd(&gh[hist_index(bd, sum)], 1ull);
     }
@@ -291,7 +315,8 @@ __global__ __launch_bounds__(64) void k_finalize_stream(FinalizeParams p)
         for (uint64_t m = m_begin + lane;; m += 64) {
             const uint64_t j = 29 + 10 * m;
             if (j >= p.sub_end) break;
-            const double sum = window_energy_eager<30, false>(P, (uint32_t)(j % cap), cap, C, p.weights) / (30.0 * S);
+            double sum = window_energy_eager<30, false>(P, (uint32_t)(j % cap), cap, C, p.weights) / (30.0 * S);
+            if (j > bad_from) sum = __builtin_nan("");
             ns++;
             if (sum >= bd0) atomicAdd(&gh[kHistBins + hist_index(bd, sum)], 1ull);
         }
@@ -411,13 +436,14 @@ __global__ __launch_bounds__(256) void k_ring_energy(const double *ring, uint32_
             c += cstep; if (c >= C) c -= C;
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) acc = fma(w[q] * y[q], y[q], acc);
-    }
+        for (int q = 0; q < 4; q++) acc = w[q] != 0.0 ? fma(w[q] * y[q], y[q], acc) : acc;      // (weight 0: a channel the crate does not
+    }                                                                                              //  filter — its ring stays zero there, whatever the input)
     for (; i < total; i += kStride) {
         uint32_t e = begin_elem + i;
         if (e >= ring_elems) e -= ring_elems;
         const double y = ring[e];
-        acc = fma(weights[c] * y, y, acc);
+        const double wc = weights[c];
+        acc = wc != 0.0 ? fma(wc * y, y, acc) : acc;
         c += cstep; if (c >= C) c -= C;
     }
     // workgroup sum: shuffle tree inside each wave, then the four wave sums in a fixed order

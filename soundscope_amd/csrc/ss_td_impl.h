@@ -203,6 +203,14 @@ constexpr int kTdBatch = SS_TD_BATCH;          // LDS reads issued together in t
     u3 = fma(b3, v0_, u4);                       \
     u4 = b4 * v0_;
 
+// one tap of the crate's interpolator loop: the product and the sum rounded separately (Rust does not contract a * b + c)
+__device__ __forceinline__ float tp_mul_then_add(float acc, float x, float c)
+{
+#pragma clang fp contract(off)
+    const float pr = x * c;
+    return acc + pr;
+}
+
 // maximum over the wave of a non-negative float, as its bit pattern in an SGPR (non-negative floats order like
 // unsigned integers): four DPP row rotations and three scalar maxima — no LDS crossbar traffic
 __device__ __forceinline__ uint32_t wave_max_nonneg_bits(float v)
@@ -294,13 +302,14 @@ __device__ __forceinline__ void ring_window_partial(const TdParams &p, uint32_t 
             c += cstep; if (c >= C) c -= C;
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) acc = fma(w[q] * y[q], y[q], acc);
+        for (int q = 0; q < 4; q++) acc = w[q] != 0.0 ? fma(w[q] * y[q], y[q], acc) : acc;      // (weight 0: the crate does not filter that channel)
     }
     for (; i < p.st_old_total; i += stride) {
         uint32_t e = p.st_begin_elem + i;
         if (e >= ring_elems) e -= ring_elems;
         const double y = p.ring[e];
-        acc = fma(p.st_weights[c] * y, y, acc);
+        const double wc = p.st_weights[c];
+        acc = wc != 0.0 ? fma(wc * y, y, acc) : acc;
         c += cstep; if (c >= C) c -= C;
     }
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_down(acc, d, 64);

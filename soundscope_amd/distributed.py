@@ -28,12 +28,25 @@ class Comm:
 
     def __init__(self, rank=None, world=None, rendezvous_file=None, transport="rccl", device=None):
         """rank None: everything from the launcher's environment (ss_comm_init_from_env: RANK, WORLD_SIZE, the rank's GPU from
-        SS_COMM_DEVICE or LOCAL_RANK).  device (RCCL): the rank's GPU, made current INSIDE the call, behind the HSA IPC default —
+        SS_COMM_DEVICE or LOCAL_RANK; a LOCAL_RANK beyond the visible devices — launchers that mask one GPU per rank — wraps onto
+        them).  device (RCCL; ignored by the host transport, which touches no GPU): the rank's GPU, made current INSIDE the call, behind the HSA IPC default —
         a rank creates its communicator before any other GPU call and does not call ss_set_device first (include/soundscope_hip.h)."""
         t = {"rccl": L.SS_COMM_RCCL, "host-tcp": L.SS_COMM_HOST_TCP}[transport]
         self._h = C.c_void_p()
         if rank is None:
-            rc = L.lib().ss_comm_init_from_env(t, C.byref(self._h))
+            # (an explicit device with ranks from the environment: handed to the library as SS_COMM_DEVICE for this one call)
+            import os
+            had = os.environ.get("SS_COMM_DEVICE")
+            if device is not None:
+                os.environ["SS_COMM_DEVICE"] = str(int(device))
+            try:
+                rc = L.lib().ss_comm_init_from_env(t, C.byref(self._h))
+            finally:
+                if device is not None:
+                    if had is None:
+                        os.environ.pop("SS_COMM_DEVICE", None)
+                    else:
+                        os.environ["SS_COMM_DEVICE"] = had
         else:
             f = rendezvous_file.encode() if rendezvous_file else None
             if device is None:

@@ -216,28 +216,27 @@ def test_true_peak_quiet_streams(oracle, peak, arith):
     assert rel_close(l, max(m.true_peak(0), m.sample_peak(0))) and rel_close(r, max(m.true_peak(1), m.sample_peak(1)))
 
 
-def test_documented_deviation_nan_samples_is_pinned(oracle):
-    """DESIGN section 6 lists ONE deliberate deviation; this pins what the device actually returns for it.
-    NaN samples: the oracle's interpolator loses the 12 outputs per phase that touch a NaN; the device's matrix
-    form loses the outputs of the whole 16-sample window.  Both ignore NaN in every maximum (IEEE maxNum /
-    Rust's `>`), so results stay finite and, when the programme's peak is not next to the NaN, equal."""
+def test_nan_samples_next_to_the_interpolator_match_the_crate(oracle):
+    """Until round 5 this pinned DESIGN section 6's one deliberate deviation (the matrix form lost the whole 16-sample window of a
+    NaN, the crate the 12 outputs per phase whose taps touch it).  A tile that holds a non-finite sample — or has one within the
+    interpolator's reach in front of it — now runs the crate's own loop instead of the matrix product, so this is a plain parity
+    test: peaks AND the loudness readings (the NaN poisons every later gating block: tests/test_gpu_nonfinite.py)."""
     rate, frames = 48000, 48000 * 4
     x = make_stereo(321, frames, rate, level=0.4)
-    # the loudest inter-sample region sits somewhere in the programme; put NaNs far away from the global sample peak
-    pk = int(np.argmax(np.abs(x[0::2])))
-    holes = [f for f in (1000, 50001, 123456, 150000) if abs(f - pk) > 64]
     xn = x.copy()
-    for f in holes:
+    for f in (1000, 50001, 123456, 150000):
         xn[2 * f] = np.nan
     b = ssa.Batch(rate, 2, 2, frames, 4096, 1024, flags=L.SS_BATCH_TRUE_PEAK | L.SS_BATCH_LUFS)
     b.upload(0, np.concatenate([x, xn])); b.run(); b.sync()
     res = b.results()
-    m = oracle.Meter(2, rate); m.add_frames(xn)
-    assert np.isfinite(res[1].true_peak[0]) and np.isfinite(res[1].sample_peak[0])
-    assert res[1].sample_peak[0] == m.sample_peak(0) and res[1].sample_peak[1] == m.sample_peak(1)
-    assert rel_close(res[1].true_peak[1], max(m.true_peak(1), m.sample_peak(1)))        # the channel without NaN
-    assert res[1].true_peak[0] <= res[0].true_peak[0] * (1 + 1e-6)                       # a NaN can only hide outputs
-    assert res[1].true_peak[0] >= res[1].sample_peak[0]
+    for i, sig in enumerate((x, xn)):
+        m = oracle.Meter(2, rate); m.add_frames(sig)
+        for c in range(2):
+            assert res[i].sample_peak[c] == m.sample_peak(c)
+            assert rel_close(res[i].true_peak[c], max(m.true_peak(c), m.sample_peak(c))), (i, c)
+        assert lufs_close(res[i].integrated_lufs, m.integrated()), (i, res[i].integrated_lufs, m.integrated())
+        assert abs(res[i].loudness_range - m.loudness_range()) <= TOL_DB
+    assert np.isfinite(res[1].true_peak[0]) and res[1].true_peak[0] <= res[0].true_peak[0] * (1 + 1e-6)     # a NaN can only hide outputs
 
 
 @pytest.mark.parametrize("rate,slice_len", [(48000, 16384), (44100, 2 * 4410), (96000, 16384)])

@@ -1,0 +1,25 @@
+#!/bin/bash
+# round 6's same-box A/B calls (logs under gpurun_out/<tag>/; summaries copied into profiles/r06_ab_*.txt)
+#   a: the non-finite-sample handling (TdState::bad_key, the exact true-peak path for tiles that hold one) against round 5's
+#      library at config 3 and config 5, three interleaved repetitions; and the new tests against round 5's library (they must fail there)
+set -u
+what=${1:?which}; tag=${2:-r6ab}
+out=gpurun_out/$tag; mkdir -p $out
+case $what in
+  a)
+    for rep in 1 2 3; do
+      for lib in tools/bin/r5.so default; do
+        echo "=== config 3 rep $rep $lib"
+        if [ $lib = default ]; then python tools/perf_probe.py 1024 10; else SOUNDSCOPE_HIP_LIB=$(realpath $lib) python tools/perf_probe.py 1024 10; fi
+      done
+    done > $out/ab_nonfinite_cfg3.txt 2>&1
+    for rep in 1 2; do
+      for lib in tools/bin/r5.so default; do
+        echo "=== config 5 rep $rep $lib"
+        if [ $lib = default ]; then python tools/probe_cfg5.py 64; else SOUNDSCOPE_HIP_LIB=$(realpath $lib) python tools/probe_cfg5.py 64; fi
+      done
+    done > $out/ab_nonfinite_cfg5.txt 2>&1
+    SOUNDSCOPE_HIP_LIB=$(realpath tools/bin/r5.so) python -m pytest tests/test_gpu_nonfinite.py -m gpu -q 2>&1 | tail -45 > $out/nonfinite_tests_on_round5_lib.txt
+    grep -E "===|k_time_domain|k_fft|sum" $out/ab_nonfinite_cfg3.txt; grep -E "===|k_time_domain|k_fft16k" $out/ab_nonfinite_cfg5.txt; tail -32 $out/nonfinite_tests_on_round5_lib.txt
+    ;;
+esac

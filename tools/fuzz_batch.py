@@ -60,6 +60,14 @@ def plan(seed):
         if r2 < 0.12 and ch == 2: x[1::2] = x[0::2]                        # dual mono: the side row is the -150 dB floor + pink
         elif r2 < 0.24: x[: ch * (slot // 2)] = 0.0                        # digital silence in front of the programme: empty rows, the floor again
         elif r2 < 0.30 and ch > 1: x.reshape(slot, ch)[:, ch - 1] = 0.0    # one silent channel
+        # non-finite samples (round 6): one to three of NaN / +Inf / -Inf anywhere, any channel (weighted or not), the programme 20 dB
+        # louder behind the first of them — in the crate the channel's filter state is NaN from there on and no later block counts
+        r4 = np.random.default_rng(seed * 13 + k + 4 * 10 ** 6)
+        if r4.random() < 0.25 and "--finite" not in sys.argv:
+            xm = x.reshape(slot, ch)
+            at = sorted(int(v) for v in r4.integers(0, slot, int(r4.integers(1, 4))))
+            if r4.random() < 0.7: xm[: at[0]] *= np.float32(0.1)
+            for f in at: xm[f, int(r4.integers(0, ch))] = [np.nan, np.inf, -np.inf][int(r4.integers(0, 3))]
         content.append(x)
     lens = [slot] * ns
     if ragged:
@@ -115,7 +123,7 @@ def programme(seed):
             if n:
                 m = po.Meter(ch, rate, force_tp_factor=tpf); m.add_frames(x)
                 r["I"], r["lra"] = m.integrated(), m.loudness_range()
-                r["tp"] = [m.true_peak(c) for c in range(ch)]; r["sp"] = [m.sample_peak(c) for c in range(ch)]
+                r["sp"] = [m.sample_peak(c) for c in range(ch)]; r["tp"] = [max(m.true_peak(c), r["sp"][c]) for c in range(ch)]
                 r["wave"] = po.get_waveform(x, n / rate)
             refs[key] = r
         r = refs[key]
@@ -128,7 +136,7 @@ def programme(seed):
         tp, sp = b.peaks(i)
         if flags & L.SS_BATCH_TRUE_PEAK:
             for c in range(ch):
-                if not abs(tp[c] - r["tp"][c]) <= 1e-4 * max(abs(r["tp"][c]), 1e-30): bad(f"pass {pass_no} stream {i} ch {c}: true peak {tp[c]} vs {r['tp'][c]}")
+                if not (tp[c] == r["tp"][c] or abs(tp[c] - r["tp"][c]) <= 1e-4 * max(abs(r["tp"][c]), 1e-30)): bad(f"pass {pass_no} stream {i} ch {c}: true peak {tp[c]} vs {r['tp'][c]}")
                 if sp[c] != r["sp"][c]: bad(f"pass {pass_no} stream {i} ch {c}: sample peak {sp[c]} vs {r['sp'][c]}")
         if flags & L.SS_BATCH_WAVEFORM:
             w = b.waveform(i).reshape(-1)
@@ -147,7 +155,8 @@ def programme(seed):
                 for wdx in sorted(set([0, nw // 2, nw - 1])):
                     start = (wdx + fft_n // hop + 1) * hop - fft_n      # positions p = k hop with N < p <= F, window [p - N, p) (tui.rs:1489)
                     for c in sorted(set([0, len(sig) - 1])):
-                        ref = po.get_fft(rate, sig[c][start:start + fft_n])[:, 1]
+                        try: ref = po.get_fft(rate, sig[c][start:start + fft_n])[:, 1]
+                        except po.OracleError: continue                 # (a non-finite sample inside the window: the crate refuses it)
                         # (0.015 dB here, 0.01 in the committed tests: at the metric's edge, 70 dB under the row's peak, the difference of two
                         # f32 transforms' rounding noise is 0.004 dB typical — over thousands of random rows the tail reaches 0.011, seed 102143)
                         if not db_close(fft[wdx, c], ref, 0.015): bad(f"pass {pass_no} stream {i} window {wdx} ch {c}: spectrum row differs {db_report(fft[wdx, c], ref)} row peak {float(ref.max()):.1f} dB")
