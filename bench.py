@@ -589,8 +589,9 @@ def main():
                                    f" x {args.seconds:g} s, {args.rate} Hz stereo f32: mid/side {args.fft_n}-pt Hann FFT "
                                    f"hop {args.hop} + K-weighted gated LUFS/LRA + 4x true peak + min-max decimation "
                                    "+ corpus gate (1 all-reduce of 2x1000 u64)",
-                       "n1_workload": "N = 1 runs BASELINE config 3 (1024 streams on the GPU); N > 1 runs config 4 (8192 streams in total, "
-                                      "sharded, strong scaling): samples/s are comparable across N, ms_per_step are not",
+                       "n1_workload": "N = 1: value = BASELINE config 3 (1024 streams on the GPU); N > 1 runs config 4 (8192 streams in total, "
+                                      "sharded, strong scaling).  The same-workload base of the N > 1 points is config.n1_strong_value of the "
+                                      "N = 1 line (config 4's 8192 streams on ONE GPU); samples/s are comparable across N, ms_per_step are not",
                        "streams_total": total_streams, "streams_this_rank": count, "windows_per_stream": lay.n_windows, "bins": lay.n_bins,
                        "sharding": f"streams, {world} rank(s)",
                        "collective": ({"lib": "none", "nranks": 1} if comm is None else {"lib": comm.transport, "nranks": comm.size, "ncclCommCount": comm.size if comm.transport == "rccl" else None,
@@ -640,9 +641,53 @@ def main():
             out["config"]["gpu_over_cpu_1core"] = value / cb["value"]
         else:
             out["cpu_baseline"] = None
+        # what the driver's record keeps of `config` are its scalar entries: the facts a reader of BENCH / SCALE files needs are
+        # repeated flat beside the nested objects
+        cfgd = out["config"]
+        cfgd["collective_lib"] = "none" if comm is None else comm.transport
+        cfgd["collective_nranks"] = 1 if comm is None else comm.size
+        cfgd["ncclCommCount"] = comm.size if (comm is not None and comm.transport == "rccl") else None
+        cfgd["rccl_version"] = comm.library_version if comm is not None else None
+        cfgd["td_segments"] = geo.td_segments
+        cfgd["td_handover"] = cfgd["geometry"]["td_handover"]
+        for kname, kms in kernels.items():
+            cfgd["kernel_ms_" + kname] = kms
+        if sustained:
+            cfgd["sustained_value"] = sustained["value"]
+            cfgd["sustained_ms_per_step"] = sustained["ms_per_step"]
+            cfgd["sustained_sclk_mhz_under_load"] = sustained["sclk_mhz_under_load"]
+        if io_floor_ms:
+            out["roofline"]["io_floor_ms"] = io_floor_ms
+            out["roofline"]["kernel_over_io_floor"] = (fft_ms / max(fft_n_launch, 1)) / io_floor_ms
         if world == 1 and not args.no_extra:
             b.close()
             extra = []
+            if not strong:
+                # The same-workload base of the scaling curve: N > 1 runs BASELINE config 4 (8192 streams in total, sharded), so N = 1
+                # ALSO times config 4's whole corpus on this one GPU (85 GB of the 288 fit) — the step of the N > 1 runs, rank count 1.
+                # `value` stays config 3 (the metric's configuration); this is the figure the N >= 2 points divide by.
+                try:
+                    b8 = ssa.Batch(args.rate, 2, CONFIG4_TOTAL_STREAMS, frames, args.fft_n, args.hop, flags=L.SS_BATCH_ALL)
+                    b8.synthesize(0x5EED0000, 0)
+                    b8.set_overlap(ov_mode)
+                    for _ in range(2):
+                        b8.run(); b8.corpus_gate_enqueue(None)
+                    lib.ss_device_synchronize()
+                    n8 = 5
+                    t8 = time.perf_counter()
+                    for _ in range(n8):
+                        b8.run(); b8.corpus_gate_enqueue(None)
+                    lib.ss_device_synchronize()
+                    d8 = time.perf_counter() - t8
+                    b8.sync()
+                    cfgd["n1_strong_value"] = CONFIG4_TOTAL_STREAMS * frames * 2 * n8 / d8
+                    cfgd["n1_strong_ms_per_step"] = d8 / n8 * 1e3
+                    cfgd["n1_strong_streams"] = CONFIG4_TOTAL_STREAMS
+                    cfgd["n1_strong_corpus_integrated_lufs"] = b8.corpus_gate_read()[0]
+                    b8.close()
+                except Exception as ex:                                   # noqa: BLE001 — (a smaller card: the line says so)
+                    cfgd["n1_strong_value"] = None
+                    cfgd["n1_strong_error"] = repr(ex)
             try:
                 # config 3 as BASELINE.json words it ("4096-pt FFT + LUFS"): the headline step additionally carries the
                 # 4x true peak and the decimation that north_star puts on the path
@@ -670,6 +715,10 @@ def main():
                     e = time_config(ssa, L, 96000, 8, 64, 960000, 16384, 1024, tp, steps=3)
                     e["workload"] = f"config 5: 64 streams x 10 s, 96 kHz 8 ch, N=16384 hop 1024 per channel, {name}"
                     extra.append(e)
+                    tag = "config5_tp4x" if tp == 4 else "config5_tp2x"
+                    cfgd[tag + "_samples_per_s"] = e.get("samples_per_s")
+                    for kname, kms in (e.get("kernel_ms") or {}).items():
+                        cfgd[tag + "_ms_" + kname] = kms
             except Exception as ex:
                 extra.append({"error": repr(ex)})
             out["config"]["extra"] = extra

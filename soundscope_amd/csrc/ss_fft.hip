@@ -260,6 +260,20 @@ __device__ __forceinline__ void fft4096_epilogue(const v2f *xb, int t, uint32_t 
 // every sample is +-0; a NaN does not count, its row is garbage either way); a window whose row is empty takes this rare
 // path BEHIND the ordinary epilogue and overwrites that row with the floor, -150 dB + pink (exactly what the epilogue
 // writes for a zero magnitude).  Kept out of the epilogue itself: the hot path's registers.
+// Rows of windows the reference REFUSES (a NaN or an infinite sample inside: SpectrumAnalyzerError::NaNValuesNotSupported /
+// InfinityValuesNotSupported, analyzer.rs:60-65): NaN in every bin.  (A transform that carries such a sample comes out non-finite
+// in every bin by itself; this is for the kernels that pack TWO windows into one transform and keep the refused one out of it.)
+__device__ __forceinline__ void fft4096_nan_rows(int t, uint32_t n_bins, float *o_first, float *o_second, bool first_nan, bool second_nan)
+{
+    const uint32_t ngroups = (n_bins + 3) >> 2;
+    __builtin_amdgcn_s_waitcnt(0);                  // the ordinary stores of these rows have left the wave: these come after them
+    const float qn = __builtin_nanf("");
+    for (uint32_t g = (uint32_t)t; g < ngroups; g += 256u) {
+        if (first_nan) reinterpret_cast<float4 *>(o_first)[g] = make_float4(qn, qn, qn, qn);
+        if (second_nan) reinterpret_cast<float4 *>(o_second)[g] = make_float4(qn, qn, qn, qn);
+    }
+}
+
 __device__ __forceinline__ void fft4096_floor_rows(int t, uint32_t n_bins, float db_offset, const float *__restrict__ offpink,
                                                 float *o_first, float *o_second, bool first_zero, bool second_zero)
 {
@@ -949,8 +963,12 @@ __global__ __launch_bounds__(256, SS_FFT_PAIRW_WAVES) void k_fft4096_pairw(FftBa
     // every level 0 — is the zero-row case of fft4096_floor_rows
     const uint32_t wvid = (uint32_t)__builtin_amdgcn_readfirstlane(t >> 6);
     const bool lane63 = (t & 63) == 63;
+    // (largest |.| as a bit pattern, taken with INTEGER maxima: a NaN — which fmaxf would drop — and an infinity both read
+    // >= 0x7F800000, and that is how a window the reference refuses is recognised below)
     auto hop_level = [&](float a, float b, float c, float d) -> uint32_t {
-        return wave_umax_lane63(__float_as_uint(fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d)))));
+        const uint32_t ua = __float_as_uint(a) & 0x7FFFFFFFu, ub = __float_as_uint(b) & 0x7FFFFFFFu;
+        const uint32_t uc = __float_as_uint(c) & 0x7FFFFFFFu, ud = __float_as_uint(d) & 0x7FFFFFFFu;
+        return wave_umax_lane63(umax(umax(ua, ub), umax(uc, ud)));
     };
     auto read_level = [&](const uint32_t *lv) -> uint32_t {
         const uint4 q = *reinterpret_cast<const uint4 *>(lv);
@@ -969,6 +987,7 @@ __global__ __launch_bounds__(256, SS_FFT_PAIRW_WAVES) void k_fft4096_pairw(FftBa
     // block exponent of the pair now in the registers; hw2 is rewritten when it moves by two or more
     auto settle = [&]() {
         if ((P[0] | P[1] | P[2] | P[3]) == 0u || (P[1] | P[2] | P[3] | P[4]) == 0u) return;      // an empty window has no level
+        if (umax(umax(umax(P[0], P[1]), umax(P[2], P[3])), P[4]) >= 0x7F800000u) return;          // ... nor has a refused one (E stays)
         const uint32_t ma = umax(P[1], P[2]), ea = umax(P[0], P[3]), mb = umax(P[2], P[3]), eb = umax(P[1], P[4]);
         int T;
         if (ma != 0u && mb != 0u && ea <= ma + 0x800000u && eb <= mb + 0x800000u) {
@@ -1006,9 +1025,18 @@ __global__ __launch_bounds__(256, SS_FFT_PAIRW_WAVES) void k_fft4096_pairw(FftBa
             nx[q] = 0.0f;
             if (q < 4 ? more : more2) nx[q] = nsrc[(size_t)(256 * (20 + q)) * C];
         }
+        // A window with a NaN or an infinite sample is refused by the reference; its partner in the transform — three quarters the
+        // same samples, but possibly not the one that matters — is not, and must not inherit the poison: the refused window stays
+        // OUT of the transform (zeros) and its row is written as NaN behind the epilogue.  Wave-uniform and rare.
+        const bool bad_a = umax(umax(P[0], P[1]), umax(P[2], P[3])) >= 0x7F800000u;
+        const bool bad_b = umax(umax(P[1], P[2]), umax(P[3], P[4])) >= 0x7F800000u;
         v2f z[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) z[j] = v2f{raw[j] * hw[j], raw[j + 4] * hw2[j]};
+        if (__builtin_expect(bad_a != bad_b, 0)) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) { if (bad_a) z[j].x = 0.0f; else z[j].y = 0.0f; }
+        }
         SS_PRIO_LO();
         fft16(z);
         SS_PRIO_HI();
@@ -1069,6 +1097,8 @@ __global__ __launch_bounds__(256, SS_FFT_PAIRW_WAVES) void k_fft4096_pairw(FftBa
         fft4096_epilogue(xbuf, t, p.first_bin, p.n_bins, p.db_offset, p.offpink, o_first, o_first + row_stride, two, block_off(E));
         if (__builtin_expect(zrow_a || (two && zrow_b), 0))
             fft4096_floor_rows(t, p.n_bins, p.db_offset, p.offpink, o_first, o_first + row_stride, zrow_a, two && zrow_b);
+        if (__builtin_expect(bad_a || bad_b, 0))
+            fft4096_nan_rows(t, p.n_bins, o_first, o_first + row_stride, bad_a, two && bad_b);
         if (more) {
 #pragma unroll
             for (int j = 0; j < 12; j++) raw[j] = raw[j + 8];
@@ -1303,6 +1333,7 @@ __global__ __launch_bounds__(512, SS_RUN8_WAVES) void k_fft16k_run(FftBatchParam
 #pragma unroll
     for (int j = 0; j < 16; j++) asm volatile("" : "+v"(raw[j]));
     __syncthreads();
+    SS_FPROF_DECL      // (-DSS_FFT_PROF: the window loop's phases, tools/probe_fft16k_phases.py)
 
     for (uint32_t w = w_begin; w < w_end; ++w) {
         const bool more = (w + 1 < w_end);
@@ -1343,10 +1374,14 @@ __global__ __launch_bounds__(512, SS_RUN8_WAVES) void k_fft16k_run(FftBatchParam
             xbuf[X1W(ka, tb, hi)] = v;
         }
         if (more) nx = ld2((size_t)(w + 1 - w_begin) * 1024u + n0 + 1024u * 15u);
+        SS_FPROF_MARK(0);
         __syncthreads();
+        SS_FPROF_MARK(1);
 #pragma unroll
         for (int ta = 0; ta < 16; ta++) z[ta] = lds_ld64(&xbuf[X1W(hi, tb, ta)]);
+        SS_FPROF_MARK(2);
         __syncthreads();
+        SS_FPROF_MARK(3);
         fft16(z);
         xbuf[X2W(0, hi, tb)] = z[R16(0)];
         {   // second-pass twiddles from the [kb][tb] table, four at a time, the next four requested before the current four are used
@@ -1369,10 +1404,14 @@ __global__ __launch_bounds__(512, SS_RUN8_WAVES) void k_fft16k_run(FftBatchParam
                 for (int j = 0; j < 4; j++) twa[j] = twb[j];
             }
         }
+        SS_FPROF_MARK(4);
         __syncthreads();
+        SS_FPROF_MARK(5);
 #pragma unroll
         for (int qq = 0; qq < 16; qq++) z[qq] = lds_ld64(&xbuf[X2W(hi, tb, qq)]);
+        SS_FPROF_MARK(6);
         __syncthreads();
+        SS_FPROF_MARK(7);
         fft16(z);
 #pragma unroll
         for (int kc = 0; kc < 16; kc++) xbuf[kc * 256 + t] = z[R16(kc)];          // Z_q[k] at k (natural order)
@@ -1385,7 +1424,9 @@ __global__ __launch_bounds__(512, SS_RUN8_WAVES) void k_fft16k_run(FftBatchParam
 #pragma unroll
             for (int e = 0; e < 4; e++) wt[e] = tw16k[(fbq + 256u * wv + 64u * e + lane) & 8191u];
         }
+        SS_FPROF_MARK(8);
         __syncthreads();
+        SS_FPROF_MARK(9);
         asm volatile("" : "+v"(nx));        // the prefetched hop is claimed in front of the epilogue's stores
 
         // ---- epilogue, all eight waves (both spectra are published).  Iteration `it` covers 2048 retained bins, wave wv the 256
@@ -1463,8 +1504,11 @@ __global__ __launch_bounds__(512, SS_RUN8_WAVES) void k_fft16k_run(FftBatchParam
             for (int j = 0; j < 15; j++) raw[j] = raw[j + 1];
             raw[15] = nx;
         }
+        SS_FPROF_MARK(10);
         __syncthreads();                    // epilogue reads are done before the next window's pass-1 writes
+        SS_FPROF_MARK(11);
     }
+    SS_FPROF_END;
 #undef X1W
 #undef X2W
 }

@@ -491,14 +491,16 @@ static hipError_t td_launch(const TdParams &p, hipStream_t s)
 {
     // a workgroup is four waves, one per SIMD: three workgroups per CU hold the whole grid -> the spill-free build
     if constexpr (RING) return td_launch_w<FACTOR, RING, CT, WAVE, 3>(p, s);      // a streaming call is one stream: one workgroup
-    const uint64_t waves = (uint64_t)p.n_streams * (p.fixup ? p.nseg - 1u : p.nseg);
-    const uint64_t blocks = (waves + kTdWavesPerBlock - 1) / kTdWavesPerBlock;
-    bool three = SS_TD_WAVES == 4 && blocks <= 3ull * td_device_cus();
+    else {                                             // (else: the four-waves build of a streaming form is never instantiated)
+        const uint64_t waves = (uint64_t)p.n_streams * (p.fixup ? p.nseg - 1u : p.nseg);
+        const uint64_t blocks = (waves + kTdWavesPerBlock - 1) / kTdWavesPerBlock;
+        bool three = SS_TD_WAVES == 4 && blocks <= 3ull * td_device_cus();
 #ifdef SS_TUNING        // development builds only: SS_TD_WPS=3|4 forces a register build
-    if (const char *e = std::getenv("SS_TD_WPS")) three = SS_TD_WAVES == 4 && std::atoi(e) == 3;
+        if (const char *e = std::getenv("SS_TD_WPS")) three = SS_TD_WAVES == 4 && std::atoi(e) == 3;
 #endif
-    if (three) return td_launch_w<FACTOR, RING, CT, WAVE, 3>(p, s);
-    return td_launch_w<FACTOR, RING, CT, WAVE, SS_TD_WAVES>(p, s);
+        if (three) return td_launch_w<FACTOR, RING, CT, WAVE, 3>(p, s);
+        return td_launch_w<FACTOR, RING, CT, WAVE, SS_TD_WAVES>(p, s);
+    }
 }
 
 // Decimation fast path (WAVE = 2): samples per bin spp = len / W is an exact integer multiple of four (<= 128), so
@@ -553,7 +555,7 @@ static hipError_t td_launch_c(const TdParams &p, hipStream_t s, const FftBatchPa
 #ifdef SS_TUNING        // development builds only: SS_TD_SPLIT=0 keeps streaming calls on one wave (A/B, drift measurements)
     if (const char *e = std::getenv("SS_TD_SPLIT")) split = split && std::atoi(e) != 0;
 #endif
-    if (split) {
+    if constexpr (RING) if (split) {            // (constexpr: the batch side never instantiates these forms)
         const uint32_t C = p.channels, S = p.s100;
         const uint32_t cap = (64u / C) * td_chunk_frames(C, S);
         const uint32_t pieces = (S + cap - 1) / cap;

@@ -75,6 +75,18 @@ def db_close_survey(got, ref, tol_db=0.01):
     return bool(ok_loud.all() and (lin_err <= 1e-4).all())
 
 
+def f64_spectrum_row(oracle, rate, s, fft_n):
+    """The row get_fft returns for window `s`, with the transform carried in f64 (numpy rfft of the oracle's f32 Hann-windowed
+    samples, the oracle's f32 bin frequencies, the same dB and pink expression): what both f32 transforms round around."""
+    hw = oracle.hann_window(s).astype(np.float64)
+    X = np.fft.rfft(hw)
+    fr = np.arange(X.size) * (np.float32(rate) / np.float32(fft_n))
+    keep = (fr >= 20) & (fr <= 20000)
+    mag, f = np.abs(X[keep]), fr[keep].astype(np.float64)
+    with np.errstate(divide="ignore"):
+        return np.where(mag == 0, -150.0, 20 * np.log10(mag * 4 / fft_n)) + 10 * np.log10(f / 1000.0)
+
+
 def db_report(got, ref, rel_floor_db=70.0):
     """(max |d| dB over the bins within rel_floor_db of the row peak, max linear error / peak amplitude below) — diagnostics"""
     got = np.asarray(got, np.float64); ref = np.asarray(ref, np.float64)

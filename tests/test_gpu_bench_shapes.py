@@ -162,6 +162,49 @@ def test_config5_bench_shape_all_channels(oracle, tp_factor, overlap, arith, td_
                 assert db_close(fft[w, c], ref[:, 1], TOL_DB), (i, w, c)
 
 
+@pytest.mark.parametrize("tp_factor", [4, 0])
+def test_config5_every_window_of_two_streams(oracle, tp_factor):
+    """Config 5's spectrum to the standard of config 3's: EVERY window (921) of all EIGHT channels of two streams — the first and the
+    last of the batch — against the oracle, with the benchmark's forced 4x true peak beside it and with the crate's rule (2x at
+    96 kHz).  Every row meets SURVEY section 7's wording of the bar (0.01 dB at >= -90 dBFS, 1e-4 of the row's largest amplitude
+    below).  The stricter row-peak metric (0.01 dB down to 70 dB under the row's own loudest bin, wherever that is) is met by all
+    but a handful of the 14736 rows: at N = 16384 a bin 70 dB under the peak sits where two f32 transforms of different radix are
+    each ~0.007 dB from the f64 result (stream 63, window 647, channel 3: a -42 dBFS row, device 0.0134 dB from the oracle at a
+    -112 dBFS bin; tools/probe_cfg5_rows.py).  Such a row must be within 0.015 dB of the oracle AND within 0.01 dB of the f64
+    transform of the same windowed samples (conftest.f64_spectrum_row) — i.e. the excess is the oracle's rounding, not the device's."""
+    from conftest import db_close_survey, f64_spectrum_row
+    rate, ch, frames, ns = 96000, 8, 960000, 64
+    b = ssa.Batch(rate, ch, ns, frames, 16384, 1024, flags=L.SS_BATCH_ALL, true_peak_factor=tp_factor)
+    b.synthesize(0x5EED0000, 0)
+    b.run(); b.sync()
+    lay, g = b.layout, b.geometry
+    assert (lay.n_windows, lay.fft_channels, lay.n_bins) == (921, 8, 3410)
+    assert g.fft_windows_per_block == 116 and g.td_true_peak_factor == (4 if tp_factor == 4 else 2)
+    n_edge = 0
+    for i in (0, ns - 1):
+        x = b.download_input(i).reshape(frames, ch)
+        cols = [np.ascontiguousarray(x[:, c]) for c in range(ch)]
+        fft = b.fft(i)
+        jobs = [(w, c) for w in range(lay.n_windows) for c in range(ch)]
+
+        def row_state(job):
+            w, c = job
+            start = (w + 1) * 1024                                  # window [p - N, p) at p = (w + 17) hop (tui.rs:1489)
+            s = cols[c][start:start + 16384]
+            ref = oracle.get_fft(rate, s)[:, 1]
+            if not db_close_survey(fft[w, c], ref, TOL_DB):
+                return 2
+            if db_close(fft[w, c], ref, TOL_DB):
+                return 0
+            return 1 if db_close(fft[w, c], ref, 0.015) and db_close(fft[w, c], f64_spectrum_row(oracle, rate, s, 16384), TOL_DB) else 2
+        with ThreadPoolExecutor(_threads()) as ex:
+            st = list(ex.map(row_state, jobs, chunksize=64))
+        bad = [jobs[k] for k, v in enumerate(st) if v == 2]
+        assert not bad, (i, len(bad), bad[:8])
+        n_edge += sum(1 for v in st if v == 1)
+    assert n_edge <= 4, n_edge                                      # (one, on the synthetic corpus of the benchmark)
+
+
 def test_batch_peaks_api(oracle):
     from conftest import make_multich
     rate, ch, frames = 48000, 6, 48000 * 2

@@ -296,3 +296,41 @@ def test_unused_channel_carries_anything_without_effect(oracle, kind):
             got, want = an.filter_state(c), m.filter_state(c)
             assert np.array_equal(np.isnan(got), np.isnan(want)), (ch, c, got, want)
         assert np.array_equal(an.filter_state(3), np.zeros(4))                      # never filtered
+
+
+# ---------------------------------------------------------------- the spectrum beside a refused window
+@pytest.mark.parametrize("rate,channels,fft_n", [(48000, 1, 4096), (48000, 6, 4096), (48000, 2, 4096), (96000, 8, 16384), (48000, 2, 16384), (44100, 3, 2048)])
+@pytest.mark.parametrize("kind", ["nan", "+inf"])
+def test_spectrum_rows_next_to_a_refused_window(oracle, rate, channels, fft_n, kind):
+    """get_fft refuses a window that holds a NaN or an infinite sample (spectrum-analyzer 1.7.0: NaNValuesNotSupported /
+    InfinityValuesNotSupported, analyzer.rs:60-65) and the reference's driver then draws nothing for that tick (tui.rs:1500-1520); every
+    OTHER window is analysed as ever.  In a batch: the rows of refused windows are non-finite in every bin, every other row equals
+    the oracle's — also in the kernels that pack two windows into one transform (mono / multichannel N = 4096 at hop 1024: windows
+    w and w + 1 ride together, and a sample in the last hop of w + 1 must not reach window w; found by tools/fuzz_batch.py once it
+    injected non-finite samples, round 6)."""
+    from conftest import db_close
+    hop = 1024
+    frames = fft_n + hop * 24 + 500
+    x = make_multich(900 + channels, frames, channels, rate, level=0.5) if channels != 2 else make_stereo(900, frames, rate, level=0.5)
+    holes = [(fft_n + hop * 5 + 17, 0), (fft_n + hop * 14 - 1, channels - 1), (fft_n + hop * 20 + hop // 2, 0)]
+    for f, c in holes:
+        x[channels * f + c] = BAD[kind]
+    b = ssa.Batch(rate, channels, 1, frames, fft_n, hop, flags=L.SS_BATCH_FFT)
+    b.upload(0, x); b.run(); b.sync()
+    fft = b.fft(0)
+    nw = frames // hop - fft_n // hop
+    assert fft.shape[0] == nw
+    sig = oracle.mid_side(x) if channels == 2 else [np.ascontiguousarray(x.reshape(frames, channels)[:, c]) for c in range(channels)]
+    n_refused = 0
+    for w in range(nw):
+        start = (w + fft_n // hop + 1) * hop - fft_n
+        for r in range(len(sig)):
+            s = sig[r][start:start + fft_n]
+            if np.isfinite(s).all():
+                ref = oracle.get_fft(rate, s)[:, 1]
+                assert np.isfinite(fft[w, r]).all(), (w, r)
+                assert db_close(fft[w, r], ref, TOL_DB), (w, r)
+            else:
+                n_refused += 1
+                assert not np.isfinite(fft[w, r]).any(), (w, r, fft[w, r][:8])
+    assert n_refused >= 3 * min(fft_n // hop, 8) - 2             # (every hole refuses fft_n / hop windows of its row, as far as the stream reaches)

@@ -218,9 +218,12 @@ def test_streaming_tiles_shared_by_four_waves_equal_one_wave(rate, channels):
     """A streaming call longer than one tile of the time-domain kernel is walked by the four waves of a workgroup, the filter
     state and the lanes' energy shares handed from tile to tile through LDS (k_time_domain SPLIT); a call of at most one tile
     runs on one wave.  The same programme fed in tick-sized calls (8192 frames: nine tiles at 48 kHz) and in single-tile
-    calls must leave the same meter: every reading to 1e-9 LU (the hand-over behind the scan is a different rounding of the
-    same state, 1e-16 relative; the energy sums keep their order), the carried state to 1e-9 of its largest component, the
-    sample peak exactly, the true peak to 1e-6 (a tile's f16-split scale looks at the twelve frames in front of it)."""
+    calls must leave the same meter: every reading to 1e-9 LU (the energy sums keep their order), the carried state to 1e-8 of its
+    largest component, the sample peak exactly, the true peak to 1e-6 (a tile's f16-split scale looks at the twelve frames in
+    front of it).  The state bar is the distance at which EITHER path stands from the sequential recurrence: a one-wave call runs
+    its first chunk from the carried state itself (round 6), the shared call applies that state behind the scan as a matrix
+    product — two roundings of one state, 5e-11 apart at 48 kHz and 3e-9 at 96 kHz, where each is 3e-9 ... 7e-9 from the oracle's
+    filter (tools/probe_split_vs_one.py)."""
     frames = rate * 4 + 123
     x = make_multich(7 + channels, frames, channels, rate) if channels != 2 else make_stereo(7, frames, rate, level=0.7, gap=True)
     small = 256                                                     # frames per call: inside one tile at every rate
@@ -236,7 +239,7 @@ def test_streaming_tiles_shared_by_four_waves_equal_one_wave(rate, channels):
             assert va == vb or abs(va - vb) <= 1e-9, (name, off, va, vb)
         for c in range(channels):
             ga, gb = a.filter_state(c), b.filter_state(c)
-            assert np.abs(ga - gb).max() <= 1e-9 * max(np.abs(gb).max(), 1e-300), (off, c, ga, gb)
+            assert np.abs(ga - gb).max() <= 1e-8 * max(np.abs(gb).max(), 1e-300), (off, c, ga, gb)
             assert a.get_sample_peak_channel(c) == b.get_sample_peak_channel(c)
             ta, tb = a.get_true_peak_channel(c), b.get_true_peak_channel(c)
             assert abs(ta - tb) <= 1e-6 * tb, (off, c, ta, tb)

@@ -132,7 +132,10 @@ def programme(seed, steps=40):
                     return fail(f"get_fft status {got if isinstance(got, int) else 'ok'} vs {ref if isinstance(ref, int) else 'ok'}")
             else:
                 if got.shape != ref.shape: return fail(f"get_fft shape {got.shape} vs {ref.shape}")
-                if ref.shape[0] and not (np.array_equal(got[:, 0], ref[:, 0]) and db_close(got[:, 1], ref[:, 1], 0.01)): return fail("get_fft values")
+                if ref.shape[0] and not (np.array_equal(got[:, 0], ref[:, 0]) and db_close(got[:, 1], ref[:, 1], 0.01)):
+                    from conftest import db_report
+                    return fail(f"get_fft values: x equal {np.array_equal(got[:, 0], ref[:, 0])}, (dB within 70 dB of the row peak, linear below) {db_report(got[:, 1], ref[:, 1])}, "
+                                f"row peak {ref[:, 1].max():.1f} dB, input peak {np.abs(x).max():.3g}, mean {x.mean():.3g}")
         elif op == "wave":
             n = int(rng.choice([0, 1, 7, 100, 1000, 44100, int(rng.integers(0, 300000))]))
             x = rng.uniform(-1, 1, n).astype(np.float32)
