@@ -109,6 +109,57 @@ static __device__ unsigned long long g_td_trace[32][16];
 #define SS_TRACE(slot)
 #endif
 
+// packed-f32 forms of the true-peak interpolator (stereo: a frame (L, R) is one packed operand): acc += c x with the tap c broadcast
+// from the low / high half of an SGPR pair
+typedef float v2f_td __attribute__((ext_vector_type(2)));
+// One polyphase branch over THREE consecutive frames, both channels: out0..2 = sum over k of c[k] (L, R)[n - k], k ascending, as
+// three interleaved chains of twelve packed operations (a multiply, eleven FMAs) in ONE asm statement — between separate statements
+// the compiler keeps a wait state for hazards it cannot rule out for inline asm (an s_nop per three instructions).  Operands:
+// %0..%2 the three results (frames n, n + 1, n + 2), %3..%16 the window's fourteen frames (n - 11 .. n + 2), %17..%22 the taps as
+// six SGPR pairs (c[2 m], c[2 m + 1]), broadcast through op_sel.
+#define SS_TP_VALU_PHASE3(o0, o1, o2, W, g, tc)                                                                          \
+    asm("v_pk_mul_f32 %0, %17, %14 op_sel:[0,0] op_sel_hi:[0,1]\n\t" \
+        "v_pk_mul_f32 %1, %17, %15 op_sel:[0,0] op_sel_hi:[0,1]\n\t" \
+        "v_pk_mul_f32 %2, %17, %16 op_sel:[0,0] op_sel_hi:[0,1]\n\t" \
+        "v_pk_fma_f32 %0, %17, %13, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 %1, %17, %14, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 %2, %17, %15, %2 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 %0, %18, %12, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t" \
+        "v_pk_fma_f32 %1, %18, %13, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t" \
+        "v_pk_fma_f32 %2, %18, %14, %2 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t" \
+        "v_pk_fma_f32 %0, %18, %11, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 %1, %18, %12, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 %2, %18, %13, %2 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 %0, %19, %10, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t" \
+        "v_pk_fma_f32 %1, %19, %11, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t" \
+        "v_pk_fma_f32 %2, %19, %12, %2 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t" \
+        "v_pk_fma_f32 %0, %19, %9, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 %1, %19, %10, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 %2, %19, %11, %2 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 %0, %20, %8, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t" \
+        "v_pk_fma_f32 %1, %20, %9, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t" \
+        "v_pk_fma_f32 %2, %20, %10, %2 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t" \
+        "v_pk_fma_f32 %0, %20, %7, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 %1, %20, %8, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 %2, %20, %9, %2 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 %0, %21, %6, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t" \
+        "v_pk_fma_f32 %1, %21, %7, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t" \
+        "v_pk_fma_f32 %2, %21, %8, %2 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t" \
+        "v_pk_fma_f32 %0, %21, %5, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 %1, %21, %6, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 %2, %21, %7, %2 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 %0, %22, %4, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t" \
+        "v_pk_fma_f32 %1, %22, %5, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t" \
+        "v_pk_fma_f32 %2, %22, %6, %2 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t" \
+        "v_pk_fma_f32 %0, %22, %3, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 %1, %22, %4, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 %2, %22, %5, %2 op_sel:[1,0,0] op_sel_hi:[1,1,1]"                                                                                                           \
+        : "=&v"(o0), "=&v"(o1), "=&v"(o2)                                                                                \
+        : "v"(W[3 * (g) + 0]), "v"(W[3 * (g) + 1]), "v"(W[3 * (g) + 2]), "v"(W[3 * (g) + 3]), "v"(W[3 * (g) + 4]),       \
+          "v"(W[3 * (g) + 5]), "v"(W[3 * (g) + 6]), "v"(W[3 * (g) + 7]), "v"(W[3 * (g) + 8]), "v"(W[3 * (g) + 9]),       \
+          "v"(W[3 * (g) + 10]), "v"(W[3 * (g) + 11]), "v"(W[3 * (g) + 12]), "v"(W[3 * (g) + 13]),                        \
+          "s"(tc[0]), "s"(tc[1]), "s"(tc[2]), "s"(tc[3]), "s"(tc[4]), "s"(tc[5]))
+
 template <int FACTOR>
 struct TpCfg {
     static constexpr int HIST = (FACTOR == 2) ? 24 : 12;     // taps per polyphase branch

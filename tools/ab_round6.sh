@@ -37,4 +37,15 @@ case $what in
     grep -E "===|k_time_domain|k_fft|sum|err" $out/ab_td_cuts_cfg3.txt; grep -E "===|k_time_domain|k_fft16k" $out/ab_td_cuts_cfg5.txt
     python -m pytest tests/test_gpu_nonfinite.py tests/test_gpu_bench_shapes.py -m gpu -q -x 2>&1 | tail -5
     ;;
+  c)  # the stereo 4x true peak on the packed-f32 VALU (v_pk_fma_f32, fifteen frames of both channels per lane) against the f32 MFMA
+      # banded product of the tree in front of it (tools/bin/r6b.so), config 3, three interleaved repetitions + the tests that hold the peaks
+    for rep in 1 2 3; do
+      for lib in tools/bin/r6b.so default; do
+        echo "=== config 3 rep $rep $lib"
+        if [ $lib = default ]; then python tools/perf_probe.py 1024 10 --check; else SOUNDSCOPE_HIP_LIB=$(realpath $lib) python tools/perf_probe.py 1024 10; fi
+      done
+    done > $out/ab_tp_valu_cfg3.txt 2>&1
+    grep -E "===|k_time_domain|k_fft|sum|err" $out/ab_tp_valu_cfg3.txt
+    python -m pytest tests/test_gpu_parity.py tests/test_gpu_nonfinite.py tests/test_gpu_bench_shapes.py tests/test_gpu_independent.py -m gpu -q -x 2>&1 | tail -5
+    ;;
 esac
