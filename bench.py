@@ -482,8 +482,8 @@ def main():
         raise SystemExit(f"device corpus gate {corpus_i, corpus_lra} != host {host_i, host_lra}")
 
     # The reference's true-peak arithmetic is an f32 FIR (ebur128's interpolator: f32 taps, f32 accumulation; analyzer.rs:139-141,
-    # 159-164).  The timed step above runs it at that width (SS_TP_ARITH_F32, the library's default: v_mfma_f32_16x16x4_f32, an
-    # f32 fma chain per output).  The SAME step is timed again with the opt-in f16x3 split on the matrix cores
+    # 159-164).  The timed step above runs it at that width (SS_TP_ARITH_F32, the library's default: an f32 fma chain per output —
+    # v_pk_fma_f32 on the packed VALU for 2 / 6 / 8 channels since round 6, v_mfma_f32_16x16x4_f32 for other counts).  The SAME step is timed again with the opt-in f16x3 split on the matrix cores
     # (ss_batch_set_true_peak_arith), and both modes' peaks of the timed batch are measured against an f64 polyphase
     # convolution of the same streams (numpy, independent of the oracle).
     if b.true_peak_arith != L.SS_TP_ARITH_F32:
@@ -535,9 +535,9 @@ def main():
         err_f16x3 = tp_error()
         b.set_true_peak_arith(L.SS_TP_ARITH_F32)
         b.run(); b.sync()
-        tp_arith = {"timed_default": "SS_TP_ARITH_F32 (v_mfma_f32_16x16x4_f32, the reference's width)",
+        tp_arith = {"timed_default": "SS_TP_ARITH_F32 (f32 fma chain per output on the packed VALU, v_pk_fma_f32: the reference's width)",
                     "value_f16x3_split": samples_per_step * args.steps / dt16, "ms_per_step_f16x3_split": dt16 / args.steps * 1e3,
-                    "max_rel_err_vs_f64_polyphase": {"f32_mfma (timed default, reference width)": err_f32, "f16x3_split (opt-in)": err_f16x3},
+                    "max_rel_err_vs_f64_polyphase": {"f32 (timed default, reference width)": err_f32, "f16x3_split (opt-in)": err_f16x3},
                     "streams_checked": min(4, count), "bar": 1e-4,
                     "what": "the same timed step with SS_TP_ARITH_F16X3 (opt-in, not the headline); errors of the 4x true peak of the "
                             "timed batch against an f64 polyphase convolution with the crate's f32 taps (numpy)"}

@@ -358,13 +358,16 @@ int ss_batch_set_time_domain_mode(ss_batch *b, int mode);
  * Per-kernel event timing (ss_batch_timing_enable) always runs sequentially. */
 int ss_batch_set_overlap(ss_batch *b, int mode);
 /* arithmetic of the 4x true-peak interpolator in batches (the Analyzer handle and the sessions: ss_analyzer_set_true_peak_arith, same default):
- *   SS_TP_ARITH_F32 (default)    v_mfma_f32_16x16x4_f32: an f32 fmaf chain per output, the width of ebur128's interpolator
- *                                (its 12 products per phase summed in f32; analyzer.rs:139-141,159-164);
+ *   SS_TP_ARITH_F32 (default)    an f32 fmaf chain per output, the width of ebur128's interpolator (its 12 products per phase
+ *                                summed in f32; analyzer.rs:139-141,159-164).  Factor 4 with 2, 6 or 8 channels: on the packed-f32
+ *                                VALU (v_pk_fma_f32; a frame's pair of adjacent channels is one packed operand, round 6);
+ *                                other channel counts and factor 2: v_mfma_f32_16x16x4_f32 as a banded-Toeplitz product;
  *   SS_TP_ARITH_F16X3 (opt-in)   three-term f16 split on the matrix cores with f32 accumulation, scaled per tile by a
  *                                power of two from the tile's own peak: within 2^-21 of the tile peak of the f32 result
  *                                (measured 2.0e-7 relative on the bench corpus against 1.1e-7 for the f32 product; north_star's
- *                                bar is 1e-4), ~25 % less time-domain kernel time.  2 / 8 channels only: other shapes, and
- *                                tiles with non-finite samples, take the f32 product whatever the mode. */
+ *                                bar is 1e-4), 3-5 % less time-domain kernel time since the f32 form left the matrix pipe
+ *                                (it was 25 %).  2 / 8 channels only: other shapes, and tiles with non-finite samples, take
+ *                                the f32 form whatever the mode. */
 enum { SS_TP_ARITH_F16X3 = 0, SS_TP_ARITH_F32 = 1 };
 int ss_batch_set_true_peak_arith(ss_batch *b, int arith);
 int ss_batch_get_true_peak_arith(const ss_batch *b);      /* SS_TP_ARITH_* */

@@ -48,7 +48,7 @@ def test_config3_bench_geometry_matches_oracle(oracle, overlap, arith, td_mode):
     full with the oracle (every window of both rows, LUFS, LRA, both peaks, every decimation bin), and the corpus
     histograms with the sum of all 1024 per-stream oracle histograms.
     arith: the 4x true peak at the reference's f32 width (the default, None, which bench.py's headline times:
-    v_mfma_f32_16x16x4_f32 on the stereo tile path), set explicitly, and as the opt-in f16x3 split.
+    v_pk_fma_f32 on the stereo tile path), set explicitly, and as the opt-in f16x3 split.
     td_mode: how the time-domain kernel walks a stream (ss_batch_set_time_domain_mode) — the default (time segments with the
     exact state hand-over: a fix-up launch over the first two sub-blocks of segments 1..3), the run-in form of earlier rounds,
     and whole-stream workgroups."""
