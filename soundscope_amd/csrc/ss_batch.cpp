@@ -352,7 +352,8 @@ int ss_batch_create(const ss_batch_config *cfg, ss_batch **out)
         // fuse into the time-domain pass when that pass runs and a bin (plus its shared edge sample)
         // fits the per-wave halo; otherwise the standalone kernel handles it
         if (b->td && W > 0 && spp >= 16.0 && spp <= 1000.0 && len < (1ull << 31)) {
-            const uint32_t need = ((uint32_t)std::ceil(spp) + 2 + C - 1) / C;
+            // (+ 3: the general decimation path reads the aligned 16-byte piece a bin starts in, up to three samples in front of it)
+            const uint32_t need = ((uint32_t)std::ceil(spp) + 5 + C - 1) / C;
             uint32_t halo = need < 24 ? 24 : need;
             halo = (halo + 3u) & ~3u;
             if (halo <= 512) { b->wave_fused = true; b->wave_halo = halo; }
