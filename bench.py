@@ -461,14 +461,28 @@ def main():
             comm.barrier()
         lib.ss_device_synchronize()
 
+    # Per-kernel HIP events INSIDE the timed region (sequential mode: ss_batch_timing_enable records an event pair around every
+    # kernel on the batch's own stream into a ring of 32 passes' event sets — no host synchronisation between passes, the ring
+    # is read behind the fence; a K beyond the ring collects every 32 passes).  roofline.achieved is the spectrum kernel's
+    # average duration over exactly these K steps.  (Overlap modes: a per-kernel time would not describe either of two kernels
+    # sharing the chip — there the kernels are timed in a separate sequential pass further down.)
+    timed_in_region = ov_mode == 0
     for _ in range(args.warmup):
         step()
     fence()
+    region0 = None
+    if timed_in_region:
+        b.timing_enable(True)
+        region0 = [b.timing_read(k) for k in range(L.SS_KERNEL_COUNT)]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    region = None
+    if timed_in_region:
+        region = [tuple(a - b0 for a, b0 in zip(b.timing_read(k), region0[k])) for k in range(L.SS_KERNEL_COUNT)]
+        b.timing_enable(False)
     if comm is not None:
         dt = float(comm.allreduce_max_f64(np.array([dt]))[0])
     b.sync()
@@ -542,23 +556,27 @@ def main():
                     "what": "the same timed step with SS_TP_ARITH_F16X3 (opt-in, not the headline); errors of the 4x true peak of the "
                             "timed batch against an f64 polyphase convolution with the crate's f32 taps (numpy)"}
 
-    # per-kernel times: a separate SEQUENTIAL pass (with two kernels sharing the chip a per-kernel HIP-event time
+    # per-kernel times of an overlap mode: a separate SEQUENTIAL pass (with two kernels sharing the chip a per-kernel HIP-event time
     # would not describe either of them); HIP events on the batch's own stream
-    b.timing_enable(True)
-    for _ in range(max(3, min(args.steps, 10))):
-        b.run(); b.sync()
+    if region is None:
+        b.timing_enable(True)
+        region0 = [b.timing_read(k) for k in range(L.SS_KERNEL_COUNT)]
+        for _ in range(max(3, min(args.steps, 10))):
+            b.run(); b.sync()
+        region = [tuple(a - b0 for a, b0 in zip(b.timing_read(k), region0[k])) for k in range(L.SS_KERNEL_COUNT)]
+        b.timing_enable(False)
     if comm is not None:
         comm.barrier()
 
     if rank == 0:
         # dominant kernel: the spectrum kernel.  Algorithmic bytes per launch:
         # every input f32 once + every retained bin once = 4 B/sample + 4*W*2*nbins per stream.
-        fft_ms, fft_n_launch = b.timing_read(L.SS_KERNEL_FFT)
+        fft_ms, fft_n_launch = region[L.SS_KERNEL_FFT]
         alg_bytes = count * (frames * 2 * 4 + lay.n_windows * lay.fft_channels * lay.n_bins * 4)
         achieved = alg_bytes / (fft_ms / max(fft_n_launch, 1) * 1e-3) / 1e9 if fft_ms > 0 else None
         kernels = {}
         for k in range(L.SS_KERNEL_COUNT):
-            ms, n = b.timing_read(k)
+            ms, n = region[k]
             kernels[lib.ss_batch_kernel_name(b._h, k).decode()] = round(ms / max(n, 1), 4)
         seq_ms = sum(kernels.values())
         traffic, traffic_src = None, None
@@ -569,7 +587,7 @@ def main():
                 traffic_src = "profiles/fft_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run)"
             except Exception:
                 traffic = None
-        td_ms, td_n = b.timing_read(L.SS_KERNEL_TIME_DOMAIN)
+        td_ms, td_n = region[L.SS_KERNEL_TIME_DOMAIN]
         td = {"kernel": lib.ss_batch_kernel_name(b._h, L.SS_KERNEL_TIME_DOMAIN).decode(),
               "algorithmic_bytes_per_launch": count * frames * 2 * 4}
         if td_ms > 0:
@@ -608,7 +626,8 @@ def main():
                                     "waveform_fused": geo.waveform_fused},
                        "sustained": sustained,
                        "corpus_integrated_lufs": corpus_i, "corpus_lra": corpus_lra,
-                       "kernel_ms": kernels, "kernel_ms_note": "separate sequential pass, HIP events on the batch's stream",
+                       "kernel_ms": kernels, "kernel_ms_note": ("HIP events on the batch's stream around every kernel of the K timed steps themselves (ring of event sets, no host "
+                                                              "synchronisation inside the region)" if timed_in_region else "separate sequential pass, HIP events on the batch's stream"),
                        "sequential_gpu_ms": round(seq_ms, 4),
                        "step_hbm_frac": step_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                        "time_domain_kernel": td},

@@ -484,7 +484,11 @@ void ss_waveform_view(double playhead_ms, double waveform_window_s, size_t chart
                       double *x_min, double *x_max);
 
 /* kernel timing with HIP events on the batch's own stream (for roofline
- * reporting): enable, run N passes, then read accumulated per-kernel time. */
+ * reporting): enable, run N passes, then read accumulated per-kernel time.
+ * Timed passes queue back to back: the event pairs go into a ring of 32 passes'
+ * sets and are read (one stream synchronisation) by ss_batch_timing_read /
+ * ss_batch_sync / ss_batch_timing_enable — or by ss_batch_run itself when 32 passes
+ * are pending — so a timed region of K passes measures its own kernels. */
 enum { SS_KERNEL_FFT = 0, SS_KERNEL_TIME_DOMAIN = 1, SS_KERNEL_FINALIZE = 2, SS_KERNEL_WAVEFORM = 3, SS_KERNEL_COUNT = 4 };
 int ss_batch_timing_enable(ss_batch *b, int enable);
 int ss_batch_timing_read(ss_batch *b, int kernel, double *total_ms, uint64_t *launches);

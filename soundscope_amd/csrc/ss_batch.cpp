@@ -64,11 +64,15 @@ struct ss_batch {
     int tp_arith = SS_TP_ARITH_F32;   // SS_TP_ARITH_*: the reference's width unless the caller opts into the f16 split
     int overlap = 0;                  // 0 sequential, 1 the spectrum kernel beside the time-domain chain, 2 beside its tail only
     bool timing = false;
-    hipEvent_t ev[2 * SS_KERNEL_COUNT] = {};
+    // per-kernel event timing: a ring of kTimingDepth passes' event sets, so that timed passes queue back to back without a host
+    // synchronisation between them (bench.py times its kernels INSIDE the timed region); collected when read, or when the ring is full
+    static constexpr int kTimingDepth = 32;
+    hipEvent_t ev[kTimingDepth * 2 * SS_KERNEL_COUNT] = {};
+    uint32_t ev_mask[kTimingDepth] = {};       // which of a pass's events were recorded
+    uint32_t ev_head = 0, ev_count = 0;        // next slot to record into; passes recorded and not yet collected
     bool ev_ready = false;
     double t_ms[SS_KERNEL_COUNT] = {0, 0, 0, 0};
     uint64_t t_n[SS_KERNEL_COUNT] = {0, 0, 0, 0};
-    bool pending_events = false;
 };
 
 namespace ssi {
@@ -90,14 +94,20 @@ uint32_t spectrum_column_of(double chart_x, uint32_t cols)
 
 int batch_collect_timing(ss_batch *b)
 {
-    if (!b->pending_events) return SS_OK;
+    if (!b->ev_count) return SS_OK;
     HIPCHK(hipStreamSynchronize(b->stream));
-    for (int k = 0; k < SS_KERNEL_COUNT; k++) {
-        float ms = 0.f;
-        hipError_t e = hipEventElapsedTime(&ms, b->ev[2 * k], b->ev[2 * k + 1]);
-        if (e == hipSuccess) { b->t_ms[k] += ms; b->t_n[k]++; }
+    constexpr uint32_t D = ss_batch::kTimingDepth;
+    for (uint32_t i = 0; i < b->ev_count; i++) {
+        const uint32_t slot = (b->ev_head + D - b->ev_count + i) % D;
+        hipEvent_t *ev = b->ev + (size_t)slot * 2 * SS_KERNEL_COUNT;
+        for (int k = 0; k < SS_KERNEL_COUNT; k++) {
+            if ((b->ev_mask[slot] >> (2 * k) & 3u) != 3u) continue;       // this pass did not run kernel k
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]) == hipSuccess) { b->t_ms[k] += ms; b->t_n[k]++; }
+        }
+        b->ev_mask[slot] = 0;
     }
-    b->pending_events = false;
+    b->ev_count = 0;
     return SS_OK;
 }
 
@@ -572,14 +582,19 @@ int ss_batch_run(ss_batch *b)
 {
     SS_ON_DEVICE(b);
     if (!b) return SS_ERR_INVALID_ARG;
-    int rc = batch_collect_timing(b);
+    int rc = (b->ev_count >= (uint32_t)ss_batch::kTimingDepth || !b->timing) ? batch_collect_timing(b) : SS_OK;     // (a full ring: collect first)
     if (rc) return rc;
     b->corpus_reduced = false;
     const ss_batch_config &c = b->cfg;
     const ss_batch_layout &L = b->lay;
     const uint32_t C = c.channels;
     const bool tm = b->timing;
-    auto rec = [&](int idx) -> hipError_t { return tm ? hipEventRecord(b->ev[idx], b->stream) : hipSuccess; };
+    const uint32_t ev_slot = b->ev_head;
+    auto rec = [&](int idx) -> hipError_t {
+        if (!tm) return hipSuccess;
+        b->ev_mask[ev_slot] |= 1u << idx;
+        return hipEventRecord(b->ev[(size_t)ev_slot * 2 * SS_KERNEL_COUNT + idx], b->stream);
+    };
 
     // overlap mode: fork — the spectrum kernel goes to stream2 after everything already queued on the main stream
     // (uploads, the previous pass), the time-domain chain stays on the main stream, join at the end.  Per-kernel
@@ -726,7 +741,7 @@ int ss_batch_run(ss_batch *b)
         HIPCHK(hipEventRecord(b->ev_join, b->stream2));
         HIPCHK(hipStreamWaitEvent(b->stream, b->ev_join, 0));
     }
-    b->pending_events = tm;
+    if (tm) { b->ev_head = (b->ev_head + 1u) % (uint32_t)ss_batch::kTimingDepth; b->ev_count++; }
     return SS_OK;
 }
 
