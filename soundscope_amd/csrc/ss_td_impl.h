@@ -116,8 +116,9 @@ typedef float v2f_td __attribute__((ext_vector_type(2)));
 // three interleaved chains of twelve packed operations (a multiply, eleven FMAs) in ONE asm statement — between separate statements
 // the compiler keeps a wait state for hazards it cannot rule out for inline asm (an s_nop per three instructions).  Operands:
 // %0..%2 the three results (frames n, n + 1, n + 2), %3..%16 the window's fourteen frames (n - 11 .. n + 2), %17..%22 the taps as
-// six SGPR pairs (c[2 m], c[2 m + 1]), broadcast through op_sel.
-#define SS_TP_VALU_PHASE3(o0, o1, o2, W, g, tc)                                                                          \
+// six register pairs (c[2 m], c[2 m + 1]), broadcast through op_sel — SGPR pairs where the taps are the wave's, VGPR pairs where
+// neighbouring lanes run different halves of a longer branch (factor 2).
+#define SS_TP_VALU_PHASE3_(CK, o0, o1, o2, W, g, tc)                                                                        \
     asm("v_pk_mul_f32 %0, %17, %14 op_sel:[0,0] op_sel_hi:[0,1]\n\t" \
         "v_pk_mul_f32 %1, %17, %15 op_sel:[0,0] op_sel_hi:[0,1]\n\t" \
         "v_pk_mul_f32 %2, %17, %16 op_sel:[0,0] op_sel_hi:[0,1]\n\t" \
@@ -158,7 +159,9 @@ typedef float v2f_td __attribute__((ext_vector_type(2)));
         : "v"(W[3 * (g) + 0]), "v"(W[3 * (g) + 1]), "v"(W[3 * (g) + 2]), "v"(W[3 * (g) + 3]), "v"(W[3 * (g) + 4]),       \
           "v"(W[3 * (g) + 5]), "v"(W[3 * (g) + 6]), "v"(W[3 * (g) + 7]), "v"(W[3 * (g) + 8]), "v"(W[3 * (g) + 9]),       \
           "v"(W[3 * (g) + 10]), "v"(W[3 * (g) + 11]), "v"(W[3 * (g) + 12]), "v"(W[3 * (g) + 13]),                        \
-          "s"(tc[0]), "s"(tc[1]), "s"(tc[2]), "s"(tc[3]), "s"(tc[4]), "s"(tc[5]))
+          CK(tc[0]), CK(tc[1]), CK(tc[2]), CK(tc[3]), CK(tc[4]), CK(tc[5]))
+#define SS_TP_VALU_PHASE3(o0, o1, o2, W, g, tc) SS_TP_VALU_PHASE3_("s", o0, o1, o2, W, g, tc)       /* taps wave-uniform: SGPR pairs */
+#define SS_TP_VALU_PHASE3V(o0, o1, o2, W, g, tc) SS_TP_VALU_PHASE3_("v", o0, o1, o2, W, g, tc)      /* taps per lane: VGPR pairs */
 
 template <int FACTOR>
 struct TpCfg {

@@ -1,6 +1,7 @@
 """The two forms k_time_domain got in round 6, at their edges, through the C ABI against the oracle:
 
-* the 4x true peak on the packed-f32 VALU (2 / 6 / 8 channels): a lane takes fifteen frames of one channel pair, so the tile lengths
+* the 4x (and, in the three-waves register builds, the 2x) true peak on the packed-f32 VALU (2 / 6 / 8 channels): a lane takes fifteen
+  frames of one channel pair (at factor 2: two neighbouring lanes, a half of the 24-tap branch each), so the tile lengths
   that are no multiple of fifteen (the last lane takes the tile's last fifteen frames again), tiles shorter than fifteen frames (the
   crate's own loop) and streaming calls of every small size are the cases;
 * the min-max decimation with ANY samples per bin (44.1 kHz material, odd lengths), read as the aligned 16-byte pieces that overlap
@@ -31,14 +32,15 @@ def _signal(seed, frames, channels, rate):
 
 
 @pytest.mark.parametrize("rate,channels", [(48000, 2), (44100, 2), (8000, 2), (32000, 2), (22050, 2), (11025, 2), (48000, 6), (44100, 6),
-                                           (8000, 6), (48000, 8), (32000, 8), (22050, 8)])
+                                           (8000, 6), (48000, 8), (32000, 8), (22050, 8),
+                                           (96000, 2), (96000, 6), (96000, 8), (176400, 2), (128000, 6)])      # factor 2: the branch's halves on lane pairs
 def test_packed_true_peak_tile_lengths(oracle, rate, channels):
     """Batches whose 100 ms sub-blocks cut into tiles of every length class: 960 and 1470 frames (multiples of fifteen), 800, 1103,
     2205 ... (not), over three streams of a length that leaves a short last tile.  Every channel's true and sample peak, the loudness."""
     frames = int(rate * 2.5) + 7                                   # the last tile of a stream is seven frames long (the crate's loop)
     xs = [_signal(40 + i, frames, channels, rate) for i in range(3)]
     b = ssa.Batch(rate, channels, 3, frames, 4096, 1024, flags=L.SS_BATCH_LUFS | L.SS_BATCH_TRUE_PEAK | L.SS_BATCH_WAVEFORM)
-    assert b.geometry.td_true_peak_factor == 4 and b.true_peak_arith == L.SS_TP_ARITH_F32
+    assert b.geometry.td_true_peak_factor == (4 if rate < 96000 else 2) and b.true_peak_arith == L.SS_TP_ARITH_F32
     b.upload(0, np.concatenate(xs)); b.run(); b.sync()
     res = b.results()
     for i, x in enumerate(xs):
@@ -52,12 +54,12 @@ def test_packed_true_peak_tile_lengths(oracle, rate, channels):
         assert abs(res[i].integrated_lufs - m.integrated()) <= 0.01, i
 
 
+@pytest.mark.parametrize("rate", [48000, 96000])
 @pytest.mark.parametrize("channels", [2, 6, 8])
-def test_packed_true_peak_streaming_call_sizes(oracle, channels):
+def test_packed_true_peak_streaming_call_sizes(oracle, channels, rate):
     """The handle's add_samples in calls of 1 ... 20 frames (tiles under fifteen frames: the crate's loop; fifteen and up: one lane
     of the packed form reading its history from the carried frames), then a few hundred, then a tick-sized call: the peak of a
-    click moves through every position of a lane's window."""
-    rate = 48000
+    click moves through every position of a lane's window.  96 kHz: factor 2, a lane pair per fifteen frames."""
     frames = 3 * rate // 2
     x = _signal(70 + channels, frames, channels, rate)
     an = ssa.Analyzer(); an.create_loudness_meter(channels, rate)

@@ -18,12 +18,15 @@ SHAPES = [  # label, rate, channels, streams, frames
     ("48 kHz 5.1 x 512 x 10 s", 48000, 6, 512, 480000),
     ("44.1 kHz 5.1 x 512 x 10 s", 44100, 6, 512, 441000),
     ("96 kHz 8 ch x 64 x 10 s, 4x (config 5)", 96000, 8, 64, 960000),
+    ("96 kHz 8 ch x 64 x 10 s, the crate's 2x", 96000, 8, 64, 960000),
+    ("96 kHz stereo x 1024 x 5 s", 96000, 2, 1024, 480000),
+    ("96 kHz 5.1 x 128 x 10 s", 96000, 6, 128, 960000),
     ("48 kHz mono x 2048 x 10 s", 48000, 1, 2048, 480000),
     ("44.1 kHz mono x 2048 x 10 s", 44100, 1, 2048, 441000),
 ]
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 for label, rate, ch, ns, frames in SHAPES:
-    tpf = 4 if (rate, ch) == (96000, 8) else 0
+    tpf = 4 if "4x" in label else 0
     b = ssa.Batch(rate, ch, ns, frames, 4096, 1024, flags=L.SS_BATCH_ALL & ~L.SS_BATCH_FFT, true_peak_factor=tpf)
     b.synthesize(7, 0)
     for _ in range(2):
