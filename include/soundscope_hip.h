@@ -359,9 +359,12 @@ int ss_batch_set_time_domain_mode(ss_batch *b, int mode);
 int ss_batch_set_overlap(ss_batch *b, int mode);
 /* arithmetic of the 4x true-peak interpolator in batches (the Analyzer handle and the sessions: ss_analyzer_set_true_peak_arith, same default):
  *   SS_TP_ARITH_F32 (default)    an f32 fmaf chain per output, the width of ebur128's interpolator (its 12 products per phase
- *                                summed in f32; analyzer.rs:139-141,159-164).  Factor 4 with 2, 6 or 8 channels: on the packed-f32
- *                                VALU (v_pk_fma_f32; a frame's pair of adjacent channels is one packed operand, round 6);
- *                                other channel counts and factor 2: v_mfma_f32_16x16x4_f32 as a banded-Toeplitz product;
+ *                                summed in f32; analyzer.rs:139-141,159-164).  2, 6 or 8 channels: on the packed-f32 VALU
+ *                                (v_pk_fma_f32; a frame's pair of adjacent channels is one packed operand, round 6; at factor 2
+ *                                the 24-tap branch's halves on neighbouring lanes — in the four-waves register builds with plain
+ *                                v_fma_f32 instead); channel counts that do not divide 16 (3, 5, 7 ...): plain v_fma_f32, a lane
+ *                                per channel; mono, 4 and 16 channels: v_mfma_f32_16x16x4_f32 as a banded-Toeplitz product
+ *                                (measured the faster form there);
  *   SS_TP_ARITH_F16X3 (opt-in)   three-term f16 split on the matrix cores with f32 accumulation, scaled per tile by a
  *                                power of two from the tile's own peak: within 2^-21 of the tile peak of the f32 result
  *                                (measured 2.0e-7 relative on the bench corpus against 1.1e-7 for the f32 product; north_star's

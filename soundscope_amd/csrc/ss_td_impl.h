@@ -163,6 +163,97 @@ typedef float v2f_td __attribute__((ext_vector_type(2)));
 #define SS_TP_VALU_PHASE3(o0, o1, o2, W, g, tc) SS_TP_VALU_PHASE3_("s", o0, o1, o2, W, g, tc)       /* taps wave-uniform: SGPR pairs */
 #define SS_TP_VALU_PHASE3V(o0, o1, o2, W, g, tc) SS_TP_VALU_PHASE3_("v", o0, o1, o2, W, g, tc)      /* taps per lane: VGPR pairs */
 
+// The same over ONE channel with plain f32 FMAs (any channel count: a lane takes fifteen frames of one channel; on gfx950 a wave's
+// v_fma_f32 issues in 2.8 cycles against 5.2 for v_pk_fma_f32, so per MAC this is within a tenth of the packed form): twelve taps
+// (SGPRs, %17..%28) over three frames, window %3..%16 as above.  _ACC adds twelve further taps onto the results (factor 2: the
+// branch's second half over the window twelve frames further back).
+#define SS_TP_VALU_PLAIN3(o0, o1, o2, W, g, tc)                                                                          \
+    asm("v_mul_f32 %0, %17, %14\n\t" \
+        "v_mul_f32 %1, %17, %15\n\t" \
+        "v_mul_f32 %2, %17, %16\n\t" \
+        "v_fma_f32 %0, %18, %13, %0\n\t" \
+        "v_fma_f32 %1, %18, %14, %1\n\t" \
+        "v_fma_f32 %2, %18, %15, %2\n\t" \
+        "v_fma_f32 %0, %19, %12, %0\n\t" \
+        "v_fma_f32 %1, %19, %13, %1\n\t" \
+        "v_fma_f32 %2, %19, %14, %2\n\t" \
+        "v_fma_f32 %0, %20, %11, %0\n\t" \
+        "v_fma_f32 %1, %20, %12, %1\n\t" \
+        "v_fma_f32 %2, %20, %13, %2\n\t" \
+        "v_fma_f32 %0, %21, %10, %0\n\t" \
+        "v_fma_f32 %1, %21, %11, %1\n\t" \
+        "v_fma_f32 %2, %21, %12, %2\n\t" \
+        "v_fma_f32 %0, %22, %9, %0\n\t" \
+        "v_fma_f32 %1, %22, %10, %1\n\t" \
+        "v_fma_f32 %2, %22, %11, %2\n\t" \
+        "v_fma_f32 %0, %23, %8, %0\n\t" \
+        "v_fma_f32 %1, %23, %9, %1\n\t" \
+        "v_fma_f32 %2, %23, %10, %2\n\t" \
+        "v_fma_f32 %0, %24, %7, %0\n\t" \
+        "v_fma_f32 %1, %24, %8, %1\n\t" \
+        "v_fma_f32 %2, %24, %9, %2\n\t" \
+        "v_fma_f32 %0, %25, %6, %0\n\t" \
+        "v_fma_f32 %1, %25, %7, %1\n\t" \
+        "v_fma_f32 %2, %25, %8, %2\n\t" \
+        "v_fma_f32 %0, %26, %5, %0\n\t" \
+        "v_fma_f32 %1, %26, %6, %1\n\t" \
+        "v_fma_f32 %2, %26, %7, %2\n\t" \
+        "v_fma_f32 %0, %27, %4, %0\n\t" \
+        "v_fma_f32 %1, %27, %5, %1\n\t" \
+        "v_fma_f32 %2, %27, %6, %2\n\t" \
+        "v_fma_f32 %0, %28, %3, %0\n\t" \
+        "v_fma_f32 %1, %28, %4, %1\n\t" \
+        "v_fma_f32 %2, %28, %5, %2"                                                                                                           \
+        : "=&v"(o0), "=&v"(o1), "=&v"(o2)                                                                                \
+        : "v"((W)[3 * (g) + 0]), "v"((W)[3 * (g) + 1]), "v"((W)[3 * (g) + 2]), "v"((W)[3 * (g) + 3]), "v"((W)[3 * (g) + 4]),       \
+          "v"((W)[3 * (g) + 5]), "v"((W)[3 * (g) + 6]), "v"((W)[3 * (g) + 7]), "v"((W)[3 * (g) + 8]), "v"((W)[3 * (g) + 9]),       \
+          "v"((W)[3 * (g) + 10]), "v"((W)[3 * (g) + 11]), "v"((W)[3 * (g) + 12]), "v"((W)[3 * (g) + 13]),                        \
+          "s"((tc)[0]), "s"((tc)[1]), "s"((tc)[2]), "s"((tc)[3]), "s"((tc)[4]), "s"((tc)[5]),                                    \
+          "s"((tc)[6]), "s"((tc)[7]), "s"((tc)[8]), "s"((tc)[9]), "s"((tc)[10]), "s"((tc)[11]))
+#define SS_TP_VALU_PLAIN3_ACC(o0, o1, o2, W, g, tc)                                                                          \
+    asm("v_fma_f32 %0, %17, %14, %0\n\t" \
+        "v_fma_f32 %1, %17, %15, %1\n\t" \
+        "v_fma_f32 %2, %17, %16, %2\n\t" \
+        "v_fma_f32 %0, %18, %13, %0\n\t" \
+        "v_fma_f32 %1, %18, %14, %1\n\t" \
+        "v_fma_f32 %2, %18, %15, %2\n\t" \
+        "v_fma_f32 %0, %19, %12, %0\n\t" \
+        "v_fma_f32 %1, %19, %13, %1\n\t" \
+        "v_fma_f32 %2, %19, %14, %2\n\t" \
+        "v_fma_f32 %0, %20, %11, %0\n\t" \
+        "v_fma_f32 %1, %20, %12, %1\n\t" \
+        "v_fma_f32 %2, %20, %13, %2\n\t" \
+        "v_fma_f32 %0, %21, %10, %0\n\t" \
+        "v_fma_f32 %1, %21, %11, %1\n\t" \
+        "v_fma_f32 %2, %21, %12, %2\n\t" \
+        "v_fma_f32 %0, %22, %9, %0\n\t" \
+        "v_fma_f32 %1, %22, %10, %1\n\t" \
+        "v_fma_f32 %2, %22, %11, %2\n\t" \
+        "v_fma_f32 %0, %23, %8, %0\n\t" \
+        "v_fma_f32 %1, %23, %9, %1\n\t" \
+        "v_fma_f32 %2, %23, %10, %2\n\t" \
+        "v_fma_f32 %0, %24, %7, %0\n\t" \
+        "v_fma_f32 %1, %24, %8, %1\n\t" \
+        "v_fma_f32 %2, %24, %9, %2\n\t" \
+        "v_fma_f32 %0, %25, %6, %0\n\t" \
+        "v_fma_f32 %1, %25, %7, %1\n\t" \
+        "v_fma_f32 %2, %25, %8, %2\n\t" \
+        "v_fma_f32 %0, %26, %5, %0\n\t" \
+        "v_fma_f32 %1, %26, %6, %1\n\t" \
+        "v_fma_f32 %2, %26, %7, %2\n\t" \
+        "v_fma_f32 %0, %27, %4, %0\n\t" \
+        "v_fma_f32 %1, %27, %5, %1\n\t" \
+        "v_fma_f32 %2, %27, %6, %2\n\t" \
+        "v_fma_f32 %0, %28, %3, %0\n\t" \
+        "v_fma_f32 %1, %28, %4, %1\n\t" \
+        "v_fma_f32 %2, %28, %5, %2"                                                                                                           \
+        : "+v"(o0), "+v"(o1), "+v"(o2)                                                                                \
+        : "v"((W)[3 * (g) + 0]), "v"((W)[3 * (g) + 1]), "v"((W)[3 * (g) + 2]), "v"((W)[3 * (g) + 3]), "v"((W)[3 * (g) + 4]),       \
+          "v"((W)[3 * (g) + 5]), "v"((W)[3 * (g) + 6]), "v"((W)[3 * (g) + 7]), "v"((W)[3 * (g) + 8]), "v"((W)[3 * (g) + 9]),       \
+          "v"((W)[3 * (g) + 10]), "v"((W)[3 * (g) + 11]), "v"((W)[3 * (g) + 12]), "v"((W)[3 * (g) + 13]),                        \
+          "s"((tc)[0]), "s"((tc)[1]), "s"((tc)[2]), "s"((tc)[3]), "s"((tc)[4]), "s"((tc)[5]),                                    \
+          "s"((tc)[6]), "s"((tc)[7]), "s"((tc)[8]), "s"((tc)[9]), "s"((tc)[10]), "s"((tc)[11]))
+
 template <int FACTOR>
 struct TpCfg {
     static constexpr int HIST = (FACTOR == 2) ? 24 : 12;     // taps per polyphase branch
@@ -175,6 +266,7 @@ struct TpCfg {
 // (the matrix pointer is in the CONSTANT address space: the tables are written once by the host before any launch, and a
 // uniform constant-space address makes the sixteen loads scalar (s_load into SGPRs, K$) instead of per-lane flat loads)
 typedef const __attribute__((address_space(4))) double *const_f64_ptr;
+typedef const __attribute__((address_space(4))) float *const_f32_ptr;
 __device__ __forceinline__ void mat4_apply_add(const_f64_ptr M, const double (&x)[4], double (&z)[4])
 {
 #pragma unroll

@@ -40,7 +40,7 @@ def make_multich(seed, frames, channels, rate=48000, level=0.4):
     return x.reshape(-1)
 
 
-def db_close(got, ref, tol_db=0.01, rel_floor_db=70.0, survey=False):
+def db_close(got, ref, tol_db=0.01, rel_floor_db=70.0, survey=False, peak=None, pink=None):
     """Spectrum parity metric for ONE window row, relative to the row's OWN loudest bin — an f32 transform's error is
     scale-invariant, so an absolute floor would loosen the bar with level:
       bins within `rel_floor_db` (70 dB) of the row's loudest bin:  |got - ref| <= tol_db (0.01 dB);
@@ -49,14 +49,19 @@ def db_close(got, ref, tol_db=0.01, rel_floor_db=70.0, survey=False):
     Every row is held to its own peak: the rows of the packed kernels carry their own block exponent.
     `survey=True` ALSO asserts SURVEY section 7's wording of the bar — 0.01 dB wherever ref >= -90 dBFS, 1e-4 of the row's
     largest amplitude below — which is the stricter one for loud rows (it reaches 80-90 dB under a near-full-scale peak, into
-    the rounding noise of any f32 transform) and the looser one for quiet rows; the corpus tests assert both."""
+    the rounding noise of any f32 transform) and the looser one for quiet rows; the corpus tests assert both.
+    `peak` + `pink` (the randomised tools' second look at a row that missed): a window whose strongest component lies OUTSIDE the
+    retained band (a DC offset, rumble under 20 Hz: bins 0 ... 6 of N = 16384 are not part of the row) has its transform's rounding
+    noise set by THAT component, in the reference's f32 FFT as in any other.  With `pink` (the per-bin compensation the row
+    carries) the levels are taken without it and the 70 dB are counted from `peak` = window_peak_db() if that is the larger."""
     got = np.asarray(got, np.float64)
     ref = np.asarray(ref, np.float64)
     assert got.shape == ref.shape and got.ndim == 1, (got.shape, ref.shape)
-    peak = float(ref.max())
-    strong = ref >= peak - rel_floor_db
+    gl, rl = (got, ref) if pink is None else (got - pink, ref - pink)
+    pk = float(rl.max()) if peak is None else max(float(peak), float(rl.max()))
+    strong = rl >= pk - rel_floor_db
     ok_strong = np.abs(got[strong] - ref[strong]) <= tol_db
-    lin_err = np.abs(10 ** ((got[~strong] - peak) / 20) - 10 ** ((ref[~strong] - peak) / 20))      # in units of the peak amplitude
+    lin_err = np.abs(10 ** ((gl[~strong] - pk) / 20) - 10 ** ((rl[~strong] - pk) / 20))      # in units of the peak amplitude
     ok_weak = lin_err <= 1e-4
     ok = bool(ok_strong.all() and ok_weak.all())
     if survey:
@@ -73,6 +78,14 @@ def db_close_survey(got, ref, tol_db=0.01):
     ok_loud = np.abs(got[loud] - ref[loud]) <= tol_db
     lin_err = np.abs(10 ** ((got[~loud] - peak) / 20) - 10 ** ((ref[~loud] - peak) / 20))
     return bool(ok_loud.all() and (lin_err <= 1e-4).all())
+
+
+def window_peak_db(oracle, s):
+    """Level of the strongest component of a window over ALL its bins, retained or not (the reference's scale: 20 log10(|X| 4 / N),
+    no pink term): what an f32 transform's rounding noise is relative to."""
+    hw = oracle.hann_window(s).astype(np.float64)
+    mag = np.abs(np.fft.rfft(hw)).max()
+    return float(20 * np.log10(mag * 4 / hw.size)) if mag > 0 else -150.0
 
 
 def f64_spectrum_row(oracle, rate, s, fft_n):

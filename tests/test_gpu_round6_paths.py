@@ -4,6 +4,8 @@
   frames of one channel pair (at factor 2: two neighbouring lanes, a half of the 24-tap branch each), so the tile lengths
   that are no multiple of fifteen (the last lane takes the tile's last fifteen frames again), tiles shorter than fifteen frames (the
   crate's own loop) and streaming calls of every small size are the cases;
+* the same with plain v_fma_f32 over ONE channel per lane, for the channel counts that do not divide sixteen (3, 5, 7, 12 ...) and for
+  factor 2 in the four-waves register builds;
 * the min-max decimation with ANY samples per bin (44.1 kHz material, odd lengths), read as the aligned 16-byte pieces that overlap
   a bin with the edge pieces masked: bins starting and ending at every alignment, the shortest bins the fused path takes (16
   samples) and the longest (1000), special values sitting exactly on bin edges.
@@ -33,7 +35,9 @@ def _signal(seed, frames, channels, rate):
 
 @pytest.mark.parametrize("rate,channels", [(48000, 2), (44100, 2), (8000, 2), (32000, 2), (22050, 2), (11025, 2), (48000, 6), (44100, 6),
                                            (8000, 6), (48000, 8), (32000, 8), (22050, 8),
-                                           (96000, 2), (96000, 6), (96000, 8), (176400, 2), (128000, 6)])      # factor 2: the branch's halves on lane pairs
+                                           (96000, 2), (96000, 6), (96000, 8), (176400, 2), (128000, 6),       # factor 2: the branch's halves on lane pairs
+                                           (48000, 3), (44100, 5), (8000, 7), (96000, 3), (48000, 12),        # plain-FMA form: counts that do not divide 16
+                                           (48000, 4), (48000, 1), (96000, 4)])                               # ... and the ones that stay on the matrix pipe
 def test_packed_true_peak_tile_lengths(oracle, rate, channels):
     """Batches whose 100 ms sub-blocks cut into tiles of every length class: 960 and 1470 frames (multiples of fifteen), 800, 1103,
     2205 ... (not), over three streams of a length that leaves a short last tile.  Every channel's true and sample peak, the loudness."""
@@ -55,7 +59,7 @@ def test_packed_true_peak_tile_lengths(oracle, rate, channels):
 
 
 @pytest.mark.parametrize("rate", [48000, 96000])
-@pytest.mark.parametrize("channels", [2, 6, 8])
+@pytest.mark.parametrize("channels", [2, 6, 8, 3, 5])
 def test_packed_true_peak_streaming_call_sizes(oracle, channels, rate):
     """The handle's add_samples in calls of 1 ... 20 frames (tiles under fifteen frames: the crate's loop; fifteen and up: one lane
     of the packed form reading its history from the carried frames), then a few hundred, then a tick-sized call: the peak of a

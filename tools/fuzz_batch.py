@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import soundscope_amd as ssa
 from soundscope_amd import _lib as L
 from oracle import pyoracle as po
-from conftest import db_close, db_report, make_multich
+from conftest import db_close, db_report, make_multich, window_peak_db
 
 RATES = [8000, 22050, 32000, 44100, 48000, 48000, 48000, 88200, 96000, 96000, 192000]
 CHANNELS = [1, 2, 2, 2, 2, 3, 6, 8, 8]
@@ -22,6 +22,16 @@ def lufs_close(a, b, tol=0.01):
     if np.isinf(a) or np.isinf(b) or np.isnan(a) or np.isnan(b):
         return a == b or (np.isnan(a) and np.isnan(b))
     return abs(a - b) <= tol
+
+
+_pink = {}
+def pink_of(rate, n):
+    """the pink-noise compensation the retained bins of (rate, n) carry: 10 log10(f / 1000), f as the reference computes it (f32)"""
+    if (rate, n) not in _pink:
+        cnt, first = po.fft_bins(rate, n)
+        f = (np.arange(cnt) + first) * (np.float32(rate) / np.float32(n))
+        _pink[(rate, n)] = 10 * np.log10(f.astype(np.float64) / 1000.0)
+    return _pink[(rate, n)]
 
 
 def plan(seed):
@@ -159,7 +169,10 @@ def programme(seed):
                         except po.OracleError: continue                 # (a non-finite sample inside the window: the crate refuses it)
                         # (0.015 dB here, 0.01 in the committed tests: at the metric's edge, 70 dB under the row's peak, the difference of two
                         # f32 transforms' rounding noise is 0.004 dB typical — over thousands of random rows the tail reaches 0.011, seed 102143)
-                        if not db_close(fft[wdx, c], ref, 0.015): bad(f"pass {pass_no} stream {i} window {wdx} ch {c}: spectrum row differs {db_report(fft[wdx, c], ref)} row peak {float(ref.max()):.1f} dB")
+                        # (a row that misses is looked at again with the 70 dB counted from the window's strongest component over ALL bins:
+                        # a DC offset 20 dB above the retained band's peak — bins 0 ... 6 of N = 16384 are not in the row — sets the
+                        # rounding noise of any f32 transform of that window; seed 620369: 0.021 dB at bins 86 dB under the DC term)
+                        if not db_close(fft[wdx, c], ref, 0.015) and not db_close(fft[wdx, c], ref, 0.015, peak=window_peak_db(po, sig[c][start:start + fft_n]), pink=pink_of(rate, fft_n)): bad(f"pass {pass_no} stream {i} window {wdx} ch {c}: spectrum row differs {db_report(fft[wdx, c], ref)} row peak {float(ref.max()):.1f} dB")
     g = b.geometry
     b.close()
     return ok, what + f" [segments {g.td_segments} x {g.td_segment_subblocks}, split {g.td_split}, fixup {g.td_fixup_subblocks}]" + ("" if ok else " -> " + "; ".join(notes[:6]))
