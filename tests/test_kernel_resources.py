@@ -21,15 +21,13 @@ HIPCC = "/opt/rocm/bin/hipcc"
 SOURCES = ["ss_td_f4.hip", "ss_td_f2.hip", "ss_td_f0.hip", "ss_fft.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"]       # the Makefile's CXXFLAGS
 
-# Instantiations that may spill, with the most bytes per lane they may use (11 of 138 do at the end of round 6; 27 of 150 did in round
+# Instantiations that may spill, with the most bytes per lane they may use (10 of 138 do at the end of round 6; 27 of 150 did in round
 # 5).  All of them are register builds for FOUR waves per SIMD (128 VGPRs) of forms whose three-waves build (168 VGPRs) is spill-free;
 # the launcher takes the four-waves build only for grids of more than 768 workgroups, where it still beats the spill-free build by
 # 10-37 % (profiles/r05_td_kernel_resources.txt).
 #   SPLIT (whole-stream workgroups, SS_TD_WHOLE_STREAMS: opt-in, 11-16 % slower than time segments at such grids anyway)
-#   CT = 0 (a channel count other than 1, 2, 6, 8 in a batch of more than 3072 waves)
 ALLOW = {
-    r"k_time_domain<[420], false, [28], [0123], 4, true, false>": 48,      # (ten of them, 8-48 B; round 5: 64)
-    r"k_time_domain<[420], false, 0, [01], 4, false, false>": 16,          # (one: factor 4 with decimation; round 5: 80)
+    r"k_time_domain<[420], false, [28], [0123], 4, true, false>": 48,      # (ten of them, 8-44 B; round 5: 64)
 }
 
 # what bench.py, the tick driver and the first shapes of an integrator launch: never a spill
