@@ -643,6 +643,7 @@ def main():
                                       if io_floor_ms else None)},
         }
         # PCIe-inclusive rate (informational, never `value`): host f32 -> HBM upload of a slice + its share of a pass
+        host = None
         try:
             k = min(count, 64)
             host = np.concatenate([b.download_input(i) for i in range(k)])
@@ -707,6 +708,25 @@ def main():
                 except Exception as ex:                                   # noqa: BLE001 — (a smaller card: the line says so)
                     cfgd["n1_strong_value"] = None
                     cfgd["n1_strong_error"] = repr(ex)
+            if host is not None and not strong:
+                # The boundary hands over HOST buffers: the same full path fed over PCIe by the pipelined runner (soundscope_amd/pipeline.py:
+                # the host corpus page-locked in place, two batches as a double buffer — chunk k + 1 uploads on the copy engine while
+                # chunk k is analysed — results read back per chunk), wall clock of the whole call, second of two calls.  Informational.
+                try:
+                    corpus_h = np.tile(host, max(1, 512 * frames * 2 // host.size))
+                    for _ in range(2):
+                        tp0 = time.perf_counter()
+                        res_p, _hist_p = ssa.analyze_corpus(corpus_h, args.rate, 2, frames, chunk_streams=128, flags=L.SS_BATCH_ALL,
+                                                            fft_n=args.fft_n, hop_frames=args.hop)
+                        dtp = time.perf_counter() - tp0
+                    cfgd["pcie_inclusive_pipelined_samples_per_s"] = corpus_h.size / dtp
+                    cfgd["pcie_inclusive_pipelined_h2d_GBps"] = corpus_h.nbytes / dtp / 1e9
+                    cfgd["pcie_inclusive_pipelined_streams"] = len(res_p)
+                    cfgd["pcie_inclusive_pipelined_what"] = ("soundscope_amd.analyze_corpus: host f32 corpus page-locked in place, chunks of 128 streams double-buffered "
+                                                             "(upload of chunk k + 1 beside the full pass of chunk k), per-chunk read-back of the results; PCIe-bound")
+                    del corpus_h, res_p
+                except Exception as ex:                               # noqa: BLE001
+                    cfgd["pcie_inclusive_pipelined_error"] = repr(ex)
             try:
                 # config 3 as BASELINE.json words it ("4096-pt FFT + LUFS"): the headline step additionally carries the
                 # 4x true peak and the decimation that north_star puts on the path
