@@ -50,14 +50,19 @@ namespace ssk {
 //      pass 2: rerun each chunk from its true initial state, accumulate y^2.
 //    L is chosen by td_chunk_frames (below): whole tiles of whole chunks first (48 kHz stereo: L = 30, a
 //    sub-block = 5 tiles x 32 chunks), then occupancy and the bank conflicts of the per-lane walk.
-//  * True peak on the f32 MATRIX pipe, concurrently with other waves' f64 VALU
-//    work: the polyphase FIR  y_f[n] = sum_t c_f[t] x[n-t]  over a block of BLK
-//    consecutive outputs is a banded-Toeplitz product
-//      D[(f,r), col] = sum_k A[(f,r), k] * B[k, col],
-//      A[(f,r), k] = c_f[HIST-1 + r - k],  B[k, col] = x[start_col - (HIST-1) + k],
-//    issued as v_mfma_f32_16x16x4_f32 (exact f32 fma chain).  Factor 4: 3 phases x 5
-//    outputs = 15 rows over a 16-sample window (4 MFMAs per 16 columns, 70 % of
-//    the MACs useful); factor 2: 16 outputs over a 39-sample window (10 MFMAs).
+//  * True peak at the crate's f32 width, the polyphase FIR  y_f[n] = sum_t c_f[t] x[n-t]  (an f32 fma chain per output), in the
+//    form that measured fastest for the shape (round 6):
+//      - 2 / 6 / 8 channels: on the packed-f32 VALU — a frame's pair of adjacent channels is one packed operand, a lane takes
+//        fifteen frames of one pair, taps broadcast from SGPR pairs through op_sel (SS_TP_VALU_PHASE3); factor 2 in the
+//        three-waves builds: the 24-tap branch's halves on neighbouring lanes, taps as per-lane VGPR pairs, one DPP add per result;
+//      - channel counts that do not divide sixteen, and factor 2 in the four-waves builds: plain v_fma_f32, a lane takes fifteen
+//        frames of ONE channel (SS_TP_VALU_PLAIN3);
+//      - mono, 4 and 16 channels (and the four-waves builds of whole-stream workgroups): a banded-Toeplitz product on the f32
+//        matrix pipe over a block of BLK consecutive outputs,
+//          D[(f,r), col] = sum_k A[(f,r), k] * B[k, col],  A[(f,r), k] = c_f[HIST-1 + r - k],  B[k, col] = x[start_col - (HIST-1) + k],
+//        issued as v_mfma_f32_16x16x4_f32.  Factor 4: 3 phases x 5 outputs = 15 rows over a 16-sample window (4 MFMAs per 16
+//        columns, 70 % of the MACs useful); factor 2: 16 outputs over a 39-sample window (10 MFMAs).
+//      - opt-in SS_TP_ARITH_F16X3 (factor 4; 1, 2, 4, 8 channels): three-term f16 split on v_mfma_f32_16x16x16_f16.
 //    Phase 0 of the interpolator is the identity tap: it equals the sample peak,
 //    which true_peak() maxes in anyway (analyzer.rs:159-164 -> ebur128 true_peak).
 // ============================================================================
