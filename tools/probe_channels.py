@@ -2,7 +2,7 @@ import sys
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import soundscope_amd as ssa
 from soundscope_amd import _lib as L
-for ch, ns in ((1, 2048), (2, 1024), (6, 340)):
+for ch, ns in ((1, 2048), (2, 1024), (3, 683), (4, 512), (6, 340), (8, 256), (16, 128)):
     b = ssa.Batch(48000, ch, ns, 480000, 4096, 1024, flags=L.SS_BATCH_ALL)
     b.synthesize(3, 0)
     b.run(); b.sync()
