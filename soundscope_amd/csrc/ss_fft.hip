@@ -949,6 +949,8 @@ __global__ __launch_bounds__(256, SS_FFT_PAIRW_WAVES) void k_fft4096_pairw(FftBa
     v2f tw1[16];
     tw1[1] = twn[t]; tw1[2] = twn[2 * t]; tw1[3] = twn[3 * t];
     tw1[4] = twn[4 * t]; tw1[8] = twn[8 * t]; tw1[12] = twn[12 * t];
+    tw1[5] = twn[5 * t]; tw1[6] = twn[6 * t]; tw1[7] = twn[7 * t];               // three more resident (k_fft4096_ms1's TWN = 9; round 6: -3 %,
+                                                                                 // 166 VGPRs; twelve would cost the third wave per SIMD)
     tw2s[t] = reinterpret_cast<const v2f *>(p.tw_256)[(t & 15) * (t >> 4)];      // [kb][tb]: W_256^(tb kb) at kb * 16 + tb (see k_fft4096_ms1)
     const int tb = t & 15, hi = t >> 4;
     const int tsw = SPEC_POS(t);
@@ -1044,8 +1046,11 @@ __global__ __launch_bounds__(256, SS_FFT_PAIRW_WAVES) void k_fft4096_pairw(FftBa
 #pragma unroll
         for (int ka = 1; ka < 16; ka++) {
             v2f v = z[R16(ka)];
-            if (ka & 3) v = pk_cmul(v, tw1[ka & 3]);
-            if (ka & 12) v = pk_cmul(v, tw1[ka & 12]);
+            if ((ka >> 2) == 1) v = pk_cmul(v, tw1[ka]);
+            else {
+                if (ka & 3) v = pk_cmul(v, tw1[ka & 3]);
+                if (ka & 12) v = pk_cmul(v, tw1[ka & 12]);
+            }
             xbuf[X1W(ka, tb, hi)] = v;
         }
         __syncthreads();
