@@ -804,28 +804,14 @@ __global__ __launch_bounds__(256, SS_FFT1_WAVES) void k_fft4096_ms1(FftBatchPara
         fft16(z);
         SS_PRIO_HI();
         xbuf[X1W(0, tb, hi)] = z[R16(0)];
-#ifdef SS_MS1_TWPROD
-        // experiment: the three rebuilt twiddles as products of the resident ones, computed per window OFF the data's dependent chain
-        v2f twp[16];
-#pragma unroll
-        for (int ka = 1; ka < 16; ka++)
-            if (TW6 && !tw_resident(ka)) {
-                v2f m;
-                asm volatile("v_pk_mul_f32 %1, %2, %3 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
-                             "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,0]"
-                             : "=v"(twp[ka]), "=&v"(m) : "v"(tw1[ka & 3]), "v"(tw1[ka & 12]));
-            }
-#endif
 #pragma unroll
         for (int ka = 1; ka < 16; ka++) {
             v2f v = z[R16(ka)];
             if (TW6 && !tw_resident(ka)) {
-#ifdef SS_MS1_TWPROD
-                v = pk_cmul(v, twp[ka]);
-#else
+                // (the product tw1[ka & 3] tw1[ka & 12] formed per window off the data's dependent chain, then ONE multiply of the data:
+                // measured in round 6, six interleaved repetitions: 2.996 vs 2.995 ms — nothing)
                 v = pk_cmul(v, tw1[ka & 3]);
                 v = pk_cmul(v, tw1[ka & 12]);
-#endif
             } else {
                 v = pk_cmul(v, tw1[ka]);
             }
