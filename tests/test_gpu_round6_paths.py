@@ -129,3 +129,31 @@ def test_decimation_any_samples_per_bin(oracle, rate, channels, frames, window):
         bad = np.flatnonzero(got.view(np.uint32)[~nan] != ref.view(np.uint32)[~nan])
         assert bad.size == 0, (i, bad[:8], got[~nan][bad[:8]], ref[~nan][bad[:8]])
         assert nan.any() and np.isinf(ref).any()
+
+
+def test_kernel_timing_ring_counts_every_pass_without_synchronising():
+    """ss_batch_timing_enable keeps a ring of 32 passes' event sets: passes queue back to back (bench.py times its kernels inside its
+    timed region), every pass is counted once — also beyond the ring's depth, where ss_batch_run collects first — and the results
+    of a timed pass equal an untimed one's."""
+    rate, frames = 48000, 48000
+    b = ssa.Batch(rate, 2, 8, frames, 4096, 1024, flags=L.SS_BATCH_ALL)
+    b.synthesize(3, 0)
+    b.run(); b.sync()
+    want = [(r.integrated_lufs, tuple(r.true_peak[:2])) for r in b.results()]
+    fft0 = b.fft(0).copy()
+    b.timing_enable(True)
+    base = [b.timing_read(k) for k in range(L.SS_KERNEL_COUNT)]
+    for n_pass in (5, 32, 71):                                   # inside the ring, exactly the ring, beyond it
+        for _ in range(n_pass):
+            b.run()                                              # (no sync between passes)
+        now = [b.timing_read(k) for k in range(L.SS_KERNEL_COUNT)]
+        for k in (L.SS_KERNEL_FFT, L.SS_KERNEL_TIME_DOMAIN, L.SS_KERNEL_FINALIZE):
+            ms, n = now[k][0] - base[k][0], now[k][1] - base[k][1]
+            assert n == n_pass, (k, n, n_pass)
+            assert 0.0 < ms / n < 50.0, (k, ms, n)
+        base = now
+    b.timing_enable(False)                                       # (switching the mode clears the counters)
+    b.run(); b.sync()
+    assert b.timing_read(L.SS_KERNEL_FFT) == (0.0, 0)            # an untimed pass is not counted
+    got = [(r.integrated_lufs, tuple(r.true_peak[:2])) for r in b.results()]
+    assert got == want and np.array_equal(b.fft(0), fft0)
