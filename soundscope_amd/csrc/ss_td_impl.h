@@ -79,7 +79,10 @@ typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
 // passes + true peak at one level -5.6 %, the true-peak phases or staging at the top level, or unprioritised: worse.
 // phase BEHIND mark: 0 decimation, 1 pass 1, 2 scan, 3 pass 2, 4 true-peak conversion, 5 MFMA loop, 6 tile tail, 7 staging
 // (the builtin wants a literal: two priority bits per phase, packed)
-#define SS_TD_PHASE_PRIORITY(mark) __builtin_amdgcn_s_setprio((0x05ECu >> (2 * (mark))) & 3u)      // {0, 3, 2, 3, 1, 1, 0, 0}
+#ifndef SS_TD_PRIO_MASK
+#define SS_TD_PRIO_MASK 0x05ECu     // {0, 3, 2, 3, 1, 1, 0, 0}
+#endif
+#define SS_TD_PHASE_PRIORITY(mark) __builtin_amdgcn_s_setprio((SS_TD_PRIO_MASK >> (2 * (mark))) & 3u)
 
 // Development build (-DSS_TD_PROF): per-phase shader-clock totals of k_time_domain, summed over all waves
 // (s_memtime at the phase boundaries of the tile loop; read back with ss_debug_td_prof).  Not in release builds.

@@ -132,7 +132,8 @@ def programme(seed, steps=40):
                     return fail(f"get_fft status {got if isinstance(got, int) else 'ok'} vs {ref if isinstance(ref, int) else 'ok'}")
             else:
                 if got.shape != ref.shape: return fail(f"get_fft shape {got.shape} vs {ref.shape}")
-                if ref.shape[0] and not (np.array_equal(got[:, 0], ref[:, 0]) and db_close(got[:, 1], ref[:, 1], 0.01)):
+                if ref.shape[0] and not (np.array_equal(got[:, 0], ref[:, 0]) and db_close(got[:, 1], ref[:, 1], 0.015)):      # (0.015 dB like fuzz_batch: at 70 dB under a row's peak the difference of two f32
+                                                                                                                  #  transforms of 32768 points reaches 0.01006 — seed 670448 — where the committed tests hold 0.01 at their sizes)
                     from conftest import db_report
                     return fail(f"get_fft values: x equal {np.array_equal(got[:, 0], ref[:, 0])}, (dB within 70 dB of the row peak, linear below) {db_report(got[:, 1], ref[:, 1])}, "
                                 f"row peak {ref[:, 1].max():.1f} dB, input peak {np.abs(x).max():.3g}, mean {x.mean():.3g}")
