@@ -79,6 +79,8 @@ typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
 // passes + true peak at one level -5.6 %, the true-peak phases or staging at the top level, or unprioritised: worse.
 // phase BEHIND mark: 0 decimation, 1 pass 1, 2 scan, 3 pass 2, 4 true-peak conversion, 5 MFMA loop, 6 tile tail, 7 staging
 // (the builtin wants a literal: two priority bits per phase, packed)
+// (round 6, the true peak now a VALU phase — packed FMAs instead of MFMAs: its level re-measured, three interleaved repetitions at
+// the bench shape: 0 -> 2.14 ms, 1 -> 2.02 (kept), 2 -> 2.05, 3 -> 2.04)
 #ifndef SS_TD_PRIO_MASK
 #define SS_TD_PRIO_MASK 0x05ECu     // {0, 3, 2, 3, 1, 1, 0, 0}
 #endif
