@@ -313,8 +313,11 @@ constexpr int kTdSplitWaves = 8;        // SPLIT: waves that share one streaming
 #define SS_TD_PREFETCH 8
 #endif
 constexpr int kTdPrefetch = SS_TD_PREFETCH;        // float4 per lane held in flight for the next tile
+// (round 6, with the true peak on the VALU: 3 / 5 / 6 / 10 reads per batch -> 2.16 / 2.03 / 2.05 / 2.08 ms at the bench shape on one box,
+// 15 -> +1 % on another; five is also 1-4 % better at 44.1 kHz, 5.1 and mono, 1.7 % worse at one odd length,
+// profiles/r06_ab_td_read_batch.txt)
 #ifndef SS_TD_BATCH
-#define SS_TD_BATCH 10
+#define SS_TD_BATCH 5
 #endif
 constexpr int kTdBatch = SS_TD_BATCH;          // LDS reads issued together in the sequential passes
 
